@@ -1,0 +1,86 @@
+"""Model / dataset / training configurations with the reference's JSON schema.
+
+`hpnn()` reproduces the hyper-parameters of the reference's experiments/hpnn.json (the model the headline
+benchmark is quoted on); `hpnn_neumann()` those of experiments/hpnn_neumann.json.  A user's own copy of
+those JSON files loads unchanged through `load_config(path)`: strings such as "tf.nn.leaky_relu" are kept
+as names and resolved by `poisson_cnn_amd.utils.convert_tf_object_names` through a lookup table instead of
+the reference's eval() (utils/convert_tf_object_names.py:13-18).
+"""
+import copy
+import json
+
+
+def hpnn():
+    model = {
+        'use_batchnorm': True, 'use_scaling': True, 'data_format': 'channels_first', 'postsmoother_iterations': 0,
+        'pre_bottleneck_convolutions_config': {
+            'filters': [4, 16, 32], 'kernel_sizes': [15, 13, 11], 'padding_mode': 'symmetric',
+            'activation': 'tf.nn.leaky_relu', 'use_bias': True, 'bias_initializer': 'zeros'},
+        'bottleneck_deconv_config': {
+            'downsampling_factors': [2, 3, 4, 8, 16], 'upsampling_factors': [2, 3, 4, 8, 16], 'filters': 32,
+            'conv_kernel_sizes': [11, 9, 7, 7, 7, 5], 'deconv_kernel_sizes': [2, 3, 4, 8, 16], 'n_convs': [3, 3, 3, 3, 3, 3],
+            'padding_mode': 'SYMMETRIC', 'conv_activation': 'tf.nn.leaky_relu', 'conv_use_bias': True, 'use_resnet': True,
+            'pool_downsampling_method': 'average', 'downsampling_method': 'pool'},
+        'bottleneck_multilinear_config': {
+            'downsampling_factors': [32, 64, 128], 'upsampling_factors': [32, 64, 128], 'filters': 32,
+            'conv_kernel_sizes': [5, 5, 5], 'n_convs': [3, 3, 3], 'padding_mode': 'CONSTANT', 'constant_padding_value': 0.0,
+            'conv_activation': 'tf.nn.leaky_relu', 'conv_use_bias': True, 'use_resnet': True, 'downsampling_method': 'pool',
+            'pool_downsampling_method': 'average', 'resize_methods': ['bicubic', 'bilinear', 'nearest']},
+        'final_convolutions_config': {
+            'filters': [32, 28, 24, 20, 16, 12, 8, 4, 1], 'kernel_sizes': [15, 13, 9, 7, 5, 3, 3, 3, 3],
+            'padding_mode': 'CONSTANT', 'constant_padding_value': 0.0, 'activation': 'tf.nn.leaky_relu', 'use_bias': True,
+            'bias_initializer': 'zeros'},
+        'scaling_config': {
+            'downsampling_ratio_per_stage': 3, 'stages': 3, 'filters': 4, 'spp_levels': [[2, 2], 3, 5],
+            'activation': 'tf.nn.leaky_relu', 'kernel_size': 3},
+    }
+    dataset = {
+        'batch_size': 50, 'batches_per_epoch': 200, 'random_output_shape_range': [[192, 384], [192, 384]],
+        'fourier_coeff_grid_size_range': [[1, 8], [1, 8]], 'taylor_degree_range': [[2, 6], [2, 6]],
+        'grid_spacings_range': [5e-3, 5e-2], 'homogeneous_bc': True, 'return_rhses': True, 'return_boundaries': False,
+        'return_dx': True, 'normalizations': {'rhs_max_magnitude': True, 'max_domain_size_squared': True},
+        'uniform_grid_spacing': True,
+    }
+    training = {
+        'n_epochs': 200, 'precision': 'float32', 'optimizer': 'adam',
+        'optimizer_parameters': {'learning_rate': 1e-5, 'amsgrad': False}, 'min_learning_rate': 1e-7,
+        'loss_parameters': {
+            'ndims': 2, 'data_format': 'channels_first', 'mae_loss_weight': 1.0, 'integral_loss_weight': 0.4,
+            'integral_loss_config': {'n_quadpts': 47, 'Lp_norm_power': 2},
+            'physics_informed_loss_weight': 0.0,
+            'physics_informed_loss_config': {'stencil_sizes': [5, 5], 'orders': 2, 'normalize': False},
+            'scale_sample_loss_by_target_peak_magnitude': True},
+    }
+    return {'model': model, 'dataset': dataset, 'training': training}
+
+
+def hpnn_neumann():
+    cfg = hpnn()
+    cfg['model']['bc_type'] = 'neumann'
+    for k in ('taylor_degree_range', 'homogeneous_bc', 'return_boundaries'):
+        cfg['dataset'].pop(k)
+    return cfg
+
+
+def hpnn_tiny():
+    """A reduced-width model with the same topology, for fast CPU-side tests of host logic."""
+    cfg = hpnn()
+    m = cfg['model']
+    m['pre_bottleneck_convolutions_config'].update(filters=[4, 8], kernel_sizes=[5, 3])
+    m['bottleneck_deconv_config'].update(downsampling_factors=[2, 3], upsampling_factors=[2, 3], filters=8,
+                                         conv_kernel_sizes=[5, 3], deconv_kernel_sizes=[2, 3], n_convs=[2, 2])
+    m['bottleneck_multilinear_config'].update(downsampling_factors=[4, 8, 16], upsampling_factors=[4, 8, 16], filters=8,
+                                              conv_kernel_sizes=[3, 3, 3], n_convs=[2, 2, 2])
+    m['final_convolutions_config'].update(filters=[8, 12, 4, 4, 1], kernel_sizes=[5, 3, 3, 3, 3])
+    m['scaling_config'].update(downsampling_ratio_per_stage=2, stages=2)
+    return cfg
+
+
+def load_config(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def dump_config(cfg, path):
+    with open(path, 'w') as f:
+        json.dump(copy.deepcopy(cfg), f, indent=2)

@@ -1,0 +1,206 @@
+"""The numpy oracle's ops against independent PyTorch-CPU implementations (where semantics coincide),
+hand-derived small cases (where they do not), and the autograd twin against the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import np_ops, torch_twin, hpnn, loss as oloss
+from poisson_cnn_amd import configs
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize('k,mode', [(3, 'CONSTANT'), (5, 'SYMMETRIC'), (7, 'REFLECT'), (4, 'CONSTANT'), (15, 'SYMMETRIC')])
+def test_padded_conv_vs_torch(k, mode):
+    rng = np.random.default_rng(k)
+    x = rng.standard_normal((2, 3, 17, 19))
+    w = rng.standard_normal((k, k, 3, 5))
+    b = rng.standard_normal(5)
+    got = np_ops.padded_conv2d(x, w, b, mode, 0.25, 'tf.nn.leaky_relu')
+    # independent: build the padded tensor by hand-written index maps, conv with F.conv2d
+    pb, pa = k // 2, k // 2 - (1 - k % 2)
+    def idx(n):
+        i = np.arange(-pb, n + pa)
+        if mode == 'SYMMETRIC':
+            i = np.where(i < 0, -i - 1, np.where(i >= n, 2 * n - 1 - i, i))
+        elif mode == 'REFLECT':
+            i = np.where(i < 0, -i, np.where(i >= n, 2 * n - 2 - i, i))
+        return i
+    if mode == 'CONSTANT':
+        xp = np.full((2, 3, 17 + pb + pa, 19 + pb + pa), 0.25)
+        xp[:, :, pb:pb + 17, pb:pb + 19] = x
+    else:
+        xp = x[:, :, idx(17)][:, :, :, idx(19)]
+    ref = F.conv2d(torch.tensor(xp), torch.tensor(w).permute(3, 2, 0, 1), torch.tensor(b))
+    ref = F.leaky_relu(ref, 0.2).numpy()
+    assert got.shape == (2, 5, 17, 19)
+    assert rel(got, ref) < 1e-13
+    tw = torch_twin.padded_conv2d(torch.tensor(x), w, b, mode, 0.25, 'tf.nn.leaky_relu').numpy()
+    assert rel(tw, got) < 1e-13
+
+
+def test_same_conv_vs_torch():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 4, 9, 11)); w = rng.standard_normal((5, 5, 4, 3)); b = rng.standard_normal(3)
+    ref = F.conv2d(torch.tensor(x), torch.tensor(w).permute(3, 2, 0, 1), torch.tensor(b), padding=2).numpy()
+    assert rel(np_ops.same_conv2d(x, w, b), ref) < 1e-13
+
+
+@pytest.mark.parametrize('H,W,f', [(12, 8, 2), (13, 10, 3), (7, 9, 4), (5, 6, 8), (33, 17, 16)])
+def test_pool_same(H, W, f):
+    rng = np.random.default_rng(f)
+    x = rng.standard_normal((2, 3, H, W))
+    for kind in ('average', 'max'):
+        got = np_ops.pool2d_same(x, f, kind)
+        Ho, Wo = -(-H // f), -(-W // f)
+        assert got.shape == (2, 3, Ho, Wo)
+        # independent: pad to Ho*f with NaN using TF's SAME split, nan-aware reduce
+        pty, ptx = Ho * f - H, Wo * f - W
+        xp = np.full((2, 3, Ho * f, Wo * f), np.nan)
+        xp[:, :, pty // 2:pty // 2 + H, ptx // 2:ptx // 2 + W] = x
+        blocks = xp.reshape(2, 3, Ho, f, Wo, f)
+        ref = np.nanmean(blocks, axis=(3, 5)) if kind == 'average' else np.nanmax(blocks, axis=(3, 5))
+        assert rel(got, ref) < 1e-13
+        assert rel(torch_twin.pool2d_same(torch.tensor(x), f, kind).numpy(), got) < 1e-13
+    if H % f == 0 and W % f == 0:
+        assert rel(np_ops.pool2d_same(x, f, 'average'), F.avg_pool2d(torch.tensor(x), f).numpy()) < 1e-13
+
+
+@pytest.mark.parametrize('H,W,f', [(12, 8, 2), (13, 10, 3), (7, 9, 4), (33, 17, 16)])
+def test_conv_transpose_same(H, W, f):
+    rng = np.random.default_rng(f)
+    h, w_ = -(-H // f), -(-W // f)
+    x = rng.standard_normal((2, 3, h, w_)); k = rng.standard_normal((f, f, 4, 3)); b = rng.standard_normal(4)
+    got = np_ops.conv2d_transpose_same(x, k, b, (H, W), f)
+    # independent definition: adjoint of the SAME strided forward conv (dot-product test)
+    y = rng.standard_normal((2, 4, H, W))
+    pby, pbx = (h * f - H) // 2, (w_ * f - W) // 2
+    yp = np.zeros((2, 4, h * f, w_ * f)); yp[:, :, pby:pby + H, pbx:pbx + W] = y
+    fwd = F.conv2d(torch.tensor(yp), torch.tensor(k).permute(3, 2, 0, 1), stride=f).numpy()   # (2,3,h,w): conv with HWIO = (f,f,4,3)
+    assert abs((got - b[None, :, None, None]) .ravel() @ y.ravel() - fwd.ravel() @ x.ravel()) < 1e-9 * abs(fwd.ravel() @ x.ravel()) + 1e-9
+    # pixel-shuffle closed form (k == f): out[i] = x[(i+pb)//f] k[(i+pb)%f]
+    for (i, j) in [(0, 0), (H - 1, W - 1), (H // 2, W // 3)]:
+        oi, ti, oj, tj = (i + pby) // f, (i + pby) % f, (j + pbx) // f, (j + pbx) % f
+        ref = np.einsum('nc,oc->no', x[:, :, oi, oj], k[ti, tj]) + b
+        assert np.allclose(got[:, :, i, j], ref, rtol=1e-12, atol=1e-12)
+    assert rel(torch_twin.conv2d_transpose_same(torch.tensor(x), k, b, (H, W), f).numpy(), got) < 1e-13
+
+
+def test_resize_bilinear_nearest_vs_torch():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 3, 5, 7))
+    for out in [(20, 28), (17, 23), (40, 35)]:
+        ref = F.interpolate(torch.tensor(x), size=out, mode='bilinear', align_corners=False).numpy()
+        assert rel(np_ops.resize2d(x, out, 'bilinear'), ref) < 2e-6   # weights are float32 in TF
+        ref = F.interpolate(torch.tensor(x), size=out, mode='nearest-exact').numpy()
+        assert rel(np_ops.resize2d(x, out, 'nearest'), ref) == 0.0
+
+
+def test_resize_bicubic_properties():
+    # Keys a=-0.5 half-pixel: rows sum to 1 (renormalised at the borders), reproduces constants and,
+    # away from the borders, linear ramps; interior weights match torch's bicubic with a=-0.5? torch uses -0.75,
+    # so compare against a direct evaluation of the Keys kernel instead.
+    n_in, n_out = 9, 31
+    M = np_ops.resize_matrix(n_in, n_out, 'bicubic')
+    assert np.allclose(M.sum(1), 1.0, atol=1e-6)
+    def keys(t, a=-0.5):
+        t = abs(t)
+        return ((a + 2) * t - (a + 3)) * t * t + 1 if t <= 1 else (((t - 5) * t + 8) * t - 4) * a if t < 2 else 0.0
+    scale = n_in / n_out
+    for o in range(n_out):
+        src = (o + 0.5) * scale - 0.5
+        loc = int(np.floor(src))
+        if loc - 1 < 0 or loc + 2 > n_in - 1:
+            continue
+        # table lookup quantises delta to 1/1024
+        delta = round((src - loc) * 1024) / 1024
+        ref = np.zeros(n_in)
+        for t, i in zip([1 + delta, delta, 1 - delta, 2 - delta], [loc - 1, loc, loc + 1, loc + 2]):
+            ref[i] += keys(t)
+        assert np.allclose(M[o], ref / ref.sum(), atol=2e-6)
+    # legacy align_corners bicubic (a=-0.75) hits the control points exactly
+    M2 = np_ops.resize_matrix(5, 17, 'bicubic', half_pixel=False, align_corners=True)
+    for i in range(5):
+        assert np.allclose(M2[4 * i], np.eye(5)[i], atol=1e-6)
+    ref = F.interpolate(torch.arange(5.0, dtype=torch.float64)[None, None, None].expand(1, 1, 5, 5).contiguous(), size=(17, 17),
+                        mode='bicubic', align_corners=True).numpy()[0, 0, 0]
+    assert np.allclose(M2 @ np.arange(5.0), ref, atol=1e-5)
+
+
+def test_spp_and_split_indices():
+    assert list(np_ops.split_indices(229, 4)) == [0, 58, 115, 172, 229]      # dataset/utils/split_indices.py:13
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 4, 11, 13))
+    f = np_ops.spatial_pyramid_pool(x, [[2, 2], 3, 5], 'max')
+    assert f.shape == (3, 38)
+    assert np.isclose(f[1, 0], x[1, :, :6, :7].max())
+    assert np.isclose(f[2, 3], x[2, :, 6:, 7:].max())
+    assert rel(torch_twin.spatial_pyramid_pool(torch.tensor(x), [[2, 2], 3, 5], 'max').numpy(), f) == 0
+
+
+def test_bn_dense_ring_jacobi_twin_agree():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 4, 9, 8))
+    g, b, m, v = rng.uniform(0.5, 1.5, 4), rng.standard_normal(4), rng.standard_normal(4), rng.uniform(0.5, 2, 4)
+    got = np_ops.batchnorm_inference(x, g, b, m, v)
+    ref = F.batch_norm(torch.tensor(x), torch.tensor(m), torch.tensor(v), torch.tensor(g), torch.tensor(b), False, 0.0, 1e-3).numpy()
+    assert rel(got, ref) < 1e-13
+    tr = np_ops.batchnorm_training(x, g, b)[0]
+    ref = F.batch_norm(torch.tensor(x), None, None, torch.tensor(g), torch.tensor(b), True, 0.0, 1e-3).numpy()
+    assert rel(tr, ref) < 1e-13
+    for mode in ('CONSTANT', 'SYMMETRIC'):
+        r = np_ops.bc_ring(x, mode)
+        assert np.array_equal(r[:, :, 1:-1, 1:-1], x[:, :, 1:-1, 1:-1])
+        if mode == 'CONSTANT':
+            assert np.all(r[:, :, 0] == 0) and np.all(r[:, :, :, -1] == 0)
+        else:
+            assert np.array_equal(r[:, :, 0, 1:-1], x[:, :, 1, 1:-1]) and r[0, 0, 0, 0] == x[0, 0, 1, 1]
+        assert rel(torch_twin.bc_ring(torch.tensor(x), mode).numpy(), r) == 0
+    dx = rng.uniform(0.01, 0.05, (2, 2))
+    j = np_ops.jacobi_iterations(x[:, :1], x[:, 1:2], dx, 3)
+    jt = torch_twin.jacobi_iterations(torch.tensor(x[:, :1]), x[:, 1:2], dx, 3).numpy()
+    assert rel(jt, j) < 1e-13
+    # a Jacobi fixed point: the discrete solution of lap(u) = f stays put
+    u = rng.standard_normal((1, 1, 7, 7)); d = np.array([[0.1, 0.1]])
+    lap = (u[:, :, 2:, 1:-1] + u[:, :, :-2, 1:-1] + u[:, :, 1:-1, 2:] + u[:, :, 1:-1, :-2] - 4 * u[:, :, 1:-1, 1:-1]) / 0.01
+    f = np.zeros_like(u); f[:, :, 1:-1, 1:-1] = lap
+    assert rel(np_ops.jacobi_iterations(u, f, d, 2), u) < 1e-12
+
+
+@pytest.mark.parametrize('bc', ['dirichlet', 'neumann'])
+def test_hpnn_forward_numpy_vs_twin(bc):
+    cfg = configs.hpnn_tiny()['model']
+    cfg['bc_type'] = bc
+    p = hpnn.init_params(cfg, seed=5, gain=1.5, randomize_all=True)
+    rng = np.random.default_rng(7)
+    rhs = rng.uniform(-1, 1, (2, 1, 36, 40)); dx = rng.uniform(5e-3, 5e-2, (2, 1))
+    y = hpnn.forward(np_ops, cfg, p, rhs, dx)
+    assert y.shape == rhs.shape and np.isfinite(y).all() and np.abs(y).max() > 0
+    yt = hpnn.forward(torch_twin, cfg, p, torch.tensor(rhs), torch.tensor(dx)).numpy()
+    assert rel(yt, y) < 1e-12
+    if bc == 'dirichlet':
+        assert np.all(y[:, :, 0, :] == 0) and np.all(y[:, :, :, -1] == 0)
+
+
+def test_loss_numpy_vs_twin_and_gradcheck():
+    rng = np.random.default_rng(11)
+    yt = rng.standard_normal((3, 1, 20, 24)); yp = rng.standard_normal((3, 1, 20, 24)); rhs = rng.standard_normal((3, 1, 20, 24))
+    dx = rng.uniform(0.5, 1.0, (3, 2))   # O(1) spacings keep the PI term's magnitude FD-friendly
+    lp = dict(configs.hpnn()['training']['loss_parameters'])
+    lp.update(physics_informed_loss_weight=6e-4, mse_loss_weight=0.3)
+    L = oloss.loss_wrapper(global_batch_size=6, **lp)
+    a = L(yt, yp, rhs, dx)
+    ypt = torch.tensor(yp, requires_grad=True)
+    b = L(yt, ypt, torch.tensor(rhs), dx)
+    assert abs(float(b.detach()) - a) < 1e-12 * abs(a)
+    b.backward()
+    g = ypt.grad.numpy()
+    # finite-difference spot checks of the twin's gradient against the numpy oracle
+    for idx in [(0, 0, 3, 4), (2, 0, 10, 23), (1, 0, 0, 0)]:
+        e = np.zeros_like(yp); e[idx] = 1e-6
+        fd = (L(yt, yp + e, rhs, dx) - L(yt, yp - e, rhs, dx)) / 2e-6
+        assert abs(fd - g[idx]) < 1e-6 * max(1.0, abs(g[idx]))
