@@ -1,0 +1,192 @@
+/* libpcnn - MI355X (gfx950) native kernels for the poisson_CNN hot path.  C-ABI drop-in boundary.
+ *
+ * The reference (aligirayhanozbay/poisson_CNN) has no FFI boundary of its own: every FLOP of its hot path runs
+ * inside TensorFlow ops called from Python.  Each entry point below therefore names the TensorFlow op (and the
+ * reference call site, path:line relative to poisson_CNN/) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All tensors are float32, device memory, NHWC ("channels innermost").  A tensor argument is a base pointer
+ *    plus an explicit channel stride `ld*` (floats between consecutive pixels), so a kernel can read/write a
+ *    channel slice of a wider buffer (this is how tf.concat(axis=1), models/Homogeneous_Poisson_NN_Legacy.py:224,
+ *    is realised without a copy).
+ *  - The caller owns every buffer.  The library owns only its handle (stream + last error string).
+ *  - Every call is asynchronous on the handle's stream and returns 0 on success, non-zero on error
+ *    (pcnn_last_error(handle) gives the message).  No exceptions cross the boundary.
+ *  - One handle per (thread, device, stream).
+ */
+#ifndef PCNN_H
+#define PCNN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcnn_handle_s* pcnn_handle;
+
+enum { PCNN_PAD_CONSTANT = 0, PCNN_PAD_SYMMETRIC = 1, PCNN_PAD_REFLECT = 2 };   /* tf.pad modes */
+enum { PCNN_ACT_LINEAR = 0, PCNN_ACT_LEAKY_RELU = 1, PCNN_ACT_TANH = 2, PCNN_ACT_RELU = 3 };
+enum { PCNN_POOL_AVERAGE = 0, PCNN_POOL_MAX = 1 };
+enum { PCNN_RESIZE_NEAREST = 0, PCNN_RESIZE_BILINEAR = 1, PCNN_RESIZE_BICUBIC = 2 };
+
+int pcnn_create(int device, void* hip_stream, pcnn_handle* out);
+int pcnn_destroy(pcnn_handle h);
+int pcnn_set_stream(pcnn_handle h, void* hip_stream);
+int pcnn_sync(pcnn_handle h);
+const char* pcnn_last_error(pcnn_handle h);
+int pcnn_version(void);
+
+/* ---- 2-D convolution: tf.pad + tf.nn.conv2d(VALID) + bias + activation (+ BN affine) (+ residual) ----------
+ * Replaces pad_and_apply_convolution (utils/apply_advanced_padding_and_call_conv_layer.py:16-20), Keras
+ * Conv2D(padding='same') (models/Homogeneous_Poisson_NN_Legacy.py:71,75,95; layers/Scaling.py:28), the fused
+ * BatchNormalization that follows it (blocks/resnet.py:31-36) and the residual add of blocks/resnet.py:37.
+ *   z[n,y,x,co]   = bias[co] + sum_{i,j,ci} xpad[n, y - pad_top + i, x - pad_left + j, ci] * w[i,j,ci,co]
+ *   a             = act(z);   y = a * bn_scale[co] + bn_shift[co] (if bn_scale);   y += residual (if residual)
+ * w is Keras HWIO (kh,kw,Cin,Cout), dense.  Out-of-image reads follow pad_mode (CONSTANT uses pad_value).
+ * Ho/Wo need not equal H/W (the data-gradient call uses Ho = H + kh - 1).
+ * If act_out != NULL the pre-BN activation `a` is also written there (needed by the backward pass). */
+typedef struct {
+  int N, H, W, Cin, ldx;          /* input  */
+  int Ho, Wo, Cout, ldy;          /* output */
+  int kh, kw, pad_top, pad_left;
+  int pad_mode; float pad_value;
+  int act; float act_alpha;
+  int ld_res;                     /* channel stride of residual (if given) */
+  int ld_act_out;                 /* channel stride of act_out  (if given) */
+} pcnn_conv_desc;
+
+int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias,
+                    const float* bn_scale, const float* bn_shift, const float* residual, float* y, float* act_out);
+
+/* w (kh,kw,Cin,Cout) -> wt (kh,kw,Cout,Cin) with both taps reversed: the filter of the data-gradient convolution. */
+int pcnn_conv2d_flip_transpose_weights(pcnn_handle h, const float* w, float* wt, int kh, int kw, int Cin, int Cout);
+
+/* Filter gradient of the convolution above (tf.nn.conv2d backprop-filter):
+ *   dw[i,j,ci,co] = sum_{n,y,x} xpad[n, y - pad_top + i, x - pad_left + j, ci] * dz[n,y,x,co]
+ * d describes the FORWARD convolution (x is its input, dz the gradient at its pre-activation output, ldy = its
+ * channel stride).  workspace must hold pcnn_conv2d_wgrad_workspace(d) bytes.  The result is deterministic. */
+size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d);
+int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
+                      void* workspace, size_t workspace_bytes);
+
+/* Backward of the fused epilogue: given dy (gradient at y) and the saved activation a = act(z),
+ *   dz = dy * bn_scale[c] * act'(z)      (act' recovered from a: leaky -> a>0 ? 1 : alpha, tanh -> 1-a^2)
+ * and the per-channel sums  dbias[c] = sum dz,  dgamma_hat[c] = sum dy*a,  dbeta[c] = sum dy  (the caller turns
+ * dgamma_hat/dbeta into BN gamma/beta gradients).  Any of dbias/dsum_dy_a/dsum_dy may be NULL.
+ * npix = N*H*W.  workspace: pcnn_colsum_workspace(C) bytes. */
+size_t pcnn_colsum_workspace(int C);
+int pcnn_conv2d_epilogue_bwd(pcnn_handle h, int64_t npix, int C, const float* dy, int lddy, const float* a, int lda,
+                             const float* bn_scale, int act, float act_alpha, float* dz, int lddz,
+                             float* dbias, float* dsum_dy_a, float* dsum_dy, void* workspace, size_t workspace_bytes);
+
+/* Adjoint of tf.pad SYMMETRIC / REFLECT / CONSTANT: folds the gradient on the padded domain
+ * gp (N, H+pt+pb, W+pl+pr, C) back onto the un-padded image: gx[n,y,x,c] = sum of gp over all padded positions
+ * that read (y,x).  accumulate != 0 adds into gx. */
+int pcnn_pad_fold_bwd(pcnn_handle h, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int pad_mode,
+                      const float* gp, int ldgp, float* gx, int ldgx, int accumulate);
+
+/* ---- pooling: tf.keras.layers.{Average,Max}Pooling2D(pool_size=f, strides=f, padding='same') ----------------
+ * (utils/get_pooling_method.py:3-6; blocks/bottleneck_block.py:36-37; layers/Scaling.py:29).
+ * Ho = ceil(H/f); window origin o*f - (Ho*f-H)/2; the average divides by the number of valid elements. */
+int pcnn_pool2d_fwd(pcnn_handle h, int kind, int N, int H, int W, int C, int f, const float* x, int ldx, float* y, int ldy);
+int pcnn_pool2d_bwd(pcnn_handle h, int kind, int N, int H, int W, int C, int f, const float* x, int ldx,
+                    const float* y, int ldy, const float* dy, int lddy, float* dx, int lddx, int accumulate);
+
+/* ---- transposed convolution with kernel == stride (layers/deconvupscale.py:103-108) ---------------------------
+ * tf.nn.conv2d_transpose(x, k, output_shape=(N,Cout,H,W), strides=f, padding='SAME') + bias, k is (f,f,Cout,Cin):
+ *   y[n,Y,X,co] = bias[co] + sum_ci x[n,(Y+py)/f,(X+px)/f,ci] * k[(Y+py)%f,(X+px)%f,co,ci],  py=(h*f-H)/2.
+ * y = beta*y + alpha*(...) so the 8-way branch merge (models/Homogeneous_Poisson_NN_Legacy.py:222) accumulates in place. */
+int pcnn_deconv_fwd(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* x, int ldx,
+                    const float* k, const float* bias, float alpha, float beta, float* y, int ldy);
+int pcnn_deconv_bwd_data(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* dy, int lddy,
+                         const float* k, float alpha, float* dx, int lddx);
+/* dk (f,f,Cout,Cin) and dbias (Cout) ; workspace: pcnn_deconv_wgrad_workspace bytes */
+size_t pcnn_deconv_wgrad_workspace(int N, int hc, int wc, int Cin, int Cout, int f);
+int pcnn_deconv_bwd_filter(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* x, int ldx,
+                           const float* dy, int lddy, float alpha, float* dk, float* dbias, void* workspace, size_t workspace_bytes);
+
+/* ---- tf.image.resize(antialias=False, half-pixel centres) (layers/Upsample.py:56-59) ------------------------
+ * Separable 4-tap gather: idx_y/wt_y are (Ho,4) tables, idx_x/wt_x (Wo,4) (nearest/bilinear use fewer taps with
+ * zero weights).  Tables come from pcnn_resize_tables (host, float32 arithmetic of the TF kernels).
+ * y = beta*y + alpha*resize(x). */
+int pcnn_resize_tables(int method, int n_in, int n_out, int32_t* idx /*n_out*4*/, float* wt /*n_out*4*/);
+int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* x, int ldx,
+                    const int32_t* idx_y, const float* wt_y, const int32_t* idx_x, const float* wt_x,
+                    float alpha, float beta, float* y, int ldy);
+/* dx = alpha * resize^T(dy); tmp must hold N*hc*Wo*C floats */
+int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* dy, int lddy,
+                    const int32_t* idx_y, const float* wt_y, const int32_t* idx_x, const float* wt_x,
+                    float alpha, float* tmp, float* dx, int lddx);
+
+/* ---- small dense layers (tf.keras.layers.Dense: models/Homogeneous_Poisson_NN_Legacy.py:99-102, layers/Scaling.py:31-33)
+ * y[n,o] = act(b[o] + sum_i x[n,i] w[i,o]);  bwd: given dy and y, dx, dw (+=), db (+=) */
+int pcnn_dense_fwd(pcnn_handle h, int N, int In, int Out, const float* x, const float* w, const float* b, int act, float alpha, float* y);
+int pcnn_dense_bwd(pcnn_handle h, int N, int In, int Out, const float* x, const float* w, const float* y, const float* dy,
+                   int act, float alpha, float* dx, float* dw, float* db);
+
+/* ---- elementwise / layout helpers -------------------------------------------------------------------------- */
+/* input assembly: out[n,y,x,0]=rhs, [1]=cos(pi*y/(H-1)), [2]=cos(pi*x/(W-1))  (models/..Legacy.py:172-180,198) */
+int pcnn_assemble_input(pcnn_handle h, int N, int H, int W, const float* rhs, int use_pos, float* out, int ldo);
+/* y = alpha*x + beta*y over npix x C with channel strides */
+int pcnn_axpby(pcnn_handle h, int64_t npix, int C, float alpha, const float* x, int ldx, float beta, float* y, int ldy);
+/* y[n,p,c] = x[n,p,c]*s[n,c]  (tf.einsum('ijkl,ij->ijkl'), models/..Legacy.py:231); bwd gives dx and ds */
+int pcnn_channel_scale_fwd(pcnn_handle h, int N, int64_t hw, int C, const float* x, int ldx, const float* s, float* y, int ldy);
+int pcnn_channel_scale_bwd(pcnn_handle h, int N, int64_t hw, int C, const float* x, int ldx, const float* s, const float* dy, int lddy,
+                           float* dx, int lddx, float* ds, void* workspace, size_t workspace_bytes);
+size_t pcnn_channel_scale_workspace(int N, int64_t hw, int C);
+/* per-sample scalar scale: y[n,..] = x[n,..]*(1+g[n]) (layers/Scaling.py:55); bwd: dx, dg[n] = sum dy*x */
+int pcnn_sample_scale_fwd(pcnn_handle h, int N, int64_t per, const float* x, const float* g, float* y);
+int pcnn_sample_scale_bwd(pcnn_handle h, int N, int64_t per, const float* x, const float* g, const float* dy, float* dx, float* dg);
+/* BC ring (models/..Legacy.py:251): Dirichlet -> ring = 0 ; Neumann -> ring = adjacent interior.  1 channel. */
+int pcnn_bc_ring_fwd(pcnn_handle h, int N, int H, int W, int neumann, const float* x, float* y);
+int pcnn_bc_ring_bwd(pcnn_handle h, int N, int H, int W, int neumann, const float* dy, float* dx);
+/* Spatial pyramid max-pool over channels and spatial bins (layers/SpatialPyramidPool.py:35-66).
+ * bins: nb x 4 int32 (y0,y1,x0,x1) on device; out (N, nb); argmax (N, nb) int32 flat index into (H,W,C) for bwd */
+int pcnn_spp_max_fwd(pcnn_handle h, int N, int H, int W, int C, int nb, const int32_t* bins, const float* x, float* out, int32_t* argmax);
+int pcnn_spp_max_bwd(pcnn_handle h, int N, int H, int W, int C, int nb, const int32_t* argmax, const float* dout, float* dx);
+/* Jacobi post-smoother (layers/JacobiIterationLayer.py:43-66), 3x3 second-order stencil, one sweep */
+int pcnn_jacobi_sweep(pcnn_handle h, int N, int H, int W, const float* u, const float* rhs, const float* dx /*N x 2*/, float* out);
+int pcnn_jacobi_sweep_bwd(pcnn_handle h, int N, int H, int W, const float* dout, const float* dx /*N x 2*/, float* du);
+
+/* ---- loss (losses/loss_wrapper.py:53-71, losses/integral_loss.py:126-179) --------------------------------------
+ * per-sample partial sums: out[n] = {sum|p-t|, sum (p-t)^2, sum G*(p-t)^2, max|t|}; G is the (H,W) quadrature map.
+ * bwd: dpred[n,p] = c_mae[n]*sign(p-t) + (c_mse[n] + c_int[n]*G[p]) * 2 (p-t) */
+int pcnn_loss_partials(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, float* out /*N x 4*/);
+int pcnn_loss_bwd(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G,
+                  const float* c_mae, const float* c_mse, const float* c_int, float* dpred);
+/* FD-Laplacian residual loss (losses/physics_informed_loss.py:35-50): per-sample sum of (rhs - conv(pred,kern_n))^2 over
+ * the interior; kern (N, s, s); bwd accumulates into dpred.  */
+int pcnn_pi_loss_partials(pcnn_handle h, int N, int H, int W, int s, const float* pred, const float* rhs, const float* kern, float* out /*N*/);
+int pcnn_pi_loss_bwd(pcnn_handle h, int N, int H, int W, int s, const float* pred, const float* rhs, const float* kern,
+                     const float* coef /*N*/, float* dpred);
+
+/* ---- optimizer: tf.keras.optimizers.Adam (train/utils.py:3-8), flat parameter bucket ---------------------------- */
+int pcnn_adam_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale);
+int pcnn_sgd_step(pcnn_handle h, int64_t n, float* w, const float* g, float lr, float grad_scale);
+
+/* ---- dataset: reference-solution generators (poisson_CNN/dataset) ------------------------------------------- */
+/* Dirichlet 5-point FD Poisson solve by DST-I diagonalisation; replaces multigrid_poisson_solve + poisson_RHS
+ * (dataset/solvers/multigrid.py:98-150, dataset/solvers/cholesky.py:45-119).  rhs (N,H,W); boundaries
+ * left/right (N,W) [axis -2 ends], bottom/top (N,H) [axis -1 ends]; dx (N); S_h (H-2,H-2), S_w (W-2,W-2) are the
+ * orthonormal DST-I matrices, lam_h/lam_w the eigenvalues 2-2cos(j pi/(n-1)) from pcnn_dst_setup.
+ * tmp: 2*N*(H-2)*(W-2) floats. */
+int pcnn_dst_setup(int n, float* S /*(n-2)^2 host*/, float* lam /*(n-2) host*/);
+int pcnn_fd_poisson_dst(pcnn_handle h, int N, int H, int W, const float* rhs, const float* left, const float* right,
+                        const float* bottom, const float* top, const float* dx, const float* S_h, const float* lam_h,
+                        const float* S_w, const float* lam_w, float* tmp, float* soln);
+/* Separable series synthesis out[n,a,b] = sum_{A,B} c[n,A,B] f(A x_a) g(B y_b) with f,g in {sin,cos}
+ * (dataset/utils/generate_smooth_function.py:45-62).  coef (N, ka, kb) zero-padded; trig: 0 = sin, 1 = cos.
+ * accumulate != 0 adds into out. */
+int pcnn_series_synthesis(pcnn_handle h, int N, int H, int W, int ka, int kb, const float* coef, int trig, int accumulate, float* out);
+/* out[n, :] *= target[n] / max|out[n, :]|  (dataset/utils/set_max_magnitude.py:14-25); also returns the factors */
+int pcnn_set_max_magnitude(pcnn_handle h, int N, int64_t per, const float* target, float* x, float* factors);
+/* generic batched small GEMM C[n] = A[n?] * B[n?] used by the DST (strideA/B = 0 broadcasts) */
+int pcnn_batched_gemm(pcnn_handle h, int batch, int M, int Nn, int K, const float* A, int64_t strideA, int lda, int transA,
+                      const float* B, int64_t strideB, int ldb, int transB, float* C, int64_t strideC, int ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,220 @@
+// Fused BC-padding + 2-D convolution + bias + activation (+BN affine)(+residual) as an fp32 implicit GEMM on
+// the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+//
+// Mapping (MI355X-first, not a cuDNN-style im2col):
+//   * workgroup = 256 threads = 4 waves, output tile 16 rows x 32 columns of one image, all Cout (<= 64).
+//   * GEMM M = 32 consecutive output pixels of one row (one MFMA tile), N = Cout, K = (tap, Cin chunk).
+//     Wave w owns rows 4w..4w+3 of the tile: 4 accumulators of 32x32 (64 VGPRs).
+//   * The input halo tile (16+kh-1) x (32+kw-1) x CK channels is staged ONCE per Cin chunk in LDS with the
+//     boundary-condition padding (CONSTANT / SYMMETRIC / REFLECT, tf.pad semantics) applied by the loader, so the
+//     padded tensor never exists in HBM.  Pixel stride PS = 4*odd floats makes the ds_read_b128 A-fragment reads
+//     conflict free (lane = pixel, 4 consecutive channels per lane feed 4 MFMAs).
+//   * Filter fragments (B) are read straight from global/L2 in the Keras HWIO layout: for one (tap, ci) the 32 (co)
+//     values are 128 contiguous bytes, so the B operand needs no LDS and no repacking; they are prefetched one
+//     K-step ahead in registers.
+//   * Epilogue from the accumulators: bias, activation, optional BN affine, optional residual, NHWC store with an
+//     arbitrary channel stride (so a conv can write straight into a channel slice of a concat buffer).
+#include "pcnn_internal.h"
+
+namespace {
+
+constexpr int TH = 16, TW = 32, WAVES = 4, MT = TH / WAVES;
+constexpr int MAX_LDS_BYTES = 80 * 1024;   // two workgroups per CU (160 KiB LDS)
+
+struct ConvParams {
+  const float* x; const float* w; const float* bias; const float* bn_scale; const float* bn_shift; const float* res;
+  float* y; float* act_out;
+  int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, pt, pl, pad_mode; float pad_value; int act; float alpha;
+  int ld_res, ld_act;
+  int tiles_x, tiles_y, CK, PS, vec_ok;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int half = lane >> 5, col = lane & 31;
+  int tile = blockIdx.x;
+  const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+  const int ty = tile % p.tiles_y;
+  const int n = tile / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int TR = TH + p.kh - 1, TC = TW + p.kw - 1;
+  const int PS = p.PS;
+  const int cin_pad = (p.Cin + 7) & ~7;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+
+  const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
+
+  for (int c0 = 0; c0 < cin_pad; c0 += p.CK) {
+    const int ck = min(p.CK, cin_pad - c0);
+    const int G = ck >> 2;   // float4 groups per pixel in this chunk
+    __syncthreads();         // previous chunk fully consumed
+    // ---- stage the halo tile (padding applied here)
+    for (int r = wave; r < TR; r += WAVES) {
+      const int sy = pcnn_pad_index(y0 + r - p.pt, p.H, p.pad_mode);
+      const int nel = TC * G;
+      for (int e = lane; e < nel; e += 64) {
+        const int c = e / G, g = e - c * G;
+        const int sx = pcnn_pad_index(x0 + c - p.pl, p.W, p.pad_mode);
+        const int ch = c0 + 4 * g;
+        f32x4 v;
+        if (sy < 0 || sx < 0) {
+          v[0] = ch + 0 < p.Cin ? p.pad_value : 0.f; v[1] = ch + 1 < p.Cin ? p.pad_value : 0.f;
+          v[2] = ch + 2 < p.Cin ? p.pad_value : 0.f; v[3] = ch + 3 < p.Cin ? p.pad_value : 0.f;
+        } else {
+          const float* src = xin + ((int64_t)sy * p.W + sx) * p.ldx + ch;
+          if (p.vec_ok && ch + 3 < p.Cin) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+            v[0] = ch + 0 < p.Cin ? src[0] : 0.f; v[1] = ch + 1 < p.Cin ? src[1] : 0.f;
+            v[2] = ch + 2 < p.Cin ? src[2] : 0.f; v[3] = ch + 3 < p.Cin ? src[3] : 0.f;
+          }
+        }
+        *reinterpret_cast<f32x4*>(&lds[(r * TC + c) * PS + 4 * g]) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop over (tap, 8-channel sub-chunk); B prefetched one step ahead
+    const int nsub = ck >> 3;
+    const int nsteps = p.kh * p.kw * nsub;
+    float bcur[NT][4], bnxt[NT][4];
+    auto load_b = [&](int tap, int sub, float (&b)[NT][4]) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int co = t * 32 + col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ci = c0 + sub * 8 + 4 * half + j;
+          b[t][j] = (ci < p.Cin && co < p.Cout) ? p.w[((int64_t)tap * p.Cin + ci) * p.Cout + co] : 0.f;
+        }
+      }
+    };
+    load_b(0, 0, bcur);
+    int tap = 0, sub = 0, ki = 0, kj = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      int ntap = tap, nsb = sub + 1, nki = ki, nkj = kj;
+      if (nsb == nsub) { nsb = 0; ntap = tap + 1; nkj = kj + 1; if (nkj == p.kw) { nkj = 0; nki = ki + 1; } }
+      if (s + 1 < nsteps) load_b(ntap, nsb, bnxt);
+      const float* abase = &lds[((wave * MT + ki) * TC + (col + kj)) * PS + sub * 8 + 4 * half];
+      f32x4 a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(abase + m * TC * PS);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bcur[t][j], acc[m][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bcur[t][j] = bnxt[t][j];
+      tap = ntap; sub = nsb; ki = nki; kj = nkj;
+    }
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = t * 32 + col;
+    if (co >= p.Cout) continue;
+    const float bias = p.bias ? p.bias[co] : 0.f;
+    const float sc = p.bn_scale ? p.bn_scale[co] : 1.f;
+    const float sh = p.bn_scale ? p.bn_shift[co] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oy = y0 + wave * MT + m;
+      if (oy >= p.Ho) continue;
+      const int64_t rowpix = ((int64_t)n * p.Ho + oy) * p.Wo;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ox = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
+        if (ox >= p.Wo) continue;
+        const int64_t pix = rowpix + ox;
+        float v = pcnn_act(acc[m][t][i] + bias, p.act, p.alpha);
+        if (p.act_out) p.act_out[pix * p.ld_act + co] = v;
+        v = v * sc + sh;
+        if (p.res) v += p.res[pix * p.ld_res + co];
+        p.y[pix * p.ldy + co] = v;
+      }
+    }
+  }
+}
+
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int kh, int kw, int Cin, int Cout) {
+  const int64_t total = (int64_t)kh * kw * Cin * Cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // i indexes wt (kh,kw,Cout,Cin)
+    int ci = i % Cin; int64_t r = i / Cin; int co = r % Cout; r /= Cout; int j = r % kw; int ii = r / kw;
+    wt[i] = w[(((int64_t)(kh - 1 - ii) * kw + (kw - 1 - j)) * Cin + ci) * Cout + co];
+  }
+}
+
+}  // namespace
+
+extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias,
+                               const float* bn_scale, const float* bn_shift, const float* residual, float* y, float* act_out) {
+  PCNN_REQUIRE(h, h && d && x && w && y, "pcnn_conv2d_fwd: null argument");
+  PCNN_REQUIRE(h, d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "pcnn_conv2d_fwd: empty tensor");
+  PCNN_REQUIRE(h, d->Cin >= 1 && d->Cout >= 1 && d->Cout <= 64, "pcnn_conv2d_fwd: Cout=%d unsupported (1..64)", d->Cout);
+  PCNN_REQUIRE(h, d->kh >= 1 && d->kw >= 1 && d->kh <= 31 && d->kw <= 31, "pcnn_conv2d_fwd: kernel %dx%d unsupported", d->kh, d->kw);
+  PCNN_REQUIRE(h, d->ldx >= d->Cin && d->ldy >= d->Cout, "pcnn_conv2d_fwd: channel stride smaller than channel count");
+  PCNN_REQUIRE(h, d->pad_mode >= 0 && d->pad_mode <= 2, "pcnn_conv2d_fwd: bad pad_mode %d", d->pad_mode);
+  PCNN_REQUIRE(h, (bn_scale == nullptr) == (bn_shift == nullptr), "pcnn_conv2d_fwd: bn_scale and bn_shift go together");
+  // every read must resolve inside the image: the farthest tap of the last output must be within pad reach
+  if (d->pad_mode != PCNN_PAD_CONSTANT) {
+    const int lim_y = d->pad_mode == PCNN_PAD_SYMMETRIC ? d->H : d->H - 1, lim_x = d->pad_mode == PCNN_PAD_SYMMETRIC ? d->W : d->W - 1;
+    const int pb = d->Ho - 1 - d->pad_top + d->kh - 1 - (d->H - 1), pr = d->Wo - 1 - d->pad_left + d->kw - 1 - (d->W - 1);
+    PCNN_REQUIRE(h, d->pad_top <= lim_y && pb <= lim_y && d->pad_left <= lim_x && pr <= lim_x,
+                 "pcnn_conv2d_fwd: padding exceeds what tf.pad allows for a %dx%d image", d->H, d->W);
+  }
+  ConvParams p;
+  p.x = x; p.w = w; p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.res = residual; p.y = y; p.act_out = act_out;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.ldy = d->ldy;
+  p.kh = d->kh; p.kw = d->kw; p.pt = d->pad_top; p.pl = d->pad_left; p.pad_mode = d->pad_mode; p.pad_value = d->pad_value;
+  p.act = d->act; p.alpha = d->act_alpha; p.ld_res = d->ld_res; p.ld_act = d->ld_act_out;
+  p.tiles_x = pcnn_cdiv(d->Wo, TW); p.tiles_y = pcnn_cdiv(d->Ho, TH);
+  p.vec_ok = (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const int cin_pad = (d->Cin + 7) & ~7;
+  const int TR = TH + d->kh - 1, TC = TW + d->kw - 1;
+  int CK = 8;
+  for (int cand = 64; cand >= 8; cand >>= 1) {
+    if (cin_pad % cand) continue;
+    const int ps = ((cand / 4) % 2 == 0) ? cand + 4 : cand;
+    if ((size_t)TR * TC * ps * 4 <= MAX_LDS_BYTES) { CK = cand; break; }
+  }
+  p.CK = CK; p.PS = ((CK / 4) % 2 == 0) ? CK + 4 : CK;
+  const size_t lds = (size_t)TR * TC * p.PS * 4;
+  PCNN_REQUIRE(h, lds <= 160 * 1024, "pcnn_conv2d_fwd: halo tile needs %zu B of LDS", lds);
+  const int64_t nblk = (int64_t)d->N * p.tiles_x * p.tiles_y;
+  PCNN_REQUIRE(h, nblk < (1ll << 31), "pcnn_conv2d_fwd: grid too large");
+  dim3 grid((unsigned)nblk), block(256);
+  if (d->Cout <= 32) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(conv_fwd_kernel<1>, grid, block, lds, h->stream, p);
+  } else {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(conv_fwd_kernel<2>, grid, block, lds, h->stream, p);
+  }
+  PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_fwd");
+  return 0;
+}
+
+extern "C" int pcnn_conv2d_flip_transpose_weights(pcnn_handle h, const float* w, float* wt, int kh, int kw, int Cin, int Cout) {
+  PCNN_REQUIRE(h, h && w && wt && kh > 0 && kw > 0 && Cin > 0 && Cout > 0, "pcnn_conv2d_flip_transpose_weights: bad argument");
+  const int64_t total = (int64_t)kh * kw * Cin * Cout;
+  const int blocks = (int)std::min<int64_t>(pcnn_cdiv64(total, 256), 4096);
+  hipLaunchKernelGGL(flip_transpose_kernel, dim3(blocks), dim3(256), 0, h->stream, w, wt, kh, kw, Cin, Cout);
+  PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_flip_transpose_weights");
+  return 0;
+}

@@ -1,0 +1,36 @@
+// Handle management for libpcnn.
+#include "pcnn_internal.h"
+
+extern "C" int pcnn_version(void) { return 100; }
+
+extern "C" int pcnn_create(int device, void* hip_stream, pcnn_handle* out) {
+  if (!out) return 1;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return 2;
+  if (hipSetDevice(device) != hipSuccess) return 3;
+  pcnn_handle h = new pcnn_handle_s();
+  h->device = device;
+  h->stream = static_cast<hipStream_t>(hip_stream);
+  *out = h;
+  return 0;
+}
+
+extern "C" int pcnn_destroy(pcnn_handle h) {
+  delete h;
+  return 0;
+}
+
+extern "C" int pcnn_set_stream(pcnn_handle h, void* hip_stream) {
+  if (!h) return 1;
+  h->stream = static_cast<hipStream_t>(hip_stream);
+  return 0;
+}
+
+extern "C" int pcnn_sync(pcnn_handle h) {
+  if (!h) return 1;
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) PCNN_FAIL(h, "pcnn_sync: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" const char* pcnn_last_error(pcnn_handle h) { return h ? h->err.c_str() : "null handle"; }

@@ -1,0 +1,66 @@
+// Internal helpers shared by the libpcnn translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/pcnn.h"
+
+struct pcnn_handle_s {
+  int device;
+  hipStream_t stream;
+  std::string err;
+};
+
+#define PCNN_FAIL(h, ...)                                   \
+  do {                                                      \
+    char _b[512];                                           \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);                  \
+    if (h) (h)->err = _b;                                   \
+    return 1;                                               \
+  } while (0)
+
+#define PCNN_REQUIRE(h, cond, ...) \
+  do {                             \
+    if (!(cond)) PCNN_FAIL(h, __VA_ARGS__); \
+  } while (0)
+
+#define PCNN_CHECK_LAUNCH(h, name)                                               \
+  do {                                                                           \
+    hipError_t _e = hipGetLastError();                                           \
+    if (_e != hipSuccess) PCNN_FAIL(h, "%s: %s", name, hipGetErrorString(_e));   \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pcnn_act(float v, int act, float alpha) {
+  switch (act) {
+    case PCNN_ACT_LEAKY_RELU: return v > 0.f ? v : alpha * v;
+    case PCNN_ACT_TANH: return tanhf(v);
+    case PCNN_ACT_RELU: return v > 0.f ? v : 0.f;
+    default: return v;
+  }
+}
+// derivative of the activation expressed through its OUTPUT a = act(z)
+__device__ __forceinline__ float pcnn_act_grad_from_out(float a, int act, float alpha) {
+  switch (act) {
+    case PCNN_ACT_LEAKY_RELU: return a > 0.f ? 1.f : alpha;
+    case PCNN_ACT_TANH: return 1.f - a * a;
+    case PCNN_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+    default: return 1.f;
+  }
+}
+
+// tf.pad index map.  Returns the source index in [0,n) or -1 for "use the constant".
+__device__ __forceinline__ int pcnn_pad_index(int i, int n, int mode) {
+  if (i >= 0 && i < n) return i;
+  if (mode == PCNN_PAD_CONSTANT) return -1;
+  int r;
+  if (mode == PCNN_PAD_SYMMETRIC) r = i < 0 ? -i - 1 : 2 * n - 1 - i;
+  else r = i < 0 ? -i : 2 * n - 2 - i;
+  return r < 0 ? 0 : (r >= n ? n - 1 : r);   // clamp: only reached by tile overhang that is never stored
+}
+
+static inline int pcnn_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t pcnn_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
