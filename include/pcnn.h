@@ -86,6 +86,15 @@ int pcnn_conv2d_epilogue_bwd(pcnn_handle h, int64_t npix, int C, const float* dy
 int pcnn_pad_fold_bwd(pcnn_handle h, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int pad_mode,
                       const float* gp, int ldgp, float* gx, int ldgx, int accumulate);
 
+/* Inference-mode BatchNormalization(axis=1, epsilon) folded to a per-channel affine (blocks/resnet.py:26-27,
+ * models/Homogeneous_Poisson_NN_Legacy.py:55):  scale = gamma / sqrt(var + eps), shift = beta - mean * scale, for n channels
+ * (all BN layers of a model are processed in one call).  bwd: given S1 = sum dy*a and S2 = sum dy from
+ * pcnn_conv2d_epilogue_bwd:  dgamma = (S1 - mean*S2) / sqrt(var+eps),  dbeta = S2. */
+int pcnn_bn_fold(pcnn_handle h, int n, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                 float* scale, float* shift);
+int pcnn_bn_fold_bwd(pcnn_handle h, int n, const float* s_dy_a, const float* s_dy, const float* mean, const float* var, float eps,
+                     float* dgamma, float* dbeta);
+
 /* ---- pooling: tf.keras.layers.{Average,Max}Pooling2D(pool_size=f, strides=f, padding='same') ----------------
  * (utils/get_pooling_method.py:3-6; blocks/bottleneck_block.py:36-37; layers/Scaling.py:29).
  * Ho = ceil(H/f); window origin o*f - (Ho*f-H)/2; the average divides by the number of valid elements. */

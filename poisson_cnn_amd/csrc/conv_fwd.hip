@@ -200,10 +200,10 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
   PCNN_REQUIRE(h, nblk < (1ll << 31), "pcnn_conv2d_fwd: grid too large");
   dim3 grid((unsigned)nblk), block(256);
   if (d->Cout <= 32) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(conv_fwd_kernel<1>, grid, block, lds, h->stream, p);
   } else {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(conv_fwd_kernel<2>, grid, block, lds, h->stream, p);
   }
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_fwd");

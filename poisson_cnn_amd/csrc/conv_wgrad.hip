@@ -165,7 +165,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 
 template <int MTC, int NTC, int TAPS>
 void launch_wgrad(pcnn_handle h, const WgradParams& p, const WgradPlan& pl) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MTC, NTC, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MTC, NTC, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL((wgrad_kernel<MTC, NTC, TAPS>), dim3(pl.S, p.kh, pl.gz), dim3(256), pl.lds, h->stream, p);
 }
 

@@ -1,0 +1,280 @@
+// TF-SAME pooling (stride == window) and tf.image.resize (half-pixel, antialias=False) forward/backward, NHWC.
+#include <math.h>
+#include <vector>
+#include "pcnn_internal.h"
+
+namespace {
+
+__device__ __forceinline__ void win(int o, int f, int pb, int n, int& a, int& b) {
+  a = o * f - pb; b = a + f;
+  if (a < 0) a = 0;
+  if (b > n) b = n;
+}
+
+// small windows: one thread per output element
+__global__ void pool_fwd_small_kernel(int kind, int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx,
+                                      const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy) {
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C; const int ox = r % Wo; r /= Wo; const int oy = r % Ho; const int n = r / Ho;
+    int y0, y1, x0, x1;
+    win(oy, f, pby, H, y0, y1); win(ox, f, pbx, W, x0, x1);
+    float acc = kind == PCNN_POOL_MAX ? -INFINITY : 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        const float v = x[(((int64_t)n * H + yy) * W + xx) * ldx + c];
+        acc = kind == PCNN_POOL_MAX ? fmaxf(acc, v) : acc + v;
+      }
+    if (kind == PCNN_POOL_AVERAGE) acc /= (float)((y1 - y0) * (x1 - x0));
+    y[(((int64_t)n * Ho + oy) * Wo + ox) * ldy + c] = acc;
+  }
+}
+
+// large windows: one workgroup per output pixel, threads over (window element, channel)
+__global__ __launch_bounds__(256) void pool_fwd_large_kernel(int kind, int N, int H, int W, int C, int CP, int f, int Ho, int Wo, int pby, int pbx,
+                                                             const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy) {
+  __shared__ float red[256];
+  int b = blockIdx.x;
+  const int ox = b % Wo; b /= Wo; const int oy = b % Ho; const int n = b / Ho;
+  const int tid = threadIdx.x, c = tid % CP, r = tid / CP, R = 256 / CP;
+  int y0, y1, x0, x1;
+  win(oy, f, pby, H, y0, y1); win(ox, f, pbx, W, x0, x1);
+  const int ww = x1 - x0, cnt = (y1 - y0) * ww;
+  float acc = kind == PCNN_POOL_MAX ? -INFINITY : 0.f;
+  if (c < C)
+    for (int e = r; e < cnt; e += R) {
+      const int yy = y0 + e / ww, xx = x0 + e % ww;
+      const float v = x[(((int64_t)n * H + yy) * W + xx) * ldx + c];
+      acc = kind == PCNN_POOL_MAX ? fmaxf(acc, v) : acc + v;
+    }
+  red[tid] = acc;
+  __syncthreads();
+  if (r == 0 && c < C) {
+    float t = red[c];
+    for (int q = 1; q < R; ++q) t = kind == PCNN_POOL_MAX ? fmaxf(t, red[q * CP + c]) : t + red[q * CP + c];
+    if (kind == PCNN_POOL_AVERAGE) t /= (float)cnt;
+    y[(((int64_t)n * Ho + oy) * Wo + ox) * ldy + c] = t;
+  }
+}
+
+__global__ void pool_bwd_avg_kernel(int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx, const float* __restrict__ dy, int lddy,
+                                    float* __restrict__ dx, int lddx, int accumulate) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C; const int xx = r % W; r /= W; const int yy = r % H; const int n = r / H;
+    const int oy = (yy + pby) / f, ox = (xx + pbx) / f;
+    int y0, y1, x0, x1;
+    win(oy, f, pby, H, y0, y1); win(ox, f, pbx, W, x0, x1);
+    const float g = dy[(((int64_t)n * Ho + oy) * Wo + ox) * lddy + c] / (float)((y1 - y0) * (x1 - x0));
+    float* dst = &dx[(((int64_t)n * H + yy) * W + xx) * lddx + c];
+    *dst = accumulate ? *dst + g : g;
+  }
+}
+
+// max: gradient goes to the first maximum of the window (row-major), like tf.nn.max_pool's backprop
+__global__ void pool_bwd_max_kernel(int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx, const float* __restrict__ x, int ldx,
+                                    const float* __restrict__ dy, int lddy, float* __restrict__ dx, int lddx) {
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C; const int ox = r % Wo; r /= Wo; const int oy = r % Ho; const int n = r / Ho;
+    int y0, y1, x0, x1;
+    win(oy, f, pby, H, y0, y1); win(ox, f, pbx, W, x0, x1);
+    float best = -INFINITY; int by = y0, bx = x0;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        const float v = x[(((int64_t)n * H + yy) * W + xx) * ldx + c];
+        if (v > best) { best = v; by = yy; bx = xx; }
+      }
+    dx[(((int64_t)n * H + by) * W + bx) * lddx + c] += dy[(((int64_t)n * Ho + oy) * Wo + ox) * lddy + c];   // windows are disjoint
+  }
+}
+
+__global__ void zero_strided_kernel(int64_t npix, int C, float* __restrict__ y, int ldy) {
+  const int64_t total = npix * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) y[(i / C) * ldy + i % C] = 0.f;
+}
+
+// ---------------------------------------------------------------- resize
+__global__ void resize_fwd_kernel(int N, int hc, int wc, int C, int Ho, int Wo, const float* __restrict__ x, int ldx,
+                                  const int32_t* __restrict__ iy, const float* __restrict__ wy, const int32_t* __restrict__ ix,
+                                  const float* __restrict__ wx, float alpha, float beta, float* __restrict__ y, int ldy) {
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C; const int ox = r % Wo; r /= Wo; const int oy = r % Ho; const int n = r / Ho;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float wya = wy[oy * 4 + a];
+      if (wya == 0.f) continue;
+      const float* row = x + ((int64_t)n * hc + iy[oy * 4 + a]) * wc * ldx;
+      float t = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float wxb = wx[ox * 4 + b];
+        if (wxb != 0.f) t += wxb * row[(int64_t)ix[ox * 4 + b] * ldx + c];
+      }
+      acc += wya * t;
+    }
+    float* dst = &y[(((int64_t)n * Ho + oy) * Wo + ox) * ldy + c];
+    *dst = beta == 0.f ? alpha * acc : beta * *dst + alpha * acc;
+  }
+}
+
+// pass 1 of the adjoint: tmp[n, yc, X, c] = sum_Y Ry[Y, yc] dy[n, Y, X, c]
+__global__ void resize_bwd_rows_kernel(int N, int hc, int C, int Ho, int Wo, const float* __restrict__ dy, int lddy,
+                                       const int32_t* __restrict__ iy, const float* __restrict__ wy, float* __restrict__ tmp) {
+  const int64_t total = (int64_t)N * hc * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C; const int X = r % Wo; r /= Wo; const int yc = r % hc; const int n = r / hc;
+    float acc = 0.f;
+    // only output rows whose (<= 4) taps can reach yc: conservative window around yc * (Ho/hc)
+    const float sc = (float)Ho / (float)hc;
+    int Ya = (int)floorf(((float)yc - 2.5f) * sc) - 1, Yb = (int)ceilf(((float)yc + 3.5f) * sc) + 2;
+    if (Ya < 0) Ya = 0;
+    if (Yb > Ho) Yb = Ho;
+    for (int Y = Ya; Y < Yb; ++Y) {
+      float wsum = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wsum += (iy[Y * 4 + a] == yc) ? wy[Y * 4 + a] : 0.f;
+      if (wsum != 0.f) acc += wsum * dy[(((int64_t)n * Ho + Y) * Wo + X) * lddy + c];
+    }
+    tmp[i] = acc;
+  }
+}
+
+// pass 2: dx[n, yc, xc, c] = alpha * sum_X Rx[X, xc] tmp[n, yc, X, c]
+__global__ void resize_bwd_cols_kernel(int N, int hc, int wc, int C, int Wo, const float* __restrict__ tmp, const int32_t* __restrict__ ix,
+                                       const float* __restrict__ wx, float alpha, float* __restrict__ dx, int lddx) {
+  const int64_t total = (int64_t)N * hc * wc * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; int64_t r = i / C; const int xc = r % wc; r /= wc; const int yc = r % hc; const int n = r / hc;
+    float acc = 0.f;
+    const float sc = (float)Wo / (float)wc;
+    int Xa = (int)floorf(((float)xc - 2.5f) * sc) - 1, Xb = (int)ceilf(((float)xc + 3.5f) * sc) + 2;
+    if (Xa < 0) Xa = 0;
+    if (Xb > Wo) Xb = Wo;
+    for (int X = Xa; X < Xb; ++X) {
+      float wsum = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) wsum += (ix[X * 4 + b] == xc) ? wx[X * 4 + b] : 0.f;
+      if (wsum != 0.f) acc += wsum * tmp[(((int64_t)n * hc + yc) * Wo + X) * C + c];
+    }
+    dx[(((int64_t)n * hc + yc) * wc + xc) * lddx + c] = alpha * acc;
+  }
+}
+
+static dim3 grid1d(int64_t total, int block = 256, int maxb = 16384) {
+  int64_t b = pcnn_cdiv64(total, block);
+  if (b > maxb) b = maxb;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+static int pow2_ge(int c) { int p = 1; while (p < c) p <<= 1; return p; }
+
+}  // namespace
+
+extern "C" int pcnn_pool2d_fwd(pcnn_handle h, int kind, int N, int H, int W, int C, int f, const float* x, int ldx, float* y, int ldy) {
+  PCNN_REQUIRE(h, h && x && y && f >= 1 && (kind == 0 || kind == 1), "pcnn_pool2d_fwd: bad argument");
+  const int Ho = pcnn_cdiv(H, f), Wo = pcnn_cdiv(W, f), pby = (Ho * f - H) / 2, pbx = (Wo * f - W) / 2;
+  if (f * f <= 16 || C > 256) {
+    hipLaunchKernelGGL(pool_fwd_small_kernel, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, kind, N, H, W, C, f, Ho, Wo, pby, pbx, x, ldx, y, ldy);
+  } else {
+    hipLaunchKernelGGL(pool_fwd_large_kernel, dim3((unsigned)((int64_t)N * Ho * Wo)), dim3(256), 0, h->stream, kind, N, H, W, C, pow2_ge(C), f, Ho,
+                       Wo, pby, pbx, x, ldx, y, ldy);
+  }
+  PCNN_CHECK_LAUNCH(h, "pcnn_pool2d_fwd");
+  return 0;
+}
+
+extern "C" int pcnn_pool2d_bwd(pcnn_handle h, int kind, int N, int H, int W, int C, int f, const float* x, int ldx, const float* y, int ldy,
+                               const float* dy, int lddy, float* dx, int lddx, int accumulate) {
+  PCNN_REQUIRE(h, h && dy && dx && f >= 1 && (kind == 0 || kind == 1), "pcnn_pool2d_bwd: bad argument");
+  (void)y; (void)ldy;
+  const int Ho = pcnn_cdiv(H, f), Wo = pcnn_cdiv(W, f), pby = (Ho * f - H) / 2, pbx = (Wo * f - W) / 2;
+  if (kind == PCNN_POOL_AVERAGE) {
+    hipLaunchKernelGGL(pool_bwd_avg_kernel, grid1d((int64_t)N * H * W * C), dim3(256), 0, h->stream, N, H, W, C, f, Ho, Wo, pby, pbx, dy, lddy, dx, lddx,
+                       accumulate);
+  } else {
+    PCNN_REQUIRE(h, x, "pcnn_pool2d_bwd: max pooling needs the forward input");
+    if (!accumulate) {
+      hipLaunchKernelGGL(zero_strided_kernel, grid1d((int64_t)N * H * W * C), dim3(256), 0, h->stream, (int64_t)N * H * W, C, dx, lddx);
+    }
+    hipLaunchKernelGGL(pool_bwd_max_kernel, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, N, H, W, C, f, Ho, Wo, pby, pbx, x, ldx, dy, lddy, dx,
+                       lddx);
+  }
+  PCNN_CHECK_LAUNCH(h, "pcnn_pool2d_bwd");
+  return 0;
+}
+
+// ---- host: interpolation tables in the float32 arithmetic of TF's resize kernels
+// (tensorflow/core/kernels/image/resize_{nearest_neighbor,bilinear,bicubic}_op.cc, half_pixel_centers=true)
+extern "C" int pcnn_resize_tables(int method, int n_in, int n_out, int32_t* idx, float* wt) {
+  if (!idx || !wt || n_in < 1 || n_out < 1) return 1;
+  const float scale = (float)n_in / (float)n_out;
+  static std::vector<float> table;
+  if (method == PCNN_RESIZE_BICUBIC && table.empty()) {
+    const float a = -0.5f;
+    table.resize((1024 + 1) * 2);
+    for (int i = 0; i <= 1024; ++i) {
+      float x = (float)i * 1.0f / 1024.0f;
+      table[2 * i] = ((a + 2) * x - (a + 3)) * x * x + 1;
+      x += 1.0f;
+      table[2 * i + 1] = ((a * x - 5 * a) * x + 8 * a) * x - 4 * a;
+    }
+  }
+  for (int o = 0; o < n_out; ++o) {
+    int32_t* I = idx + 4 * o; float* Wt = wt + 4 * o;
+    for (int k = 0; k < 4; ++k) { I[k] = 0; Wt[k] = 0.f; }
+    if (method == PCNN_RESIZE_NEAREST) {
+      int i = (int)floorf(((float)o + 0.5f) * scale);
+      I[0] = i < 0 ? 0 : (i > n_in - 1 ? n_in - 1 : i); Wt[0] = 1.f;
+    } else if (method == PCNN_RESIZE_BILINEAR) {
+      const float src = ((float)o + 0.5f) * scale - 0.5f;
+      const float fl = floorf(src);
+      const int lo = fl > 0.f ? (int)fl : 0;
+      const int hi = (int)fminf(ceilf(src), (float)(n_in - 1));
+      const float lerp = src - fl;
+      I[0] = lo; Wt[0] = 1.0f - lerp; I[1] = hi; Wt[1] = lerp;
+    } else if (method == PCNN_RESIZE_BICUBIC) {
+      const float src = ((float)o + 0.5f) * scale - 0.5f;
+      const int loc = (int)floorf(src);
+      const float delta = src - (float)loc;
+      const int off = (int)lrintf(delta * 1024.0f);
+      float w4[4] = {table[off * 2 + 1], table[off * 2], table[(1024 - off) * 2], table[(1024 - off) * 2 + 1]};
+      float sum = 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const int raw = loc - 1 + k;
+        const int cl = raw < 0 ? 0 : (raw > n_in - 1 ? n_in - 1 : raw);
+        if (cl != raw) w4[k] = 0.f;
+        I[k] = cl; sum += w4[k];
+      }
+      if (fabsf(sum) >= 1000.0f * 1.17549435e-38f) {
+        const float inv = 1.0f / sum;
+        for (int k = 0; k < 4; ++k) w4[k] *= inv;
+      }
+      for (int k = 0; k < 4; ++k) Wt[k] = w4[k];
+    } else {
+      return 2;
+    }
+  }
+  return 0;
+}
+
+extern "C" int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* x, int ldx, const int32_t* idx_y,
+                               const float* wt_y, const int32_t* idx_x, const float* wt_x, float alpha, float beta, float* y, int ldy) {
+  PCNN_REQUIRE(h, h && x && y && idx_y && wt_y && idx_x && wt_x, "pcnn_resize_fwd: null argument");
+  hipLaunchKernelGGL(resize_fwd_kernel, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, N, hc, wc, C, Ho, Wo, x, ldx, idx_y, wt_y, idx_x, wt_x,
+                     alpha, beta, y, ldy);
+  PCNN_CHECK_LAUNCH(h, "pcnn_resize_fwd");
+  return 0;
+}
+
+extern "C" int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* dy, int lddy, const int32_t* idx_y,
+                               const float* wt_y, const int32_t* idx_x, const float* wt_x, float alpha, float* tmp, float* dx, int lddx) {
+  PCNN_REQUIRE(h, h && dy && dx && tmp && idx_y && wt_y && idx_x && wt_x, "pcnn_resize_bwd: null argument");
+  hipLaunchKernelGGL(resize_bwd_rows_kernel, grid1d((int64_t)N * hc * Wo * C), dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
+  PCNN_CHECK_LAUNCH(h, "pcnn_resize_bwd(rows)");
+  hipLaunchKernelGGL(resize_bwd_cols_kernel, grid1d((int64_t)N * hc * wc * C), dim3(256), 0, h->stream, N, hc, wc, C, Wo, tmp, idx_x, wt_x, alpha, dx, lddx);
+  PCNN_CHECK_LAUNCH(h, "pcnn_resize_bwd(cols)");
+  return 0;
+}

@@ -1,0 +1,426 @@
+"""Layers and blocks of the Poisson CNN hot path, hosted on the libpcnn HIP kernels.
+
+Mirrors poisson_CNN/layers and poisson_CNN/blocks (reference paths relative to poisson_CNN/):
+  ConvUnit                      <- utils/apply_advanced_padding_and_call_conv_layer.py:3-21 + Keras Conv2D (+ the fused
+                                   BatchNormalization and residual add that follow it in blocks/resnet.py:29-39)
+  resnet                        <- blocks/resnet.py:6-39
+  bottleneck_block_deconvupsample / bottleneck_block_multilinearupsample <- blocks/bottleneck_block.py:8-118
+  deconvupscale                 <- layers/deconvupscale.py:8-109
+  Upsample                      <- layers/Upsample.py:14-61
+  Scaling / SpatialPyramidPool  <- layers/Scaling.py:18-55, layers/SpatialPyramidPool.py:5-66
+  JacobiIterationLayer          <- layers/JacobiIterationLayer.py:7-66
+Instead of a tracing autograd every layer has an explicit forward() that saves what backward() needs; data is NHWC
+float32 on the GPU, weights live in one flat parameter bucket (ParamStore) so that the optimizer step and the
+data-parallel all-reduce are single launches.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .utils import advanced_pad_amounts, canonical_activation, glorot_limit, same_pad_amounts, split_indices
+
+
+# ----------------------------------------------------------------------------- parameters
+class ParamStore:
+    """Ordered registry of parameters.  Physical layout: one flat fp32 buffer [conv/dense/deconv params | all BN gammas |
+    all BN betas] for the trainable ones (+ same-shaped grad / Adam moment buffers) and [all BN means | all BN variances]
+    for the moving statistics; `names` keeps the Keras-like declaration order used by get_weights()/set_weights()."""
+
+    def __init__(self):
+        self.specs = []      # (name, shape, init, kind)
+        self.bn_layers = []  # (name, channels)
+        self.finalized = False
+
+    def add(self, name, shape, init, kind='w'):
+        assert not self.finalized
+        self.specs.append((name, tuple(int(s) for s in shape), init, kind))
+        return name
+
+    def add_bn(self, name, c):
+        off = sum(ch for _, ch in self.bn_layers)
+        self.bn_layers.append((name, c))
+        for suffix, init, kind in (('gamma', 'ones', 'bn_gamma'), ('beta', 'zeros', 'bn_beta'), ('moving_mean', 'zeros', 'bn_mean'),
+                                   ('moving_variance', 'ones', 'bn_var')):
+            self.add('%s/%s' % (name, suffix), (c,), init, kind)
+        return off
+
+    @property
+    def names(self):
+        return [s[0] for s in self.specs]
+
+    def finalize(self, device):
+        nbn = sum(c for _, c in self.bn_layers)
+        self.nbn = nbn
+        nw = sum(int(np.prod(s[1])) for s in self.specs if s[3] == 'w')
+        self.n_trainable = nw + 2 * nbn
+        self.flat_w = torch.zeros(self.n_trainable, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(self.n_trainable, dtype=torch.float32, device=device)
+        self.flat_stats = torch.zeros(max(2 * nbn, 1), dtype=torch.float32, device=device)
+        self.bn_scale = torch.zeros(max(nbn, 1), dtype=torch.float32, device=device)
+        self.bn_shift = torch.zeros(max(nbn, 1), dtype=torch.float32, device=device)
+        self.bn_s1 = torch.zeros(max(nbn, 1), dtype=torch.float32, device=device)
+        self.bn_s2 = torch.zeros(max(nbn, 1), dtype=torch.float32, device=device)
+        self.w, self.g = {}, {}
+        off = 0
+        bn_off = {'bn_gamma': 0, 'bn_beta': 0, 'bn_mean': 0, 'bn_var': 0}
+        for name, shape, init, kind in self.specs:
+            n = int(np.prod(shape))
+            if kind == 'w':
+                self.w[name] = self.flat_w[off:off + n].view(shape)
+                self.g[name] = self.flat_g[off:off + n].view(shape)
+                off += n
+            elif kind in ('bn_gamma', 'bn_beta'):
+                base = nw + (0 if kind == 'bn_gamma' else nbn) + bn_off[kind]
+                self.w[name] = self.flat_w[base:base + n]
+                self.g[name] = self.flat_g[base:base + n]
+                bn_off[kind] += n
+            else:
+                base = (0 if kind == 'bn_mean' else nbn) + bn_off[kind]
+                self.w[name] = self.flat_stats[base:base + n]
+                bn_off[kind] += n
+        self.gamma_all = self.flat_w[nw:nw + nbn]
+        self.beta_all = self.flat_w[nw + nbn:nw + 2 * nbn]
+        self.dgamma_all = self.flat_g[nw:nw + nbn]
+        self.dbeta_all = self.flat_g[nw + nbn:nw + 2 * nbn]
+        self.mean_all = self.flat_stats[0:nbn]
+        self.var_all = self.flat_stats[nbn:2 * nbn]
+        self.finalized = True
+
+    def trainable_names(self):
+        return [s[0] for s in self.specs if s[3] in ('w', 'bn_gamma', 'bn_beta')]
+
+    def initialize(self, seed=0):
+        """Keras defaults: Glorot-uniform kernels (and deconv bias, layers/deconvupscale.py:37-38,60-62), zero biases,
+        BN gamma=1 beta=0 mean=0 var=1."""
+        rng = np.random.default_rng(seed)
+        for name, shape, init, kind in self.specs:
+            if init == 'glorot':
+                lim = glorot_limit(shape)
+                v = rng.uniform(-lim, lim, size=shape).astype(np.float32)
+            elif init == 'zeros':
+                v = np.zeros(shape, dtype=np.float32)
+            elif init == 'ones':
+                v = np.ones(shape, dtype=np.float32)
+            else:
+                raise ValueError(init)
+            self.w[name].copy_(torch.from_numpy(v))
+
+    def refresh_bn(self):
+        if self.nbn:
+            ops.bn_fold(self.gamma_all, self.beta_all, self.mean_all, self.var_all, self.bn_scale, self.bn_shift)
+
+    def finish_bn_grads(self):
+        if self.nbn:
+            ops.bn_fold_bwd(self.bn_s1, self.bn_s2, self.mean_all, self.var_all, self.dgamma_all, self.dbeta_all)
+
+
+class Context:
+    """Per-model scratch: workspace + the scratch filter used by data-gradient convolutions."""
+
+    def __init__(self):
+        self.ws = ops.Workspace()
+        self._wflip = None
+
+    def wflip(self, shape, device):
+        n = int(np.prod(shape))
+        if self._wflip is None or self._wflip.numel() < n:
+            self._wflip = torch.empty(n, dtype=torch.float32, device=device)
+        return self._wflip[:n].view(shape)
+
+
+# ----------------------------------------------------------------------------- conv unit
+class ConvUnit:
+    """tf.pad + Conv2D(VALID) + bias + activation [+ BatchNormalization] [+ residual] = ONE fused kernel launch."""
+
+    def __init__(self, store, ctx, name, k, cin, cout, *, pad='advanced', padding_mode='CONSTANT', pad_value=0.0, activation='linear',
+                 use_bias=True, bn_name=None):
+        self.store, self.ctx, self.name = store, ctx, name
+        self.k, self.cin, self.cout = int(k), int(cin), int(cout)
+        self.pads = advanced_pad_amounts(self.k) if pad == 'advanced' else same_pad_amounts(self.k)
+        self.mode = padding_mode.upper() if pad == 'advanced' else 'CONSTANT'
+        if self.mode not in ops.PAD_MODES:
+            raise ValueError('unknown padding mode ' + padding_mode)
+        self.pad_value = float(pad_value) if pad == 'advanced' else 0.0
+        self.act = canonical_activation(activation)
+        self.use_bias = use_bias
+        store.add(name + '/kernel', (self.k, self.k, self.cin, self.cout), 'glorot')
+        if use_bias:
+            store.add(name + '/bias', (self.cout,), 'zeros')
+        self.bn_name = bn_name
+        if bn_name is not None:
+            self.bn_off = store.add_bn(bn_name, self.cout)
+        self.saved = None
+
+    def _bn(self):
+        if self.bn_name is None:
+            return None, None
+        s = self.store
+        return s.bn_scale[self.bn_off:self.bn_off + self.cout], s.bn_shift[self.bn_off:self.bn_off + self.cout]
+
+    def forward(self, x, residual=None, out=None, training=True):
+        w = self.store.w[self.name + '/kernel']
+        b = self.store.w[self.name + '/bias'] if self.use_bias else None
+        sc, sh = self._bn()
+        N, H, W, _ = x.shape
+        if out is None:
+            out = ops.empty((N, H, W, self.cout), x.device)
+        need_a = training and (sc is not None or residual is not None)
+        a = ops.empty((N, H, W, self.cout), x.device) if need_a else None
+        ops.conv2d_fwd(x, w, b, pad_top=self.pads[0], pad_left=self.pads[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
+                       bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a)
+        if training:
+            self.saved = (x, a if a is not None else out)   # without BN/residual the output itself is the activation
+        return out
+
+    def backward(self, dy, need_dx=True, inplace=False):
+        x, a = self.saved
+        self.saved = None
+        s, g = self.store, self.store.g
+        N, H, W, _ = x.shape
+        sc, _ = self._bn()
+        dense = ops._ld(dy) == self.cout
+        dz = dy if (inplace and dense) else ops.empty((N, H, W, self.cout), dy.device)
+        s1 = s.bn_s1[self.bn_off:self.bn_off + self.cout] if sc is not None else None
+        s2 = s.bn_s2[self.bn_off:self.bn_off + self.cout] if sc is not None else None
+        trivial = self.act == 'linear' and sc is None
+        if trivial and not self.use_bias:
+            dz = dy
+        else:
+            ops.epilogue_bwd(dy, a if (self.act != 'linear' or sc is not None) else None, act=self.act, bn_scale=sc, dz=None if trivial else dz,
+                             dbias=g[self.name + '/bias'] if self.use_bias else None, s_dy_a=s1, s_dy=s2, ws=self.ctx.ws)
+            if trivial:
+                dz = dy
+        w = s.w[self.name + '/kernel']
+        ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads[0], pad_left=self.pads[0], pad_mode=self.mode, pad_value=self.pad_value,
+                         out=g[self.name + '/kernel'], ws=self.ctx.ws)
+        if not need_dx:
+            return None
+        k = self.k
+        wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((k, k, self.cout, self.cin), w.device))
+        if self.mode == 'CONSTANT':
+            return ops.conv2d_fwd(dz, wf, None, pad_top=k - 1 - self.pads[0], pad_left=k - 1 - self.pads[0])
+        gp = ops.conv2d_fwd(dz, wf, None, pad_top=k - 1, pad_left=k - 1, out_hw=(H + k - 1, W + k - 1))
+        return ops.pad_fold_bwd(gp, (H, W), (self.pads, self.pads), self.mode)
+
+
+class resnet:
+    """blocks/resnet.py:6-39: o = conv0(x); [BN0]; o = conv1(o); [BN1]; o = x + o; o = conv2(o)."""
+
+    def __init__(self, store, ctx, name, filters, kernel_size, *, use_batchnorm=False, padding_mode='constant', constant_padding_value=0.0,
+                 activation='linear', use_bias=True):
+        kw = dict(padding_mode=padding_mode, pad_value=constant_padding_value, activation=activation, use_bias=use_bias)
+        # declaration order follows the reference: the three convs, then batchnorm0, batchnorm1
+        self.c0 = ConvUnit(store, ctx, name + '/conv0', kernel_size, filters, filters, **kw)
+        self.c1 = ConvUnit(store, ctx, name + '/conv1', kernel_size, filters, filters, **kw)
+        self.c2 = ConvUnit(store, ctx, name + '/conv2', kernel_size, filters, filters, **kw)
+        if use_batchnorm:
+            for i, c in enumerate((self.c0, self.c1)):
+                c.bn_name = '%s/bn%d' % (name, i)
+                c.bn_off = store.add_bn(c.bn_name, filters)
+
+    def forward(self, x, out=None, training=True):
+        o = self.c0.forward(x, training=training)
+        o = self.c1.forward(o, residual=x, training=training)
+        return self.c2.forward(o, out=out, training=training)
+
+    def backward(self, dy, inplace=False):
+        d1 = self.c2.backward(dy, inplace=inplace)           # gradient at (x + BN1(a1))
+        d0 = self.c1.backward(d1, inplace=False)              # d1 is still needed for the skip connection
+        dx = self.c0.backward(d0, inplace=True)
+        return ops.axpby(1.0, d1, 1.0, dx)
+
+
+# ----------------------------------------------------------------------------- bottleneck blocks
+class _bottleneck_base:
+    """blocks/bottleneck_block.py:9-66 for downsampling_method='pool' + use_resnet=True (the shipped configuration)."""
+
+    def __init__(self, store, ctx, name, cin, *, downsampling_factor, filters, conv_kernel_size, n_convs=1, upsampling_factor=None,
+                 padding_mode='constant', constant_padding_value=0.0, conv_activation='linear', conv_use_bias=True, use_resnet=False,
+                 downsampling_method='conv', pool_downsampling_method='max', use_batchnorm=False, **unused):
+        if downsampling_method.lower() != 'pool' or not use_resnet:
+            raise NotImplementedError('only downsampling_method="pool" with use_resnet=True (the shipped hpnn configs) is implemented')
+        self.name, self.f = name, int(downsampling_factor)
+        self.up = int(upsampling_factor) if upsampling_factor is not None else self.f
+        self.downsampling_factor = self.f
+        self.filters = filters
+        self.pool = pool_downsampling_method.lower()
+        self.conv0 = ConvUnit(store, ctx, name + '/conv0', conv_kernel_size, cin, filters, padding_mode=padding_mode,
+                              pad_value=constant_padding_value, activation=conv_activation, use_bias=conv_use_bias)
+        self.res = [resnet(store, ctx, '%s/res%d' % (name, i), filters, conv_kernel_size, use_batchnorm=use_batchnorm, padding_mode=padding_mode,
+                           constant_padding_value=constant_padding_value, activation=conv_activation, use_bias=conv_use_bias)
+                    for i in range(n_convs - 1)]
+
+    def _down_and_convs(self, x, training):
+        self.x = x if training else None
+        o = ops.pool2d_fwd(x, self.f, self.pool)
+        o = self.conv0.forward(o, training=training)
+        for r in self.res:
+            o = r.forward(o, training=training)
+        return o
+
+    def _backward_convs_and_down(self, dcoarse, d_in):
+        d = dcoarse
+        for r in reversed(self.res):
+            d = r.backward(d, inplace=True)
+        d = self.conv0.backward(d, inplace=True)
+        ops.pool2d_bwd(self.x, d, self.f, self.pool, dx=d_in, accumulate=True)
+        self.x = None
+
+    def out_hw(self, H, W):
+        return int((H / self.f) * self.up), int((W / self.f) * self.up)   # blocks/bottleneck_block.py:82,109
+
+
+class bottleneck_block_deconvupsample(_bottleneck_base):
+    """blocks/bottleneck_block.py:88-118 + layers/deconvupscale.py."""
+
+    def __init__(self, store, ctx, name, cin, *, deconv_kernel_size, deconv_use_bias=True, **kw):
+        super().__init__(store, ctx, name, cin, **kw)
+        if int(deconv_kernel_size) != self.up:
+            raise NotImplementedError('deconvupscale is implemented for kernel_size == upsample_ratio (all shipped configs)')
+        self.store = store
+        self.ctx = ctx
+        self.deconv_use_bias = deconv_use_bias
+        store.add(name + '/deconv/kernel', (self.up, self.up, self.filters, self.filters), 'glorot')
+        if deconv_use_bias:
+            store.add(name + '/deconv/bias', (self.filters,), 'glorot')
+
+    def forward_into(self, x, merged, alpha, beta, training=True):
+        N, H, W, _ = x.shape
+        o = self._down_and_convs(x, training)
+        assert self.out_hw(H, W) == (H, W), 'deconv branch must restore the input resolution'
+        self.coarse = o if training else None
+        ops.deconv_fwd(o, self.store.w[self.name + '/deconv/kernel'], self.store.w[self.name + '/deconv/bias'] if self.deconv_use_bias else None,
+                       (H, W), self.up, alpha=alpha, beta=beta, out=merged)
+
+    def backward_from(self, dmerged, alpha, d_in):
+        g = self.store.g
+        k = self.store.w[self.name + '/deconv/kernel']
+        o = self.coarse
+        self.coarse = None
+        ops.deconv_bwd_filter(o, dmerged, self.up, alpha=alpha, dk=g[self.name + '/deconv/kernel'],
+                              dbias=g[self.name + '/deconv/bias'] if self.deconv_use_bias else None, ws=self.ctx.ws)
+        dcoarse = ops.deconv_bwd_data(dmerged, k, (o.shape[1], o.shape[2]), self.up, alpha=alpha)
+        self._backward_convs_and_down(dcoarse, d_in)
+
+
+class bottleneck_block_multilinearupsample(_bottleneck_base):
+    """blocks/bottleneck_block.py:8-86 + layers/Upsample.py (tf.image.resize, half-pixel centres)."""
+
+    def __init__(self, store, ctx, name, cin, *, resize_method='bilinear', **kw):
+        super().__init__(store, ctx, name, cin, **kw)
+        self.method = resize_method.lower()
+        if self.method not in ops.RESIZE:
+            raise ValueError('unsupported resize method ' + resize_method)
+
+    def forward_into(self, x, merged, alpha, beta, training=True):
+        N, H, W, _ = x.shape
+        o = self._down_and_convs(x, training)
+        self.coarse_hw = (o.shape[1], o.shape[2])
+        assert self.out_hw(H, W) == (H, W)
+        ops.resize_fwd(o, (H, W), self.method, alpha=alpha, beta=beta, out=merged)
+
+    def backward_from(self, dmerged, alpha, d_in):
+        dcoarse = ops.resize_bwd(dmerged, self.coarse_hw, self.method, alpha=alpha)
+        self._backward_convs_and_down(dcoarse, d_in)
+
+
+# ----------------------------------------------------------------------------- dense / scaling / jacobi
+class Dense:
+    def __init__(self, store, name, din, units, activation='linear'):
+        self.store, self.name, self.act = store, name, canonical_activation(activation)
+        store.add(name + '/kernel', (din, units), 'glorot')
+        store.add(name + '/bias', (units,), 'zeros')
+
+    def forward(self, x, training=True):
+        y = ops.dense_fwd(x, self.store.w[self.name + '/kernel'], self.store.w[self.name + '/bias'], self.act)
+        self.saved = (x, y) if training else None
+        return y
+
+    def backward(self, dy, need_dx=True):
+        x, y = self.saved
+        self.saved = None
+        g = self.store.g
+        g[self.name + '/kernel'].zero_()
+        g[self.name + '/bias'].zero_()
+        return ops.dense_bwd(x, self.store.w[self.name + '/kernel'], y, dy, self.act, g[self.name + '/kernel'], g[self.name + '/bias'], need_dx)
+
+
+class Scaling:
+    """layers/Scaling.py:18-55 with SpatialPyramidPool MAX (layers/SpatialPyramidPool.py:35-66)."""
+
+    def __init__(self, store, ctx, name='scaling', *, stages=2, downsampling_ratio_per_stage=2, spp_levels=((2, 2), 3, 5), filters=None,
+                 kernel_size=None, activation='linear', **unused):
+        self.store, self.ctx, self.name = store, ctx, name
+        self.ratio = int(downsampling_ratio_per_stage)
+        self.levels = [[lv, lv] if isinstance(lv, int) else (list(lv) * 2 if len(lv) == 1 else list(lv)) for lv in spp_levels]
+        cin = 2
+        self.convs = []
+        for i in range(stages):
+            self.convs.append(ConvUnit(store, ctx, '%s/conv%d' % (name, i), kernel_size, cin, filters, pad='same', activation=activation))
+            cin = filters
+        nfeat = sum(a * b for a, b in self.levels)
+        self.d0 = Dense(store, name + '/dense0', nfeat, 100, 'leaky_relu')
+        self.d1 = Dense(store, name + '/dense1', 100, 25, 'leaky_relu')
+        self.d2 = Dense(store, name + '/dense2', 25, 1, 'linear')
+        self._bins = {}
+
+    def _bin_table(self, H, W, device):
+        key = (H, W, str(device))
+        if key not in self._bins:
+            bins = []
+            for ly, lx in self.levels:
+                iy, ix = split_indices(H, ly), split_indices(W, lx)
+                if (np.diff(iy) <= 0).any() or (np.diff(ix) <= 0).any():
+                    raise ValueError('grid too small for the Scaling layer: a %dx%d pyramid level over a %dx%d map has empty bins' % (ly, lx, H, W))
+                bins += [[iy[a], iy[a + 1], ix[b], ix[b + 1]] for a in range(ly) for b in range(lx)]
+            self._bins[key] = torch.tensor(np.array(bins, dtype=np.int32), device=device)
+        return self._bins[key]
+
+    def forward(self, x_to_scale, other, training=True):
+        N, H, W, _ = x_to_scale.shape
+        cat = ops.empty((N, H, W, 2), x_to_scale.device)
+        ops.axpby(1.0, x_to_scale, 0.0, cat[..., 0:1])
+        ops.axpby(1.0, other, 0.0, cat[..., 1:2])
+        o = cat
+        self.pool_in = []
+        for c in self.convs:
+            o = c.forward(o, training=training)
+            self.pool_in.append(o)
+            o = ops.pool2d_fwd(o, self.ratio, 'average')
+        feats, arg = ops.spp_max_fwd(o, self._bin_table(o.shape[1], o.shape[2], o.device))
+        g = self.d2.forward(self.d1.forward(self.d0.forward(feats, training), training), training)
+        y = ops.sample_scale_fwd(x_to_scale, g)
+        self.saved = (x_to_scale, g, arg, tuple(o.shape)) if training else None
+        return y
+
+    def backward(self, dy):
+        x, g, arg, oshape = self.saved
+        self.saved = None
+        dx, dg = ops.sample_scale_bwd(x, g, dy)
+        d = self.d0.backward(self.d1.backward(self.d2.backward(dg.view(-1, 1))))
+        d = ops.spp_max_bwd(arg, d, oshape)
+        for c, pin in zip(reversed(self.convs), reversed(self.pool_in)):
+            d = ops.pool2d_bwd(pin, d, self.ratio, 'average')
+            d = c.backward(d, inplace=True)
+        self.pool_in = None
+        return ops.axpby(1.0, d[..., 0:1], 1.0, dx)   # channel 0 of the concat is x_to_scale; `other` (the rhs) needs no gradient
+
+
+class JacobiIterationLayer:
+    """layers/JacobiIterationLayer.py:7-66 for the model's ([3,3],[2,2]) stencil."""
+
+    def __init__(self, n_iterations=5):
+        self.n = int(n_iterations)
+
+    def forward(self, guess, rhs, dx2, training=True):
+        u = guess
+        for _ in range(self.n):
+            u = ops.jacobi_sweep(u, rhs, dx2)
+        self.dx2 = dx2
+        return u
+
+    def backward(self, dout):
+        d = dout
+        for _ in range(self.n):
+            d = ops.jacobi_sweep_bwd(d, self.dx2)
+        return d

@@ -1,7 +1,10 @@
-"""Thin Python wrappers over the libpcnn C-ABI.  Tensors are torch CUDA float32 in NHWC with an arbitrary channel
-stride (so channel slices of wider buffers are accepted).  torch is used for allocation and streams only."""
+"""Thin Python wrappers over the libpcnn C-ABI (include/pcnn.h).  Tensors are torch CUDA float32 in NHWC with an
+arbitrary channel stride (channel slices of wider buffers are accepted).  torch is used for allocation, streams and
+nothing else: every arithmetic op below is a HIP kernel reached through ctypes."""
+import ctypes
 from ctypes import byref, c_float, c_int, c_int64, c_size_t, c_void_p
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -9,7 +12,10 @@ from ._lib import ConvDesc
 
 PAD_MODES = {'CONSTANT': 0, 'SYMMETRIC': 1, 'REFLECT': 2}
 ACTS = {'linear': 0, 'leaky_relu': 1, 'tanh': 2, 'relu': 3}
+POOLS = {'average': 0, 'avg': 0, 'max': 1}
+RESIZE = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
 LEAKY_ALPHA = 0.2   # tf.nn.leaky_relu default
+BN_EPS = 1e-3       # tf.keras.layers.BatchNormalization default
 
 _handles = {}
 
@@ -36,7 +42,7 @@ def _p(t):
 def _chk(t, name='tensor'):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise ValueError('%s must be a CUDA float32 tensor' % name)
-    if t.stride(-1) != 1:
+    if t.dim() > 0 and t.stride(-1) != 1 and t.shape[-1] != 1:
         raise ValueError('%s must have unit channel stride (NHWC)' % name)
     return t
 
@@ -45,33 +51,362 @@ def _ld(t):
     """channel stride (floats between consecutive pixels) of an NHWC tensor; checks pixel-linear strides."""
     _chk(t)
     N, H, W, C = t.shape
-    ld = t.stride(2) if W > 1 else (t.stride(1) if H > 1 else max(C, 1))
-    if (W > 1 and t.stride(2) != ld) or (H > 1 and t.stride(1) != W * ld) or (N > 1 and t.stride(0) != H * W * ld):
+    if W > 1:
+        ld = t.stride(2)
+    elif H > 1:
+        ld = t.stride(1)
+    elif N > 1:
+        ld = t.stride(0)
+    else:
+        ld = max(C, 1)
+    if (W > 1 and t.stride(2) != ld) or (H > 1 and t.stride(1) != W * ld) or (N > 1 and t.stride(0) != H * W * ld) or ld < C:
         raise ValueError('tensor is not pixel-linear NHWC (strides %s for shape %s)' % (t.stride(), tuple(t.shape)))
     return ld
 
 
-def workspace(nbytes, device):
-    return torch.empty((max(int(nbytes), 4) + 3) // 4, dtype=torch.float32, device=device)
+def empty(shape, device='cuda'):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def zeros(shape, device='cuda'):
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+class Workspace:
+    """Grow-on-demand scratch buffer (one per model)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device='cuda'):
+        n = (int(nbytes) + 3) // 4 + 16
+        if self.buf is None or self.buf.numel() < n:
+            self.buf = None
+            self.buf = torch.empty(n, dtype=torch.float32, device=device)
+        return self.buf
+
+
+_default_ws = Workspace()
+
+
+# ----------------------------------------------------------------------------- convolution
+def conv_desc(x_shape, ldx, w_shape, out_hw, ldy, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, act='linear', ld_res=0, ld_act=0):
+    N, H, W, Cin = x_shape
+    kh, kw, ci, Cout = w_shape
+    assert ci == Cin, (ci, Cin)
+    return ConvDesc(N, H, W, Cin, ldx, out_hw[0], out_hw[1], Cout, ldy, kh, kw, pad_top, pad_left, PAD_MODES[pad_mode.upper()],
+                    float(pad_value), ACTS[act], LEAKY_ALPHA, ld_res, ld_act)
 
 
 def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CONSTANT', pad_value=0.0, act='linear',
                bn_scale=None, bn_shift=None, residual=None, out=None, act_out=None):
     N, H, W, Cin = x.shape
     kh, kw, ci, Cout = w.shape
-    assert ci == Cin and w.is_contiguous()
+    assert w.is_contiguous()
     Ho, Wo = out_hw if out_hw is not None else (H, W)
     if out is None:
-        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    d = ConvDesc(N, H, W, Cin, _ld(x), Ho, Wo, Cout, _ld(out), kh, kw, pad_top, pad_left, PAD_MODES[pad_mode.upper()],
-                 float(pad_value), ACTS[act], LEAKY_ALPHA, _ld(residual) if residual is not None else 0,
-                 _ld(act_out) if act_out is not None else 0)
+        out = empty((N, Ho, Wo, Cout), x.device)
+    d = conv_desc(x.shape, _ld(x), w.shape, (Ho, Wo), _ld(out), pad_top, pad_left, pad_mode, pad_value, act,
+                  _ld(residual) if residual is not None else 0, _ld(act_out) if act_out is not None else 0)
     handle().call('pcnn_conv2d_fwd', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out))
     return out
 
 
-def flip_transpose_weights(w):
+def flip_transpose_weights(w, out=None):
     kh, kw, ci, co = w.shape
-    wt = torch.empty((kh, kw, co, ci), dtype=torch.float32, device=w.device)
+    wt = out if out is not None else empty((kh, kw, co, ci), w.device)
     handle().call('pcnn_conv2d_flip_transpose_weights', _p(w), _p(wt), c_int(kh), c_int(kw), c_int(ci), c_int(co))
     return wt
+
+
+def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, out=None, ws=None):
+    """dw (kh,kw,Cin,Cout) of the forward conv that maps x -> dz's shape."""
+    N, Ho, Wo, Cout = dz.shape
+    d = conv_desc(x.shape, _ld(x), w_shape, (Ho, Wo), _ld(dz), pad_top, pad_left, pad_mode, pad_value)
+    lib = _lib.load()
+    nbytes = lib.pcnn_conv2d_wgrad_workspace(byref(d))
+    wsb = (ws or _default_ws).get(nbytes, x.device)
+    dw = out if out is not None else empty(tuple(w_shape), x.device)
+    assert dw.is_contiguous()
+    handle().call('pcnn_conv2d_wgrad', byref(d), _p(x), _p(dz), _p(dw), _p(wsb), c_size_t(wsb.numel() * 4))
+    return dw
+
+
+def epilogue_bwd(dy, a, *, act='linear', bn_scale=None, dz=None, dbias=None, s_dy_a=None, s_dy=None, ws=None):
+    N, H, W, C = dy.shape
+    lib = _lib.load()
+    wsb = (ws or _default_ws).get(lib.pcnn_colsum_workspace(c_int(C)), dy.device)
+    handle().call('pcnn_conv2d_epilogue_bwd', c_int64(N * H * W), c_int(C), _p(dy), c_int(_ld(dy)), _p(a), c_int(_ld(a) if a is not None else 0),
+                  _p(bn_scale), c_int(ACTS[act]), c_float(LEAKY_ALPHA), _p(dz), c_int(_ld(dz) if dz is not None else 0),
+                  _p(dbias), _p(s_dy_a), _p(s_dy), _p(wsb), c_size_t(wsb.numel() * 4))
+    return dz
+
+
+def pad_fold_bwd(gp, out_hw, pads, pad_mode, out=None, accumulate=False):
+    N, Hp, Wp, C = gp.shape
+    H, W = out_hw
+    (pt, pb), (pl, pr) = pads
+    assert Hp == H + pt + pb and Wp == W + pl + pr
+    gx = out if out is not None else empty((N, H, W, C), gp.device)
+    handle().call('pcnn_pad_fold_bwd', c_int(N), c_int(H), c_int(W), c_int(C), c_int(pt), c_int(pb), c_int(pl), c_int(pr),
+                  c_int(PAD_MODES[pad_mode.upper()]), _p(gp), c_int(_ld(gp)), _p(gx), c_int(_ld(gx)), c_int(1 if accumulate else 0))
+    return gx
+
+
+def bn_fold(gamma, beta, mean, var, scale, shift, eps=BN_EPS):
+    handle().call('pcnn_bn_fold', c_int(gamma.numel()), _p(gamma), _p(beta), _p(mean), _p(var), c_float(eps), _p(scale), _p(shift))
+
+
+def bn_fold_bwd(s1, s2, mean, var, dgamma, dbeta, eps=BN_EPS):
+    handle().call('pcnn_bn_fold_bwd', c_int(s1.numel()), _p(s1), _p(s2), _p(mean), _p(var), c_float(eps), _p(dgamma), _p(dbeta))
+
+
+# ----------------------------------------------------------------------------- pooling / deconv / resize
+def pool_out(n, f):
+    return -(-n // f)
+
+
+def pool2d_fwd(x, f, kind='average', out=None):
+    N, H, W, C = x.shape
+    y = out if out is not None else empty((N, pool_out(H, f), pool_out(W, f), C), x.device)
+    handle().call('pcnn_pool2d_fwd', c_int(POOLS[kind.lower()]), c_int(N), c_int(H), c_int(W), c_int(C), c_int(f), _p(x), c_int(_ld(x)), _p(y), c_int(_ld(y)))
+    return y
+
+
+def pool2d_bwd(x, dy, f, kind='average', dx=None, accumulate=False):
+    N, H, W, C = x.shape
+    if dx is None:
+        dx = empty((N, H, W, C), x.device)
+        accumulate = False
+    handle().call('pcnn_pool2d_bwd', c_int(POOLS[kind.lower()]), c_int(N), c_int(H), c_int(W), c_int(C), c_int(f), _p(x), c_int(_ld(x)),
+                  c_void_p(0), c_int(0), _p(dy), c_int(_ld(dy)), _p(dx), c_int(_ld(dx)), c_int(1 if accumulate else 0))
+    return dx
+
+
+def deconv_fwd(x, k, bias, out_hw, f, *, alpha=1.0, beta=0.0, out=None):
+    N, hc, wc, Cin = x.shape
+    Cout = k.shape[2]
+    H, W = out_hw
+    y = out if out is not None else empty((N, H, W, Cout), x.device)
+    handle().call('pcnn_deconv_fwd', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(x), c_int(_ld(x)),
+                  _p(k), _p(bias), c_float(alpha), c_float(beta), _p(y), c_int(_ld(y)))
+    return y
+
+
+def deconv_bwd_data(dy, k, coarse_hw, f, *, alpha=1.0, out=None):
+    N, H, W, Cout = dy.shape
+    Cin = k.shape[3]
+    hc, wc = coarse_hw
+    dx = out if out is not None else empty((N, hc, wc, Cin), dy.device)
+    handle().call('pcnn_deconv_bwd_data', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(dy), c_int(_ld(dy)),
+                  _p(k), c_float(alpha), _p(dx), c_int(_ld(dx)))
+    return dx
+
+
+def deconv_bwd_filter(x, dy, f, *, alpha=1.0, dk=None, dbias=None, ws=None):
+    N, hc, wc, Cin = x.shape
+    _, H, W, Cout = dy.shape
+    lib = _lib.load()
+    nbytes = lib.pcnn_deconv_wgrad_workspace(c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(Cout), c_int(f))
+    wsb = (ws or _default_ws).get(nbytes, x.device)
+    if dk is None:
+        dk = empty((f, f, Cout, Cin), x.device)
+    handle().call('pcnn_deconv_bwd_filter', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(x), c_int(_ld(x)),
+                  _p(dy), c_int(_ld(dy)), c_float(alpha), _p(dk), _p(dbias), _p(wsb), c_size_t(wsb.numel() * 4))
+    return dk
+
+
+_table_cache = {}
+
+
+def resize_tables(method, n_in, n_out, device):
+    key = (method, n_in, n_out, str(device))
+    t = _table_cache.get(key)
+    if t is None:
+        idx = np.zeros((n_out, 4), dtype=np.int32)
+        wt = np.zeros((n_out, 4), dtype=np.float32)
+        rc = _lib.load().pcnn_resize_tables(c_int(RESIZE[method.lower()]), c_int(n_in), c_int(n_out),
+                                           idx.ctypes.data_as(c_void_p), wt.ctypes.data_as(c_void_p))
+        if rc != 0:
+            raise RuntimeError('pcnn_resize_tables failed (%d)' % rc)
+        t = (torch.tensor(idx, device=device), torch.tensor(wt, device=device))
+        _table_cache[key] = t
+    return t
+
+
+def resize_fwd(x, out_hw, method, *, alpha=1.0, beta=0.0, out=None):
+    N, hc, wc, C = x.shape
+    Ho, Wo = out_hw
+    iy, wy = resize_tables(method, hc, Ho, x.device)
+    ix, wx = resize_tables(method, wc, Wo, x.device)
+    y = out if out is not None else empty((N, Ho, Wo, C), x.device)
+    handle().call('pcnn_resize_fwd', c_int(N), c_int(hc), c_int(wc), c_int(C), c_int(Ho), c_int(Wo), _p(x), c_int(_ld(x)), _p(iy), _p(wy), _p(ix), _p(wx),
+                  c_float(alpha), c_float(beta), _p(y), c_int(_ld(y)))
+    return y
+
+
+def resize_bwd(dy, coarse_hw, method, *, alpha=1.0, out=None):
+    N, Ho, Wo, C = dy.shape
+    hc, wc = coarse_hw
+    iy, wy = resize_tables(method, hc, Ho, dy.device)
+    ix, wx = resize_tables(method, wc, Wo, dy.device)
+    tmp = empty((N, hc, Wo, C), dy.device)
+    dx = out if out is not None else empty((N, hc, wc, C), dy.device)
+    handle().call('pcnn_resize_bwd', c_int(N), c_int(hc), c_int(wc), c_int(C), c_int(Ho), c_int(Wo), _p(dy), c_int(_ld(dy)), _p(iy), _p(wy), _p(ix), _p(wx),
+                  c_float(alpha), _p(tmp), _p(dx), c_int(_ld(dx)))
+    return dx
+
+
+# ----------------------------------------------------------------------------- dense / spp
+def dense_fwd(x, w, b, act='linear', out=None):
+    N, In = x.shape
+    Out = w.shape[1]
+    y = out if out is not None else empty((N, Out), x.device)
+    handle().call('pcnn_dense_fwd', c_int(N), c_int(In), c_int(Out), _p(x), _p(w), _p(b), c_int(ACTS[act]), c_float(LEAKY_ALPHA), _p(y))
+    return y
+
+
+def dense_bwd(x, w, y, dy, act, dw, db, need_dx=True):
+    """dw, db are ACCUMULATED into."""
+    N, In = x.shape
+    Out = w.shape[1]
+    dx = empty((N, In), x.device) if need_dx else None
+    handle().call('pcnn_dense_bwd', c_int(N), c_int(In), c_int(Out), _p(x), _p(w), _p(y), _p(dy), c_int(ACTS[act]), c_float(LEAKY_ALPHA), _p(dx), _p(dw), _p(db))
+    return dx
+
+
+def spp_max_fwd(x, bins):
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    nb = bins.shape[0]
+    out = empty((N, nb), x.device)
+    arg = torch.empty((N, nb), dtype=torch.int32, device=x.device)
+    handle().call('pcnn_spp_max_fwd', c_int(N), c_int(H), c_int(W), c_int(C), c_int(nb), _p(bins), _p(x), _p(out), _p(arg))
+    return out, arg
+
+
+def spp_max_bwd(arg, dout, x_shape):
+    N, H, W, C = x_shape
+    dx = empty((N, H, W, C), dout.device)
+    handle().call('pcnn_spp_max_bwd', c_int(N), c_int(H), c_int(W), c_int(C), c_int(arg.shape[1]), _p(arg), _p(dout), _p(dx))
+    return dx
+
+
+# ----------------------------------------------------------------------------- elementwise
+def assemble_input(rhs_nhw, use_pos=True):
+    N, H, W = rhs_nhw.shape
+    C = 3 if use_pos else 1
+    out = empty((N, H, W, C), rhs_nhw.device)
+    handle().call('pcnn_assemble_input', c_int(N), c_int(H), c_int(W), _p(rhs_nhw), c_int(1 if use_pos else 0), _p(out), c_int(C))
+    return out
+
+
+def axpby(alpha, x, beta, y):
+    """y = alpha*x + beta*y on NHWC tensors (channel slices allowed)."""
+    N, H, W, C = x.shape
+    handle().call('pcnn_axpby', c_int64(N * H * W), c_int(C), c_float(alpha), _p(x), c_int(_ld(x)), c_float(beta), _p(y), c_int(_ld(y)))
+    return y
+
+
+def axpby_flat(alpha, x, beta, y):
+    n = x.numel()
+    handle().call('pcnn_axpby', c_int64(1), c_int(n), c_float(alpha), _p(x), c_int(n), c_float(beta), _p(y), c_int(n))
+    return y
+
+
+def channel_scale_fwd(x, s, out=None):
+    N, H, W, C = x.shape
+    y = out if out is not None else empty((N, H, W, C), x.device)
+    handle().call('pcnn_channel_scale_fwd', c_int(N), c_int64(H * W), c_int(C), _p(x), c_int(_ld(x)), _p(s), _p(y), c_int(_ld(y)))
+    return y
+
+
+def channel_scale_bwd(x, s, dy, ws=None):
+    N, H, W, C = x.shape
+    lib = _lib.load()
+    wsb = (ws or _default_ws).get(lib.pcnn_channel_scale_workspace(c_int(N), c_int64(H * W), c_int(C)), x.device)
+    dx = empty((N, H, W, C), x.device)
+    ds = empty((N, C), x.device)
+    handle().call('pcnn_channel_scale_bwd', c_int(N), c_int64(H * W), c_int(C), _p(x), c_int(_ld(x)), _p(s), _p(dy), c_int(_ld(dy)), _p(dx), c_int(_ld(dx)),
+                  _p(ds), _p(wsb), c_size_t(wsb.numel() * 4))
+    return dx, ds
+
+
+def sample_scale_fwd(x, g):
+    N = x.shape[0]
+    y = torch.empty_like(x)
+    handle().call('pcnn_sample_scale_fwd', c_int(N), c_int64(x.numel() // N), _p(x), _p(g), _p(y))
+    return y
+
+
+def sample_scale_bwd(x, g, dy):
+    N = x.shape[0]
+    dx = torch.empty_like(x)
+    dg = empty((N,), x.device)
+    handle().call('pcnn_sample_scale_bwd', c_int(N), c_int64(x.numel() // N), _p(x), _p(g), _p(dy), _p(dx), _p(dg))
+    return dx, dg
+
+
+def bc_ring_fwd(x, neumann):
+    N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    y = torch.empty_like(x)
+    handle().call('pcnn_bc_ring_fwd', c_int(N), c_int(H), c_int(W), c_int(1 if neumann else 0), _p(x), _p(y))
+    return y
+
+
+def bc_ring_bwd(dy, neumann):
+    N, H, W = dy.shape[0], dy.shape[1], dy.shape[2]
+    dx = torch.empty_like(dy)
+    handle().call('pcnn_bc_ring_bwd', c_int(N), c_int(H), c_int(W), c_int(1 if neumann else 0), _p(dy), _p(dx))
+    return dx
+
+
+def jacobi_sweep(u, rhs, dx2):
+    N, H, W = u.shape[0], u.shape[1], u.shape[2]
+    out = torch.empty_like(u)
+    handle().call('pcnn_jacobi_sweep', c_int(N), c_int(H), c_int(W), _p(u), _p(rhs), _p(dx2), _p(out))
+    return out
+
+
+def jacobi_sweep_bwd(dout, dx2):
+    N, H, W = dout.shape[0], dout.shape[1], dout.shape[2]
+    du = torch.empty_like(dout)
+    handle().call('pcnn_jacobi_sweep_bwd', c_int(N), c_int(H), c_int(W), _p(dout), _p(dx2), _p(du))
+    return du
+
+
+# ----------------------------------------------------------------------------- loss / optimizer
+def loss_partials(pred, target, G):
+    N = pred.shape[0]
+    out = empty((N, 4), pred.device)
+    handle().call('pcnn_loss_partials', c_int(N), c_int64(pred.numel() // N), _p(pred), _p(target), _p(G), _p(out))
+    return out
+
+
+def loss_bwd(pred, target, G, c_mae, c_mse, c_int_, out=None):
+    N = pred.shape[0]
+    d = out if out is not None else torch.empty_like(pred)
+    handle().call('pcnn_loss_bwd', c_int(N), c_int64(pred.numel() // N), _p(pred), _p(target), _p(G), _p(c_mae), _p(c_mse), _p(c_int_), _p(d))
+    return d
+
+
+def pi_loss_partials(pred, rhs, kern):
+    N, H, W = pred.shape[0], pred.shape[-2] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[1], pred.shape[-1] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[2]
+    out = empty((N,), pred.device)
+    handle().call('pcnn_pi_loss_partials', c_int(N), c_int(H), c_int(W), c_int(kern.shape[-1]), _p(pred), _p(rhs), _p(kern), _p(out))
+    return out
+
+
+def pi_loss_bwd(pred, rhs, kern, coef, dpred):
+    N, H, W = pred.shape[0], pred.shape[-2] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[1], pred.shape[-1] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[2]
+    handle().call('pcnn_pi_loss_bwd', c_int(N), c_int(H), c_int(W), c_int(kern.shape[-1]), _p(pred), _p(rhs), _p(kern), _p(coef), _p(dpred))
+    return dpred
+
+
+def adam_step(w, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    handle().call('pcnn_adam_step', c_int64(w.numel()), _p(w), _p(g), _p(m), _p(v), c_float(lr), c_float(beta1), c_float(beta2), c_float(eps),
+                  c_int(step), c_float(grad_scale))
+
+
+def sgd_step(w, g, lr, grad_scale=1.0):
+    handle().call('pcnn_sgd_step', c_int64(w.numel()), _p(w), _p(g), c_float(lr), c_float(grad_scale))

@@ -1,0 +1,235 @@
+"""GPU parity of every libpcnn primitive (through the C-ABI) against the fp64 oracle; backward kernels are checked
+against autograd of the oracle's torch twin."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops, torch_twin, loss as oloss
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6      # per-op rel-L2 (fp32 kernels vs fp64 oracle)
+TOL_RED = 5e-6  # long fp32 reductions (filter gradients over ~1e4 pixels)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def nhwc(a):
+    return torch.tensor(np.ascontiguousarray(np.asarray(a).transpose(0, 2, 3, 1)), dtype=torch.float32, device='cuda')
+
+
+def nchw(t):
+    return t.detach().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32, device='cuda')
+
+
+def f32(a):
+    return np.asarray(a).astype(np.float32).astype(np.float64)
+
+
+BWD_CASES = [
+    (3, 8, 8, 20, 37, 'CONSTANT'), (5, 32, 32, 16, 32, 'CONSTANT'), (7, 64, 32, 19, 45, 'CONSTANT'), (15, 3, 4, 40, 50, 'SYMMETRIC'),
+    (13, 4, 16, 35, 33, 'SYMMETRIC'), (11, 16, 32, 17, 64, 'SYMMETRIC'), (13, 32, 28, 30, 41, 'CONSTANT'), (9, 28, 24, 25, 36, 'REFLECT'),
+    (3, 4, 1, 33, 31, 'CONSTANT'), (15, 32, 32, 33, 47, 'CONSTANT'), (3, 2, 4, 21, 22, 'CONSTANT'), (5, 32, 32, 2, 3, 'CONSTANT'),
+]
+
+
+@pytest.mark.parametrize('k,Cin,Cout,H,W,mode', BWD_CASES)
+def test_conv_backward_matches_autograd(k, Cin, Cout, H, W, mode):
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(k * 100 + Cin + Cout)
+    N = 2
+    x = f32(rng.standard_normal((N, Cin, H, W)))
+    w = f32(rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin))
+    dz = f32(rng.standard_normal((N, Cout, H, W)))
+    xt = torch.tensor(x, requires_grad=True); wt = torch.tensor(w, requires_grad=True)
+    y = torch_twin.padded_conv2d(xt, wt, None, mode, 0.0, 'linear')
+    (y * torch.tensor(dz)).sum().backward()
+    p = k // 2
+    xd, dzd, wd = nhwc(x), nhwc(dz), dev(w)
+    dw = ops.conv2d_wgrad(xd, dzd, w.shape, pad_top=p, pad_left=p, pad_mode=mode)
+    wflip = ops.flip_transpose_weights(wd)
+    if mode == 'CONSTANT':
+        dx = ops.conv2d_fwd(dzd, wflip, None, pad_top=k - 1 - p, pad_left=k - 1 - p)
+    else:
+        gp = ops.conv2d_fwd(dzd, wflip, None, pad_top=k - 1, pad_left=k - 1, out_hw=(H + k - 1, W + k - 1))
+        dx = ops.pad_fold_bwd(gp, (H, W), ((p, k - 1 - p), (p, k - 1 - p)), mode)
+    torch.cuda.synchronize()
+    assert rel(dw.cpu().numpy(), wt.grad.numpy()) < TOL_RED
+    assert rel(nchw(dx), xt.grad.numpy()) < TOL
+
+
+def test_epilogue_bwd_and_bn_fold():
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(0)
+    N, H, W, C = 2, 19, 23, 28
+    dy = f32(rng.standard_normal((N, H, W, C))); a = f32(rng.standard_normal((N, H, W, C)))
+    g, b, m, v = [f32(t) for t in (rng.uniform(0.5, 1.5, C), rng.standard_normal(C), rng.standard_normal(C), rng.uniform(0.5, 2, C))]
+    sc, sh = ops.empty((C,)), ops.empty((C,))
+    ops.bn_fold(dev(g), dev(b), dev(m), dev(v), sc, sh)
+    assert rel(sc.cpu().numpy(), g / np.sqrt(v + 1e-3)) < 1e-6 and rel(sh.cpu().numpy(), b - m * g / np.sqrt(v + 1e-3)) < 1e-6
+    for act, gfun in (('leaky_relu', lambda a: np.where(a > 0, 1.0, 0.2)), ('tanh', lambda a: 1 - a * a), ('linear', lambda a: np.ones_like(a))):
+        dz = ops.empty((N, H, W, C)); db, s1, s2 = ops.empty((C,)), ops.empty((C,)), ops.empty((C,))
+        ops.epilogue_bwd(dev(dy), dev(a), act=act, bn_scale=sc, dz=dz, dbias=db, s_dy_a=s1, s_dy=s2)
+        ref = dy * (g / np.sqrt(v + 1e-3)) * gfun(a)
+        assert rel(dz.cpu().numpy(), ref) < TOL
+        assert rel(db.cpu().numpy(), ref.sum((0, 1, 2))) < TOL_RED
+        assert rel(s1.cpu().numpy(), (dy * a).sum((0, 1, 2))) < TOL_RED and rel(s2.cpu().numpy(), dy.sum((0, 1, 2))) < TOL_RED
+    dg, dbt = ops.empty((C,)), ops.empty((C,))
+    ops.bn_fold_bwd(s1, s2, dev(m), dev(v), dg, dbt)
+    # autograd reference of inference BN
+    at = torch.tensor(a.transpose(0, 3, 1, 2)); gt = torch.tensor(g, requires_grad=True); bt = torch.tensor(b, requires_grad=True)
+    (torch_twin.batchnorm_inference(at, gt, bt, m, v) * torch.tensor(dy.transpose(0, 3, 1, 2))).sum().backward()
+    assert rel(dg.cpu().numpy(), gt.grad.numpy()) < 2e-5 and rel(dbt.cpu().numpy(), bt.grad.numpy()) < TOL_RED
+
+
+@pytest.mark.parametrize('H,W,f', [(12, 8, 2), (13, 10, 3), (37, 29, 4), (33, 47, 8), (33, 17, 16), (70, 90, 32), (5, 6, 8)])
+def test_pool_fwd_bwd(H, W, f):
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(f)
+    x = f32(rng.standard_normal((2, 5, H, W)))
+    for kind in ('average', 'max'):
+        xt = torch.tensor(x, requires_grad=True)
+        yt = torch_twin.pool2d_same(xt, f, kind)
+        dy = f32(rng.standard_normal(yt.shape))
+        (yt * torch.tensor(dy)).sum().backward()
+        xd = nhwc(x)
+        y = ops.pool2d_fwd(xd, f, kind)
+        assert rel(nchw(y), np_ops.pool2d_same(x, f, kind)) < TOL
+        dx = ops.pool2d_bwd(xd, nhwc(dy), f, kind)
+        assert rel(nchw(dx), xt.grad.numpy()) < TOL
+        acc = torch.ones_like(dx)
+        ops.pool2d_bwd(xd, nhwc(dy), f, kind, dx=acc, accumulate=True)
+        assert rel(nchw(acc), xt.grad.numpy() + 1.0) < TOL
+
+
+@pytest.mark.parametrize('H,W,f', [(12, 8, 2), (13, 10, 3), (37, 29, 4), (33, 47, 8), (33, 17, 16)])
+def test_deconv_fwd_bwd(H, W, f):
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(f)
+    hc, wc, Ci, Co = -(-H // f), -(-W // f), 32, 32
+    x = f32(rng.standard_normal((2, Ci, hc, wc))); k = f32(rng.standard_normal((f, f, Co, Ci)) / 6); b = f32(rng.standard_normal(Co))
+    xt, kt, bt = torch.tensor(x, requires_grad=True), torch.tensor(k, requires_grad=True), torch.tensor(b, requires_grad=True)
+    yt = torch_twin.conv2d_transpose_same(xt, kt, bt, (H, W), f)
+    dy = f32(rng.standard_normal(yt.shape))
+    (yt * torch.tensor(dy)).sum().backward()
+    alpha = 1.0 / 256
+    base = f32(rng.standard_normal((2, H, W, Co)))
+    y = dev(base).clone()
+    ops.deconv_fwd(nhwc(x), dev(k), dev(b), (H, W), f, alpha=alpha, beta=1.0, out=y)
+    assert rel(nchw(y), np_ops.conv2d_transpose_same(x, k, b, (H, W), f) * alpha + base.transpose(0, 3, 1, 2)) < TOL
+    dx = ops.deconv_bwd_data(nhwc(dy), dev(k), (hc, wc), f, alpha=alpha)
+    assert rel(nchw(dx), xt.grad.numpy() * alpha) < TOL
+    dbias = ops.empty((Co,))
+    dk = ops.deconv_bwd_filter(nhwc(x), nhwc(dy), f, alpha=alpha, dbias=dbias)
+    assert rel(dk.cpu().numpy(), kt.grad.numpy() * alpha) < TOL_RED
+    assert rel(dbias.cpu().numpy(), bt.grad.numpy() * alpha) < TOL_RED
+
+
+@pytest.mark.parametrize('method', ['nearest', 'bilinear', 'bicubic'])
+@pytest.mark.parametrize('hc,wc,Ho,Wo', [(2, 3, 64, 70), (5, 7, 33, 41), (1, 1, 40, 36), (8, 8, 128, 128)])
+def test_resize_fwd_bwd(method, hc, wc, Ho, Wo):
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(hc * 10 + wc)
+    x = f32(rng.standard_normal((2, 6, hc, wc)))
+    ref = np_ops.resize2d(x, (Ho, Wo), method)
+    y = ops.resize_fwd(nhwc(x), (Ho, Wo), method)
+    assert rel(nchw(y), ref) < TOL
+    dy = f32(rng.standard_normal(ref.shape))
+    xt = torch.tensor(x, requires_grad=True)
+    (torch_twin.resize2d(xt, (Ho, Wo), method) * torch.tensor(dy)).sum().backward()
+    dx = ops.resize_bwd(nhwc(dy), (hc, wc), method, alpha=0.5)
+    assert rel(nchw(dx), 0.5 * xt.grad.numpy()) < TOL_RED
+
+
+def test_dense_spp_scales_ring_jacobi():
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(4)
+    # dense
+    x = f32(rng.standard_normal((5, 38))); w = f32(rng.standard_normal((38, 100)) / 6); b = f32(rng.standard_normal(100))
+    for act in ('leaky_relu', 'linear'):
+        xt, wt, bt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True), torch.tensor(b, requires_grad=True)
+        yt = torch_twin.dense(xt, wt, bt, act); dy = f32(rng.standard_normal(yt.shape)); (yt * torch.tensor(dy)).sum().backward()
+        y = ops.dense_fwd(dev(x), dev(w), dev(b), act)
+        assert rel(y.cpu().numpy(), yt.detach().numpy()) < TOL
+        dw, db = ops.zeros((38, 100)), ops.zeros((100,))
+        dx = ops.dense_bwd(dev(x), dev(w), y, dev(dy), act, dw, db)
+        assert rel(dx.cpu().numpy(), xt.grad.numpy()) < TOL and rel(dw.cpu().numpy(), wt.grad.numpy()) < TOL and rel(db.cpu().numpy(), bt.grad.numpy()) < TOL
+    # spp
+    xs = f32(rng.standard_normal((3, 4, 11, 13)))
+    levels = [[2, 2], 3, 5]
+    bins = []
+    for lv in levels:
+        lv = [lv, lv] if isinstance(lv, int) else lv
+        iy, ix = np_ops.split_indices(11, lv[0]), np_ops.split_indices(13, lv[1])
+        bins += [[iy[a], iy[a + 1], ix[c], ix[c + 1]] for a in range(lv[0]) for c in range(lv[1])]
+    bins_d = torch.tensor(np.array(bins, dtype=np.int32), device='cuda')
+    out, arg = ops.spp_max_fwd(nhwc(xs), bins_d)
+    assert rel(out.cpu().numpy(), np_ops.spatial_pyramid_pool(xs, levels, 'max')) == 0
+    xt = torch.tensor(xs, requires_grad=True); ft = torch_twin.spatial_pyramid_pool(xt, levels, 'max'); df = f32(rng.standard_normal(ft.shape))
+    (ft * torch.tensor(df)).sum().backward()
+    assert rel(nchw(ops.spp_max_bwd(arg, dev(df), (3, 11, 13, 4))), xt.grad.numpy()) < TOL
+    # channel scale / sample scale
+    xc = f32(rng.standard_normal((3, 9, 10, 32))); s = f32(rng.standard_normal((3, 32))); dyc = f32(rng.standard_normal(xc.shape))
+    assert rel(ops.channel_scale_fwd(dev(xc), dev(s)).cpu().numpy(), xc * s[:, None, None, :]) < TOL
+    dxc, dsc = ops.channel_scale_bwd(dev(xc), dev(s), dev(dyc))
+    assert rel(dxc.cpu().numpy(), dyc * s[:, None, None, :]) < TOL and rel(dsc.cpu().numpy(), (dyc * xc).sum((1, 2))) < TOL_RED
+    g = f32(rng.standard_normal(3)); x1 = f32(rng.standard_normal((3, 9, 10, 1))); d1 = f32(rng.standard_normal(x1.shape))
+    assert rel(ops.sample_scale_fwd(dev(x1), dev(g)).cpu().numpy(), x1 * (1 + g)[:, None, None, None]) < TOL
+    dx1, dg = ops.sample_scale_bwd(dev(x1), dev(g), dev(d1))
+    assert rel(dx1.cpu().numpy(), d1 * (1 + g)[:, None, None, None]) < TOL and rel(dg.cpu().numpy(), (d1 * x1).sum((1, 2, 3))) < TOL_RED
+    # bc ring fwd/bwd, jacobi fwd/bwd (adjoint via autograd of the twin)
+    u = f32(rng.standard_normal((2, 1, 9, 7))); r = f32(rng.standard_normal(u.shape)); dxx = f32(rng.uniform(0.05, 0.1, (2, 2)))
+    for neumann, mode in ((False, 'CONSTANT'), (True, 'SYMMETRIC')):
+        ut = torch.tensor(u, requires_grad=True); (torch_twin.bc_ring(ut, mode) * torch.tensor(r)).sum().backward()
+        assert rel(ops.bc_ring_fwd(nhwc(u), neumann).cpu().numpy()[..., 0], np_ops.bc_ring(u, mode)[:, 0]) == 0
+        assert rel(ops.bc_ring_bwd(nhwc(r), neumann).cpu().numpy()[..., 0], ut.grad.numpy()[:, 0]) < TOL
+    ut = torch.tensor(u, requires_grad=True); jt = torch_twin.jacobi_iterations(ut, r, dxx, 1); dj = f32(rng.standard_normal(u.shape))
+    (jt * torch.tensor(dj)).sum().backward()
+    assert rel(ops.jacobi_sweep(nhwc(u), nhwc(r), dev(dxx)).cpu().numpy()[..., 0], np_ops.jacobi_iterations(u, r, dxx, 1)[:, 0]) < TOL
+    assert rel(ops.jacobi_sweep_bwd(nhwc(dj), dev(dxx)).cpu().numpy()[..., 0], ut.grad.numpy()[:, 0]) < TOL
+
+
+def test_assemble_axpby_adam():
+    from poisson_cnn_amd import ops
+    from oracle import hpnn
+    rng = np.random.default_rng(8)
+    rhs = f32(rng.standard_normal((2, 17, 23)))
+    got = ops.assemble_input(dev(rhs)).cpu().numpy()
+    ref = np.concatenate([rhs[:, None], hpnn.position_embeddings(np_ops, 2, 17, 23)], 1).transpose(0, 2, 3, 1)
+    assert rel(got, ref) < TOL
+    x = f32(rng.standard_normal((2, 5, 6, 8))); buf = f32(rng.standard_normal((2, 5, 6, 16)))
+    yb = dev(buf)
+    ops.axpby(0.5, dev(x), 2.0, yb[..., 8:])
+    ref = buf.copy(); ref[..., 8:] = 0.5 * x + 2.0 * buf[..., 8:]
+    assert rel(yb.cpu().numpy(), ref) < TOL
+    n = 1000
+    w, g = f32(rng.standard_normal(n)), f32(rng.standard_normal(n))
+    wd, md, vd = dev(w), ops.zeros((n,)), ops.zeros((n,))
+    m = np.zeros(n); v = np.zeros(n); wr = w.copy()
+    for t in range(1, 4):
+        ops.adam_step(wd, dev(g), md, vd, 1e-3, 0.9, 0.999, 1e-7, t)
+        m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
+        wr = wr - 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-7)
+    assert rel(wd.cpu().numpy(), wr) < TOL
+
+
+def test_loss_partials_and_bwd():
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(12)
+    N, H, W = 3, 40, 52
+    yt, yp = f32(rng.standard_normal((N, 1, H, W))), f32(rng.standard_normal((N, 1, H, W)))
+    G = oloss.integral_weight_map((H, W), 47)
+    part = ops.loss_partials(dev(yp), dev(yt), dev(G)).cpu().numpy()
+    d = yp - yt
+    ref = np.stack([np.abs(d).sum((1, 2, 3)), (d * d).sum((1, 2, 3)), (G * d * d).sum((1, 2, 3)), np.abs(yt).max((1, 2, 3))], 1)
+    assert rel(part, ref) < TOL_RED
+    cm, cs, ci = f32(rng.uniform(0.1, 1, N)), f32(rng.uniform(0.1, 1, N)), f32(rng.uniform(0.1, 1, N))
+    g = ops.loss_bwd(dev(yp), dev(yt), dev(G), dev(cm), dev(cs), dev(ci)).cpu().numpy()
+    refg = cm[:, None, None, None] * np.sign(d) + 2 * d * (cs[:, None, None, None] + ci[:, None, None, None] * G)
+    assert rel(g, refg) < TOL
