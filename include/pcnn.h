@@ -28,7 +28,8 @@ typedef struct pcnn_handle_s* pcnn_handle;
 enum { PCNN_PAD_CONSTANT = 0, PCNN_PAD_SYMMETRIC = 1, PCNN_PAD_REFLECT = 2 };   /* tf.pad modes */
 enum { PCNN_ACT_LINEAR = 0, PCNN_ACT_LEAKY_RELU = 1, PCNN_ACT_TANH = 2, PCNN_ACT_RELU = 3 };
 enum { PCNN_POOL_AVERAGE = 0, PCNN_POOL_MAX = 1 };
-enum { PCNN_RESIZE_NEAREST = 0, PCNN_RESIZE_BILINEAR = 1, PCNN_RESIZE_BICUBIC = 2 };
+enum { PCNN_RESIZE_NEAREST = 0, PCNN_RESIZE_BILINEAR = 1, PCNN_RESIZE_BICUBIC = 2,
+       PCNN_RESIZE_BICUBIC_LEGACY_ALIGN_CORNERS = 3 /* tf.compat.v1 resize_images(align_corners=True), dataset/utils/image_resize.py:20 */ };
 
 int pcnn_create(int device, void* hip_stream, pcnn_handle* out);
 int pcnn_destroy(pcnn_handle h);
@@ -164,6 +165,12 @@ int pcnn_jacobi_sweep_bwd(pcnn_handle h, int N, int H, int W, const float* dout,
 int pcnn_loss_partials(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, float* out /*N x 4*/);
 int pcnn_loss_bwd(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G,
                   const float* c_mae, const float* c_mse, const float* c_int, float* dpred);
+/* loss_wrapper bookkeeping on the N per-sample partials (losses/loss_wrapper.py:45-71): per-sample weights 1/peak^p,
+ * division by the GLOBAL batch size, the scalar loss (+ *extra if given), the loss_bwd coefficients and the `mse` metric
+ * of train_step (models/Homogeneous_Poisson_NN_Legacy.py:291). */
+int pcnn_loss_coefficients(pcnn_handle h, int N, int64_t hw, const float* partials, float w_mae, float w_mse, float w_int,
+                           int scale_by_peak, int global_batch_size, const float* extra, float* loss, float* c_mae, float* c_mse,
+                           float* c_int, float* mse);
 /* FD-Laplacian residual loss (losses/physics_informed_loss.py:35-50): per-sample sum of (rhs - conv(pred,kern_n))^2 over
  * the interior; kern (N, s, s); bwd accumulates into dpred.  */
 int pcnn_pi_loss_partials(pcnn_handle h, int N, int H, int W, int s, const float* pred, const float* rhs, const float* kern, float* out /*N*/);
@@ -176,24 +183,29 @@ int pcnn_adam_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m,
 int pcnn_sgd_step(pcnn_handle h, int64_t n, float* w, const float* g, float lr, float grad_scale);
 
 /* ---- dataset: reference-solution generators (poisson_CNN/dataset) ------------------------------------------- */
-/* Dirichlet 5-point FD Poisson solve by DST-I diagonalisation; replaces multigrid_poisson_solve + poisson_RHS
- * (dataset/solvers/multigrid.py:98-150, dataset/solvers/cholesky.py:45-119).  rhs (N,H,W); boundaries
- * left/right (N,W) [axis -2 ends], bottom/top (N,H) [axis -1 ends]; dx (N); S_h (H-2,H-2), S_w (W-2,W-2) are the
- * orthonormal DST-I matrices, lam_h/lam_w the eigenvalues 2-2cos(j pi/(n-1)) from pcnn_dst_setup.
- * tmp: 2*N*(H-2)*(W-2) floats. */
-int pcnn_dst_setup(int n, float* S /*(n-2)^2 host*/, float* lam /*(n-2) host*/);
+/* Dirichlet 5-point FD Poisson solve by DST-I diagonalisation, fp64 on the f64 matrix cores; replaces
+ * multigrid_poisson_solve + poisson_RHS (dataset/solvers/multigrid.py:98-150, dataset/solvers/cholesky.py:45-119):
+ *   A u_int = -dx^2 f_int + (boundary values folded onto the first interior ring),  A = pyamg.gallery.poisson((H-2, W-2)).
+ * rhs (N,H,W) fp32; left/right (N,W) are the values on axis -2 index 0 / -1, bottom/top (N,H) those on axis -1 index
+ * 0 / -1 (multigrid.py:145-148); dx (N).  S_h ((H-2)^2), lam_h (H-2), S_w, lam_w: device copies of pcnn_dst_setup output.
+ * tmp: 2*N*(H-2)*(W-2) doubles.  soln (N,H,W) fp32 (fp64 solve, fp32 I/O like the reference's cast at
+ * dataset/generators/numerical.py:131). */
+int pcnn_dst_setup(int n, double* S /* (n-2)^2, host */, double* lam /* n-2, host */);
 int pcnn_fd_poisson_dst(pcnn_handle h, int N, int H, int W, const float* rhs, const float* left, const float* right,
-                        const float* bottom, const float* top, const float* dx, const float* S_h, const float* lam_h,
-                        const float* S_w, const float* lam_w, float* tmp, float* soln);
-/* Separable series synthesis out[n,a,b] = sum_{A,B} c[n,A,B] f(A x_a) g(B y_b) with f,g in {sin,cos}
- * (dataset/utils/generate_smooth_function.py:45-62).  coef (N, ka, kb) zero-padded; trig: 0 = sin, 1 = cos.
- * accumulate != 0 adds into out. */
+                        const float* bottom, const float* top, const float* dx, const double* S_h, const double* lam_h,
+                        const double* S_w, const double* lam_w, double* tmp, float* soln);
+/* C[b] = A[b] * B[b] in fp64 (row-major, stride 0 broadcasts an operand) on v_mfma_f64_16x16x4_f64 */
+int pcnn_batched_gemm_f64(pcnn_handle h, int batch, int M, int Nn, int K, const double* A, int64_t strideA, int lda,
+                          const double* B, int64_t strideB, int ldb, double* C, int64_t strideC, int ldc);
+/* Separable series synthesis out[n,a,b] (+)= sum_{A<ka,B<kb} c[n,A,B] f((A+1) x_a) f((B+1) y_b), x = linspace(0,pi,H),
+ * y = linspace(0,pi,W), f = sin (trig 0) or cos (trig 1) (dataset/utils/generate_smooth_function.py:45-62). */
 int pcnn_series_synthesis(pcnn_handle h, int N, int H, int W, int ka, int kb, const float* coef, int trig, int accumulate, float* out);
-/* out[n, :] *= target[n] / max|out[n, :]|  (dataset/utils/set_max_magnitude.py:14-25); also returns the factors */
+/* out[n,a,b] (+)= sum_{r<R} U[n,r,a] V[n,r,b]: the Taylor component X(x)Y(y), X''Y + XY'' (dataset/generators/reverse.py:231-256) */
+int pcnn_separable_sum(pcnn_handle h, int N, int H, int W, int R, const float* U, const float* V, int accumulate, float* out);
+/* x[n,:] *= target[n] / max|x[n,:]| (dataset/utils/set_max_magnitude.py:14-50); factors (optional) receives the scale */
 int pcnn_set_max_magnitude(pcnn_handle h, int N, int64_t per, const float* target, float* x, float* factors);
-/* generic batched small GEMM C[n] = A[n?] * B[n?] used by the DST (strideA/B = 0 broadcasts) */
-int pcnn_batched_gemm(pcnn_handle h, int batch, int M, int Nn, int K, const float* A, int64_t strideA, int lda, int transA,
-                      const float* B, int64_t strideB, int ldb, int transB, float* C, int64_t strideC, int ldc);
+/* x[n,:] *= s[n] */
+int pcnn_scale_samples(pcnn_handle h, int N, int64_t per, const float* s, float* x);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ struct ConvParams {
 };
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, col = lane & 31;
@@ -43,13 +43,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
   const int PS = p.PS;
   const int cin_pad = (p.Cin + 7) & ~7;
 
-  f32x16 acc[MT][NT];
+  // Two-level (blocked) summation: `acc` collects one filter row of one Cin chunk (K <= kw*CK terms) inside the MFMA
+  // fmaf chain, then is added into `tot`.  This cuts the fp32 rounding error of the K ~ 7200 reductions by ~3x compared
+  // with one long chain, at the cost of 64 v_add per ~240 MFMAs.
+  f32x16 acc[MT][NT], tot[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+      for (int i = 0; i < 16; ++i) { acc[m][t][i] = 0.f; tot[m][t][i] = 0.f; }
 
   const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
 
@@ -119,6 +122,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) bcur[t][j] = bnxt[t][j];
+      if (nki != ki || s + 1 == nsteps) {   // end of a filter row: flush the block sum
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { tot[m][t][i] += acc[m][t][i]; acc[m][t][i] = 0.f; }
+      }
       tap = ntap; sub = nsb; ki = nki; kj = nkj;
     }
   }
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvParams p) {
         const int ox = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
         if (ox >= p.Wo) continue;
         const int64_t pix = rowpix + ox;
-        float v = pcnn_act(acc[m][t][i] + bias, p.act, p.alpha);
+        float v = pcnn_act(tot[m][t][i] + bias, p.act, p.alpha);
         if (p.act_out) p.act_out[pix * p.ld_act + co] = v;
         v = v * sc + sh;
         if (p.res) v += p.res[pix * p.ld_res + co];

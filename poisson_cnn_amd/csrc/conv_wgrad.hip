@@ -27,7 +27,7 @@ struct WgradPlan { int S, KWG, TAPS, MTC, NTC, gz; size_t lds; int ntiles, tiles
 static WgradPlan make_plan(const pcnn_conv_desc* d) {
   WgradPlan pl;
   pl.MTC = pcnn_cdiv(d->Cin, 32); pl.NTC = pcnn_cdiv(d->Cout, 32);
-  int maxTaps = 8 / (pl.MTC * pl.NTC);
+  int maxTaps = 4 / (pl.MTC * pl.NTC);   // <= 4 accumulator tiles (+4 running totals) per wave: 128 VGPRs
   if (maxTaps > 4) maxTaps = 4;
   if (maxTaps < 1) maxTaps = 1;
   pl.KWG = d->kw < 4 * maxTaps ? d->kw : 4 * maxTaps;
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   float* xs = lds;
   float* dzs = lds + ((WTH * TCx * p.Cin + 64 + 3) & ~3);
 
-  f32x16 acc[TAPS][MTC][NTC];
+  // blocked summation: `acc` holds one tile (256 pixels), `tot` the running sum over the workgroup's tiles
+  f32x16 acc[TAPS][MTC][NTC], tot[TAPS][MTC][NTC];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int q = 0; q < NTC; ++q)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][m][q][i] = 0.f;
+        for (int i = 0; i < 16; ++i) { acc[t][m][q][i] = 0.f; tot[t][m][q][i] = 0.f; }
 
   for (int tile = split; tile < p.ntiles; tile += p.S) {
     int tt = tile;
@@ -134,6 +135,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
         }
       }
     }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int m = 0; m < MTC; ++m)
+#pragma unroll
+        for (int q = 0; q < NTC; ++q)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { tot[t][m][q][i] += acc[t][m][q][i]; acc[t][m][q][i] = 0.f; }
   }
   // ---- write partials ws[split][ki][kj][ci][co]
 #pragma unroll
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int ci = m * 32 + 8 * (i >> 2) + 4 * half + (i & 3);
-          if (ci < p.Cin && co < p.Cout) dst[ci * p.Cout + co] = acc[t][m][q][i];
+          if (ci < p.Cin && co < p.Cout) dst[ci * p.Cout + co] = tot[t][m][q][i];
         }
       }
   }
@@ -194,9 +203,7 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
   p.vecdz = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
 #define PCNN_WG(M, Q, T) if (pl.MTC == M && pl.NTC == Q && pl.TAPS == T) { launch_wgrad<M, Q, T>(h, p, pl); } else
   PCNN_WG(1, 1, 1) PCNN_WG(1, 1, 2) PCNN_WG(1, 1, 3) PCNN_WG(1, 1, 4)
-  PCNN_WG(2, 1, 1) PCNN_WG(2, 1, 2) PCNN_WG(2, 1, 3) PCNN_WG(2, 1, 4)
-  PCNN_WG(1, 2, 1) PCNN_WG(1, 2, 2) PCNN_WG(1, 2, 3) PCNN_WG(1, 2, 4)
-  PCNN_WG(2, 2, 1) PCNN_WG(2, 2, 2)
+  PCNN_WG(2, 1, 1) PCNN_WG(2, 1, 2) PCNN_WG(1, 2, 1) PCNN_WG(1, 2, 2) PCNN_WG(2, 2, 1)
   { PCNN_FAIL(h, "pcnn_conv2d_wgrad: no kernel for MTC=%d NTC=%d TAPS=%d", pl.MTC, pl.NTC, pl.TAPS); }
 #undef PCNN_WG
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad");

@@ -1,0 +1,264 @@
+// On-device reference-solution generators (poisson_CNN/dataset):
+//   * Dirichlet 5-point FD Poisson solve by DST-I diagonalisation, carried out in fp64 on the f64 matrix cores
+//     (v_mfma_f64_16x16x4_f64) as four dense products with the orthonormal sine matrix - this replaces pyamg's
+//     Ruge-Stuben V-cycles / AMGX (dataset/solvers/multigrid.py:98-150) and poisson_RHS (dataset/solvers/cholesky.py:45-119)
+//     with a direct solve of the SAME linear system (fp64 solve, fp32 I/O like the reference).
+//   * separable series synthesis sum_{A,B} c[A,B] f(A x) g(B y) (dataset/utils/generate_smooth_function.py:45-62)
+//   * rank-R separable sums (the Taylor component of dataset/generators/reverse.py:231-256)
+//   * per-sample max-magnitude normalisation (dataset/utils/set_max_magnitude.py)
+#include <math.h>
+#include "pcnn_internal.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+static dim3 grid1d(int64_t total, int block = 256, int maxb = 16384) {
+  int64_t b = pcnn_cdiv64(total, block);
+  if (b > maxb) b = maxb;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+// ---------------------------------------------------------------- fp64 batched GEMM, C = A * B (row-major)
+constexpr int GT = 64, GK = 16;
+
+__global__ __launch_bounds__(256) void gemm_f64_kernel(int M, int Nn, int K, const double* __restrict__ A, int64_t sA, int lda,
+                                                       const double* __restrict__ B, int64_t sB, int ldb, double* __restrict__ C, int64_t sC, int ldc) {
+  __shared__ double As[GT][GK + 1];
+  __shared__ double Bs[GK][GT + 1];
+  const int b = blockIdx.z, m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  A += (int64_t)b * sA; B += (int64_t)b * sB; C += (int64_t)b * sC;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wr = wave >> 1, wc = wave & 1, l16 = lane & 15, lq = lane >> 4;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    __syncthreads();
+    for (int e = tid; e < GT * GK; e += 256) {
+      const int r = e / GK, c = e % GK;
+      As[r][c] = (m0 + r < M && k0 + c < K) ? A[(int64_t)(m0 + r) * lda + k0 + c] : 0.0;
+      const int r2 = e / GT, c2 = e % GT;
+      Bs[r2][c2] = (k0 + r2 < K && n0 + c2 < Nn) ? B[(int64_t)(k0 + r2) * ldb + n0 + c2] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK / 4; ++kk) {
+      double a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[wr * 32 + i * 16 + l16][kk * 4 + lq];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[j] = Bs[kk * 4 + lq][wc * 32 + j * 16 + l16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 32 + i * 16 + lq + 4 * r, colc = n0 + wc * 32 + j * 16 + l16;   // f64 C/D map: row = (lane>>4) + 4*reg
+        if (row < M && colc < Nn) C[(int64_t)row * ldc + colc] = acc[i][j][r];
+      }
+}
+
+// ---------------------------------------------------------------- DST Poisson solve pieces
+// B[n,i,j] = -dx^2 f[i+1,j+1] + boundary values folded onto the first interior ring (dataset/solvers/cholesky.py:85,114-117)
+__global__ void dst_build_rhs_kernel(int N, int H, int W, const float* __restrict__ rhs, const float* __restrict__ left, const float* __restrict__ right,
+                                     const float* __restrict__ bottom, const float* __restrict__ top, const float* __restrict__ dx, double* __restrict__ Bm) {
+  const int nh = H - 2, nw = W - 2;
+  const int64_t total = (int64_t)N * nh * nw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx % nw; const int i = (idx / nw) % nh; const int n = idx / ((int64_t)nh * nw);
+    const double h = (double)dx[n];
+    double v = -h * h * (double)rhs[((int64_t)n * H + i + 1) * W + j + 1];
+    if (j == 0) v += (double)bottom[(int64_t)n * H + i + 1];       // F[..., 1:-1, 1]  += bottom
+    if (j == nw - 1) v += (double)top[(int64_t)n * H + i + 1];     // F[..., 1:-1, -2] += top
+    if (i == 0) v += (double)left[(int64_t)n * W + j + 1];         // F[..., 1, 1:-1]  += left
+    if (i == nh - 1) v += (double)right[(int64_t)n * W + j + 1];   // F[..., -2, 1:-1] += right
+    Bm[idx] = v;
+  }
+}
+
+__global__ void dst_divide_kernel(int N, int nh, int nw, const double* __restrict__ lam_h, const double* __restrict__ lam_w, double* __restrict__ T) {
+  const int64_t total = (int64_t)N * nh * nw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx % nw; const int i = (idx / nw) % nh;
+    T[idx] /= (lam_h[i] + lam_w[j]);
+  }
+}
+
+// interior from U, then [:, -1]=top, [:, 0]=bottom, [0, :]=left, [-1, :]=right in that order (dataset/solvers/multigrid.py:145-148)
+__global__ void dst_write_soln_kernel(int N, int H, int W, const double* __restrict__ U, const float* __restrict__ left, const float* __restrict__ right,
+                                      const float* __restrict__ bottom, const float* __restrict__ top, float* __restrict__ soln) {
+  const int nh = H - 2, nw = W - 2;
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx % W; const int i = (idx / W) % H; const int n = idx / ((int64_t)H * W);
+    float v;
+    if (i == 0) v = left[(int64_t)n * W + j];
+    else if (i == H - 1) v = right[(int64_t)n * W + j];
+    else if (j == 0) v = bottom[(int64_t)n * H + i];
+    else if (j == W - 1) v = top[(int64_t)n * H + i];
+    else v = (float)U[((int64_t)n * nh + i - 1) * nw + j - 1];
+    soln[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------- series synthesis
+// out[n,a,b] (+)= sum_{A<ka,B<kb} c[n,A,B] f((A+1) x_a) g((B+1) y_b), x = linspace(0,pi,H), y = linspace(0,pi,W)
+constexpr int SYN_ROWS = 16, SYN_MAXK = 16;
+__global__ __launch_bounds__(256) void series_kernel(int H, int W, int ka, int kb, const float* __restrict__ coef, int trig, int accumulate,
+                                                     float* __restrict__ out) {
+  extern __shared__ float sm[];
+  float* T = sm;                 // [ka][W]   : sum_B c[A,B] g((B+1) y_b)
+  float* F = sm + ka * W;        // [ka][SYN_ROWS]
+  const int n = blockIdx.y, a0 = blockIdx.x * SYN_ROWS;
+  const float pi = 3.14159265358979323846f;
+  const float* c = coef + (int64_t)n * ka * kb;
+  const float dy = W > 1 ? pi / (float)(W - 1) : 0.f, dxs = H > 1 ? pi / (float)(H - 1) : 0.f;
+  for (int b = threadIdx.x; b < W; b += blockDim.x) {
+    float g[SYN_MAXK];
+    const float yb = (float)b * dy;
+    for (int B = 0; B < kb; ++B) g[B] = trig ? cosf((float)(B + 1) * yb) : sinf((float)(B + 1) * yb);
+    for (int A = 0; A < ka; ++A) {
+      float s = 0.f;
+      for (int B = 0; B < kb; ++B) s = fmaf(c[A * kb + B], g[B], s);
+      T[A * W + b] = s;
+    }
+  }
+  for (int e = threadIdx.x; e < ka * SYN_ROWS; e += blockDim.x) {
+    const int A = e / SYN_ROWS, r = e % SYN_ROWS;
+    const float xa = (float)(a0 + r) * dxs;
+    F[e] = trig ? cosf((float)(A + 1) * xa) : sinf((float)(A + 1) * xa);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < SYN_ROWS * W; e += blockDim.x) {
+    const int r = e / W, b = e % W;
+    if (a0 + r >= H) break;
+    float s = 0.f;
+    for (int A = 0; A < ka; ++A) s = fmaf(F[A * SYN_ROWS + r], T[A * W + b], s);
+    float* dst = &out[((int64_t)n * H + a0 + r) * W + b];
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+// out[n,a,b] (+)= sum_r U[n,r,a] V[n,r,b]
+__global__ void separable_sum_kernel(int N, int H, int W, int R, const float* __restrict__ U, const float* __restrict__ V, int accumulate,
+                                     float* __restrict__ out) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int b = idx % W; const int a = (idx / W) % H; const int n = idx / ((int64_t)H * W);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s = fmaf(U[((int64_t)n * R + r) * H + a], V[((int64_t)n * R + r) * W + b], s);
+    out[idx] = accumulate ? out[idx] + s : s;
+  }
+}
+
+// one workgroup per sample: x *= target / max|x|
+__global__ __launch_bounds__(1024) void set_max_magnitude_kernel(int64_t per, const float* __restrict__ target, float* __restrict__ x,
+                                                                 float* __restrict__ factors) {
+  __shared__ float red[1024];
+  const int n = blockIdx.x;
+  float* xs = x + (int64_t)n * per;
+  float mx = 0.f;
+  for (int64_t q = threadIdx.x; q < per; q += blockDim.x) mx = fmaxf(mx, fabsf(xs[q]));
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const float f = target[n] / red[0];
+  for (int64_t q = threadIdx.x; q < per; q += blockDim.x) xs[q] *= f;
+  if (threadIdx.x == 0 && factors) factors[n] = f;
+}
+
+__global__ void scale_samples_kernel(int N, int64_t per, const float* __restrict__ s, float* __restrict__ x) {
+  const int64_t total = (int64_t)N * per;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) x[i] *= s[i / per];
+}
+
+}  // namespace
+
+extern "C" int pcnn_batched_gemm_f64(pcnn_handle h, int batch, int M, int Nn, int K, const double* A, int64_t strideA, int lda, const double* B,
+                                     int64_t strideB, int ldb, double* C, int64_t strideC, int ldc) {
+  PCNN_REQUIRE(h, h && A && B && C && batch >= 1 && M >= 1 && Nn >= 1 && K >= 1, "pcnn_batched_gemm_f64: bad argument");
+  PCNN_REQUIRE(h, batch <= 65535, "pcnn_batched_gemm_f64: batch %d too large", batch);
+  hipLaunchKernelGGL(gemm_f64_kernel, dim3(pcnn_cdiv(Nn, GT), pcnn_cdiv(M, GT), batch), dim3(256), 0, h->stream, M, Nn, K, A, strideA, lda, B, strideB, ldb,
+                     C, strideC, ldc);
+  PCNN_CHECK_LAUNCH(h, "pcnn_batched_gemm_f64");
+  return 0;
+}
+
+// host helper: orthonormal DST-I matrix S[j,k] = sqrt(2/(m+1)) sin(pi (j+1)(k+1)/(m+1)) and eigenvalues 2-2cos(pi (j+1)/(m+1)),
+// m = n-2 interior points of an n-point axis.
+extern "C" int pcnn_dst_setup(int n, double* S, double* lam) {
+  if (n < 3 || !S || !lam) return 1;
+  const int m = n - 2;
+  const double c = sqrt(2.0 / (m + 1.0)), pi = 3.14159265358979323846264338327950288;
+  for (int j = 0; j < m; ++j) {
+    lam[j] = 2.0 - 2.0 * cos(pi * (j + 1.0) / (m + 1.0));
+    for (int k = 0; k < m; ++k) S[(size_t)j * m + k] = c * sin(pi * (double)(((int64_t)(j + 1) * (k + 1)) % (2 * (m + 1))) / (m + 1.0));
+  }
+  return 0;
+}
+
+extern "C" int pcnn_fd_poisson_dst(pcnn_handle h, int N, int H, int W, const float* rhs, const float* left, const float* right, const float* bottom,
+                                   const float* top, const float* dx, const double* S_h, const double* lam_h, const double* S_w, const double* lam_w,
+                                   double* tmp, float* soln) {
+  PCNN_REQUIRE(h, h && rhs && left && right && bottom && top && dx && S_h && lam_h && S_w && lam_w && tmp && soln, "pcnn_fd_poisson_dst: null argument");
+  PCNN_REQUIRE(h, H >= 3 && W >= 3 && N >= 1, "pcnn_fd_poisson_dst: grid %dx%d too small", H, W);
+  const int nh = H - 2, nw = W - 2;
+  const int64_t per = (int64_t)nh * nw;
+  double* Bm = tmp; double* T = tmp + (int64_t)N * per;
+  hipLaunchKernelGGL(dst_build_rhs_kernel, grid1d(N * per), dim3(256), 0, h->stream, N, H, W, rhs, left, right, bottom, top, dx, Bm);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_dst(build)");
+  int rc;
+  if ((rc = pcnn_batched_gemm_f64(h, N, nh, nw, nh, S_h, 0, nh, Bm, per, nw, T, per, nw))) return rc;     // T  = S_h B
+  if ((rc = pcnn_batched_gemm_f64(h, N, nh, nw, nw, T, per, nw, S_w, 0, nw, Bm, per, nw))) return rc;     // Bm = T S_w   (spectral coefficients)
+  hipLaunchKernelGGL(dst_divide_kernel, grid1d(N * per), dim3(256), 0, h->stream, N, nh, nw, lam_h, lam_w, Bm);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_dst(divide)");
+  if ((rc = pcnn_batched_gemm_f64(h, N, nh, nw, nh, S_h, 0, nh, Bm, per, nw, T, per, nw))) return rc;     // T  = S_h (.)
+  if ((rc = pcnn_batched_gemm_f64(h, N, nh, nw, nw, T, per, nw, S_w, 0, nw, Bm, per, nw))) return rc;     // Bm = T S_w = u
+  hipLaunchKernelGGL(dst_write_soln_kernel, grid1d((int64_t)N * H * W), dim3(256), 0, h->stream, N, H, W, Bm, left, right, bottom, top, soln);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_dst(write)");
+  return 0;
+}
+
+extern "C" int pcnn_series_synthesis(pcnn_handle h, int N, int H, int W, int ka, int kb, const float* coef, int trig, int accumulate, float* out) {
+  PCNN_REQUIRE(h, h && coef && out && N >= 1 && H >= 1 && W >= 1, "pcnn_series_synthesis: bad argument");
+  PCNN_REQUIRE(h, ka >= 1 && kb >= 1 && ka <= SYN_MAXK && kb <= SYN_MAXK, "pcnn_series_synthesis: %dx%d coefficients unsupported (<=%d)", ka, kb, SYN_MAXK);
+  const size_t lds = ((size_t)ka * W + (size_t)ka * SYN_ROWS) * sizeof(float);
+  PCNN_REQUIRE(h, lds <= 64 * 1024, "pcnn_series_synthesis: W=%d too wide for %d modes", W, ka);
+  hipLaunchKernelGGL(series_kernel, dim3(pcnn_cdiv(H, SYN_ROWS), N), dim3(256), lds, h->stream, H, W, ka, kb, coef, trig, accumulate, out);
+  PCNN_CHECK_LAUNCH(h, "pcnn_series_synthesis");
+  return 0;
+}
+
+extern "C" int pcnn_separable_sum(pcnn_handle h, int N, int H, int W, int R, const float* U, const float* V, int accumulate, float* out) {
+  PCNN_REQUIRE(h, h && U && V && out && R >= 1, "pcnn_separable_sum: bad argument");
+  hipLaunchKernelGGL(separable_sum_kernel, grid1d((int64_t)N * H * W), dim3(256), 0, h->stream, N, H, W, R, U, V, accumulate, out);
+  PCNN_CHECK_LAUNCH(h, "pcnn_separable_sum");
+  return 0;
+}
+
+extern "C" int pcnn_set_max_magnitude(pcnn_handle h, int N, int64_t per, const float* target, float* x, float* factors) {
+  PCNN_REQUIRE(h, h && target && x && N >= 1, "pcnn_set_max_magnitude: bad argument");
+  hipLaunchKernelGGL(set_max_magnitude_kernel, dim3(N), dim3(1024), 0, h->stream, per, target, x, factors);
+  PCNN_CHECK_LAUNCH(h, "pcnn_set_max_magnitude");
+  return 0;
+}
+
+extern "C" int pcnn_scale_samples(pcnn_handle h, int N, int64_t per, const float* s, float* x) {
+  PCNN_REQUIRE(h, h && s && x, "pcnn_scale_samples: null argument");
+  hipLaunchKernelGGL(scale_samples_kernel, grid1d((int64_t)N * per), dim3(256), 0, h->stream, N, per, s, x);
+  PCNN_CHECK_LAUNCH(h, "pcnn_scale_samples");
+  return 0;
+}

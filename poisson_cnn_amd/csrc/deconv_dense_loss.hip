@@ -371,3 +371,34 @@ extern "C" int pcnn_pi_loss_bwd(pcnn_handle h, int N, int H, int W, int s, const
   PCNN_CHECK_LAUNCH(h, "pcnn_pi_loss_bwd");
   return 0;
 }
+
+// ---- loss_wrapper bookkeeping (losses/loss_wrapper.py:45-71) on the N per-sample partial sums
+namespace {
+__global__ void loss_coefficients_kernel(int N, float inv_hw, const float* __restrict__ part, float w_mae, float w_mse, float w_int, int scale_by_peak,
+                                         float inv_gbs, const float* __restrict__ extra /*optional scalar added to the loss*/, float* __restrict__ loss,
+                                         float* __restrict__ c_mae, float* __restrict__ c_mse, float* __restrict__ c_int, float* __restrict__ mse) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float L = 0.f, sq = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float pk = scale_by_peak ? part[4 * n + 3] : 1.f;
+    const float i1 = 1.f / pk, i2 = 1.f / (pk * pk);
+    L += (w_mae * part[4 * n] * inv_hw * i1 + w_mse * part[4 * n + 1] * inv_hw * i2 + w_int * part[4 * n + 2] * i2) * inv_gbs;
+    c_mae[n] = w_mae * inv_hw * i1 * inv_gbs;
+    c_mse[n] = w_mse * inv_hw * i2 * inv_gbs;
+    c_int[n] = w_int * i2 * inv_gbs;
+    sq += part[4 * n + 1];
+  }
+  if (extra) L += extra[0];
+  loss[0] = L;
+  mse[0] = sq * inv_hw / (float)N;
+}
+}  // namespace
+
+extern "C" int pcnn_loss_coefficients(pcnn_handle h, int N, int64_t hw, const float* partials, float w_mae, float w_mse, float w_int, int scale_by_peak,
+                                      int global_batch_size, const float* extra, float* loss, float* c_mae, float* c_mse, float* c_int, float* mse) {
+  PCNN_REQUIRE(h, h && partials && loss && c_mae && c_mse && c_int && mse && N >= 1 && global_batch_size >= 1, "pcnn_loss_coefficients: bad argument");
+  hipLaunchKernelGGL(loss_coefficients_kernel, dim3(1), dim3(64), 0, h->stream, N, 1.0f / (float)hw, partials, w_mae, w_mse, w_int, scale_by_peak,
+                     1.0f / (float)global_batch_size, extra, loss, c_mae, c_mse, c_int, mse);
+  PCNN_CHECK_LAUNCH(h, "pcnn_loss_coefficients");
+  return 0;
+}

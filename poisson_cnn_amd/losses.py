@@ -1,0 +1,162 @@
+"""loss_wrapper / integral_loss / linear_operator_loss on the libpcnn loss kernels.
+
+Drop-in for poisson_CNN/losses/loss_wrapper.py:6-71 (same constructor kwargs: the "loss_parameters" section of
+experiments/hpnn.json loads unchanged; `loss(y_true, y_pred, rhs, dx)`), plus `value_and_grad` used by the model's
+train_step instead of a GradientTape.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ctypes import c_float, c_int, c_int64
+
+
+def get_fd_coefficients(stencil_positions, order):
+    """dataset/utils/get_fd_coefficients.py:4-19."""
+    from math import factorial
+    pos = np.array(sorted(stencil_positions), dtype=np.float64)
+    V = np.vander(pos, increasing=True).T
+    rhs = np.zeros(len(pos))
+    rhs[order] = factorial(order)
+    return np.linalg.solve(V, rhs)
+
+
+def build_fd_coefficients(stencil_size, orders, ndims=None):
+    """dataset/utils/build_fd_coefficients.py:5-42."""
+    if ndims is None:
+        ndims = len(stencil_size)
+    if isinstance(stencil_size, int):
+        stencil_size = [stencil_size] * ndims
+    if isinstance(orders, int):
+        orders = [orders] * ndims
+    ss = np.array(stencil_size, dtype=int)
+    if len(ss) == 1:
+        ss = np.repeat(ss, ndims)
+    assert len(ss) == ndims and np.all(ss % 2 == 1), 'Stencil sizes must be all odd'
+    coeff = np.zeros([ndims] + list(ss))
+    for d in range(ndims):
+        sl = [d] + list(ss // 2)
+        sl[d + 1] = slice(0, ss[d])
+        coeff[tuple(sl)] += get_fd_coefficients(list(range(-(ss[d] // 2), ss[d] // 2 + 1)), int(orders[d]))
+    return coeff
+
+
+class integral_loss:
+    """losses/integral_loss.py:80-179.  The Gauss-Legendre integral of the multilinear interpolant of (y-t)^p is a fixed
+    linear functional of the grid values, so it is applied as one (H,W) weight map G: L = sum(G * (y-t)^p) * vol / 2^d."""
+
+    def __init__(self, n_quadpts, ndims=None, Lp_norm_power=2, data_format='channels_first', reduce_results=False):
+        if ndims is None:
+            ndims = len(n_quadpts)
+        if ndims != 2 or data_format != 'channels_first':
+            raise NotImplementedError('integral_loss: 2-D channels_first only')
+        self.n_quadpts = [n_quadpts] * ndims if isinstance(n_quadpts, int) else list(n_quadpts)
+        self.Lp_norm_power = Lp_norm_power
+        self.reduce_results = reduce_results
+        self._maps = {}
+
+    @staticmethod
+    def _axis_vector(n, nq):
+        q, w = np.polynomial.legendre.leggauss(nq)
+        q32, w32 = q.astype(np.float32), w.astype(np.float32)
+        step = np.float32(2.0 / (n - 1))
+        pos = (q32 + np.float32(1.0)) / step                       # integral_loss.py:7-9 in float32
+        lo, hi = np.floor(pos).astype(np.int64), np.ceil(pos).astype(np.int64)
+        hi = np.where(hi == lo, hi + 1, hi)                           # :11-14
+        grid = np.linspace(-1.0, 1.0, n)
+        t = (q32.astype(np.float64) - grid[lo]) / (grid[hi] - grid[lo])
+        v = np.zeros(n)
+        np.add.at(v, lo, w32.astype(np.float64) * (1.0 - t))
+        np.add.at(v, hi, w32.astype(np.float64) * t)
+        return v
+
+    def weight_map(self, H, W, device):
+        key = (H, W, str(device))
+        if key not in self._maps:
+            G = np.outer(self._axis_vector(H, self.n_quadpts[0]), self._axis_vector(W, self.n_quadpts[1]))
+            self._maps[key] = torch.tensor(G, dtype=torch.float32, device=device)
+        return self._maps[key]
+
+
+class loss_wrapper:
+    def __init__(self, ndims, integral_loss_weight, integral_loss_config, physics_informed_loss_weight, physics_informed_loss_config,
+                 data_format='channels_first', mse_loss_weight=0.0, mae_loss_weight=0.0, scale_sample_loss_by_target_peak_magnitude=False,
+                 global_batch_size=None):
+        if ndims != 2 or data_format != 'channels_first':
+            raise NotImplementedError('loss_wrapper: 2-D channels_first only')
+        self.ndims = ndims
+        self.integral_loss_weight = float(integral_loss_weight)
+        self.physics_informed_loss_weight = float(physics_informed_loss_weight)
+        self.mse_loss_weight, self.mae_loss_weight = float(mse_loss_weight), float(mae_loss_weight)
+        self.scale = bool(scale_sample_loss_by_target_peak_magnitude)
+        self.global_batch_size = global_batch_size
+        icfg = {k: v for k, v in integral_loss_config.items() if k not in ('ndims', 'data_format')}
+        self.integral_loss = integral_loss(ndims=ndims, reduce_results=True, **icfg)
+        if self.integral_loss_weight != 0.0 and self.integral_loss.Lp_norm_power != 2:
+            raise NotImplementedError('integral loss kernel implements Lp_norm_power = 2 (all shipped configs)')
+        pcfg = {k: v for k, v in physics_informed_loss_config.items() if k not in ('ndims', 'data_format')}
+        self.pi_stencil = build_fd_coefficients(pcfg.get('stencil_sizes', 5), pcfg.get('orders', 2), ndims)
+        if self.pi_stencil.shape[1] != self.pi_stencil.shape[2]:
+            raise NotImplementedError('physics-informed loss: square stencils only')
+        self.pi_normalize = bool(pcfg.get('normalize', False))
+        self.pi_domain_norm = bool(pcfg.get('inputs_have_max_domain_size_squared_normalization', False))
+        self._last = None
+
+    # -- helpers
+    def _pi_kernels(self, dx, H, W):
+        """losses/physics_informed_loss.py:36-42: per-sample stencil sum_d coeff[d] * q[n,d]."""
+        st = torch.tensor(self.pi_stencil, dtype=torch.float32, device=dx.device)
+        if self.pi_domain_norm:
+            sizes = dx * torch.tensor([H - 1.0, W - 1.0], device=dx.device)
+            q = (sizes.max(dim=1, keepdim=True).values / dx) ** 2
+        else:
+            q = 1.0 / dx ** 2
+        return torch.einsum('dij,nd->nij', st, q).contiguous()
+
+    def _evaluate(self, y_true, y_pred, rhs, dx, want_grad):
+        N, _, H, W = y_pred.shape
+        dev = y_pred.device
+        y_true = y_true.to(device=dev, dtype=torch.float32).contiguous()
+        y_pred = y_pred.contiguous()
+        gbs = N if self.global_batch_size is None else int(self.global_batch_size)
+        G = self.integral_loss.weight_map(H, W, dev) if self.integral_loss_weight != 0.0 else None
+        part = ops.loss_partials(y_pred, y_true, G)
+        extra = None
+        pi = None
+        if self.physics_informed_loss_weight != 0.0:
+            rhs = rhs.to(device=dev, dtype=torch.float32).contiguous()
+            kern = self._pi_kernels(dx.to(dev), H, W)
+            s = kern.shape[-1]
+            sums = ops.pi_loss_partials(y_pred, rhs, kern)
+            coef = torch.full((N,), self.physics_informed_loss_weight / float(N * (H - 2 * (s // 2)) * (W - 2 * (s // 2))), device=dev)
+            if self.pi_normalize:
+                coef = coef / rhs.abs().amax(dim=(1, 2, 3)) ** 2
+            extra = (coef * sums).sum().reshape(1)
+            pi = (rhs, kern, coef)
+        out = ops.empty((3 * N + 2,), dev)
+        loss, mse = out[0:1], out[1:2]
+        c_mae, c_mse, c_int = out[2:2 + N], out[2 + N:2 + 2 * N], out[2 + 2 * N:2 + 3 * N]
+        ops.handle().call('pcnn_loss_coefficients', c_int_(N), c_int64(H * W), ops._p(part), c_float(self.mae_loss_weight), c_float(self.mse_loss_weight),
+                          c_float(self.integral_loss_weight), c_int_(1 if self.scale else 0), c_int_(gbs), ops._p(extra), ops._p(loss), ops._p(c_mae),
+                          ops._p(c_mse), ops._p(c_int), ops._p(mse))
+        self._last = {'mse': mse}
+        if not want_grad:
+            return loss[0], None
+        dpred = ops.loss_bwd(y_pred, y_true, G, c_mae, c_mse, c_int)
+        if pi is not None:
+            ops.pi_loss_bwd(y_pred, pi[0], pi[1], pi[2], dpred)
+        return loss[0], dpred
+
+    def __call__(self, y_true, y_pred, rhs, dx):
+        return self._evaluate(y_true, y_pred, rhs, dx, False)[0]
+
+    def value_and_grad(self, y_true, y_pred, rhs, dx):
+        """(loss scalar tensor, dL/dy_pred) - what tape.gradient(loss, y_pred) would give."""
+        return self._evaluate(y_true, y_pred, rhs, dx, True)
+
+    def mse_metric(self, y_true, y_pred):
+        """tf.reduce_mean((pred - ground_truth)**2) of the last evaluated (micro-)batch (train_step :291)."""
+        return self._last['mse'][0]
+
+
+c_int_ = c_int

@@ -1,0 +1,334 @@
+"""Homogeneous_Poisson_NN_Legacy on the libpcnn HIP kernels.
+
+Drop-in for poisson_CNN/models/Homogeneous_Poisson_NN_Legacy.py:10-296: same constructor kwargs (the "model" section of
+experiments/hpnn.json loads unchanged), `model([rhs, dx]) -> (N,1,H,W)`, `compile(loss, optimizer)`,
+`train_step(((rhs, dx), y))`, `fit(sequence, epochs, callbacks)`, `trainable_variables`, `get_weights/set_weights`,
+`save_weights/load_weights`, `summary()`.  The API is channels_first like the reference configs; inside, data is NHWC.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import layers as L
+from . import ops
+from .utils import get_init_arguments_from_config
+
+
+def process_normalizations(normalizations):
+    """models/Homogeneous_Poisson_NN_Metalearning.py:27-45."""
+    types, defaults = ['rhs_max_magnitude'], [False]
+    if normalizations is None:
+        return dict(zip(types, defaults))
+    normalizations = dict(normalizations)
+    for k, d in zip(types, defaults):
+        normalizations.setdefault(k, d)
+    if isinstance(normalizations['rhs_max_magnitude'], bool) and normalizations['rhs_max_magnitude']:
+        normalizations['rhs_max_magnitude'] = 1.0
+    return normalizations
+
+
+def process_output_scaling_modes(output_scalings):
+    """models/Homogeneous_Poisson_NN_Metalearning.py:47-57."""
+    modes = ['rhs_max_magnitude', 'max_domain_size_squared', 'match_peak_laplacian_magnitude_to_peak_rhs', 'soln_max_magnitude']
+    out = {m: False for m in modes}
+    if isinstance(output_scalings, dict):
+        out.update(copy.deepcopy(output_scalings))
+    return out
+
+
+def _as_device(t, device):
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(t))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Homogeneous_Poisson_NN_Legacy:
+    def __init__(self, data_format='channels_first', final_convolutions_config=None, pre_bottleneck_convolutions_config=None,
+                 bottleneck_deconv_config=None, bottleneck_multilinear_config=None, input_normalization=None, output_scaling=None,
+                 use_batchnorm=False, postsmoother_iterations=5, use_scaling=False, use_positional_embeddings=True, scaling_config=None,
+                 gradient_accumulation_steps=None, bc_type='dirichlet', device=None, seed=0):
+        if data_format != 'channels_first':
+            raise NotImplementedError('only data_format="channels_first" (all shipped configs) is supported at the API')
+        if pre_bottleneck_convolutions_config is None:
+            raise ValueError('Provide a config for pre bottleneck convolutions')
+        if bottleneck_deconv_config is None or bottleneck_multilinear_config is None:
+            raise ValueError('Provide a config for bottleneck blocks')
+        if final_convolutions_config is None:
+            raise ValueError('Provide a config for final convolutions')
+        if bc_type.lower() not in ('dirichlet', 'neumann'):
+            raise ValueError('bc_type can only be neumann or dirichlet.')
+        if device is None and not torch.cuda.is_available():
+            raise RuntimeError('Homogeneous_Poisson_NN_Legacy needs an AMD GPU: the HIP kernels are the only compute path '
+                               '(device="cpu" builds the parameter structure only; calling the model will raise)')
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.ndims = 2
+        self.data_format = data_format
+        self.gradient_accumulation_steps = gradient_accumulation_steps
+        self.input_normalization = process_normalizations(input_normalization)
+        self.output_scaling = process_output_scaling_modes(output_scaling)
+        self.use_batchnorm = use_batchnorm
+        self.use_positional_embeddings = use_positional_embeddings
+        self.neumann = bc_type.lower() == 'neumann'
+        self.store = S = L.ParamStore()
+        self.ctx = C = L.Context()
+
+        # pre-bottleneck convolutions (reference :41-57)
+        pre = copy.deepcopy(pre_bottleneck_convolutions_config)
+        mode, val = pre.pop('padding_mode', 'CONSTANT'), pre.pop('constant_padding_value', 0.0)
+        self.pre = []
+        cin = 3 if use_positional_embeddings else 1
+        for k in range(len(pre['filters'])):
+            a = get_init_arguments_from_config(pre, k, ['filters', 'kernel_sizes'], ['filters', 'kernel_size'])
+            self.pre.append(L.ConvUnit(S, C, 'pre/conv%d' % k, a['kernel_size'], cin, a['filters'], padding_mode=mode, pad_value=val,
+                                       activation=a.get('activation', 'linear'), use_bias=a.get('use_bias', True),
+                                       bn_name=('pre/bn%d' % k) if use_batchnorm else None))
+            cin = a['filters']
+        c0 = cin
+        # bottleneck blocks (:59-69), sorted by descending downsampling factor
+        assert bottleneck_deconv_config['filters'] == bottleneck_multilinear_config['filters']
+        F = self.filters = bottleneck_deconv_config['filters']
+        dfields = ['downsampling_factors', 'upsampling_factors', 'conv_kernel_sizes', 'deconv_kernel_sizes', 'n_convs']
+        dargs = ['downsampling_factor', 'upsampling_factor', 'conv_kernel_size', 'deconv_kernel_size', 'n_convs']
+        dcfgs = [get_init_arguments_from_config(bottleneck_deconv_config, k, dfields, dargs) for k in range(len(bottleneck_deconv_config['downsampling_factors']))]
+        dcfgs = sorted(dcfgs, key=lambda a: a['downsampling_factor'], reverse=True)
+        self.bottleneck_deconv_blocks = [L.bottleneck_block_deconvupsample(S, C, 'deconv_f%d' % a['downsampling_factor'], c0, use_batchnorm=use_batchnorm, **a)
+                                         for a in dcfgs]
+        mfields = ['downsampling_factors', 'upsampling_factors', 'conv_kernel_sizes', 'n_convs'] + (['resize_methods'] if 'resize_methods' in bottleneck_multilinear_config else [])
+        margs = ['downsampling_factor', 'upsampling_factor', 'conv_kernel_size', 'n_convs'] + (['resize_method'] if 'resize_methods' in bottleneck_multilinear_config else [])
+        mcfgs = [get_init_arguments_from_config(bottleneck_multilinear_config, k, mfields, margs) for k in range(len(bottleneck_multilinear_config['downsampling_factors']))]
+        mcfgs = sorted(mcfgs, key=lambda a: a['downsampling_factor'], reverse=True)
+        self.bottleneck_multilinear_blocks = [L.bottleneck_block_multilinearupsample(S, C, 'multilinear_f%d' % a['downsampling_factor'], c0, use_batchnorm=use_batchnorm, **a)
+                                              for a in mcfgs]
+        # merge + post-merge (:71-76)
+        self.non_bottleneck_conv = L.ConvUnit(S, C, 'non_bottleneck_conv', 5, c0, F, pad='same', activation='leaky_relu')
+        self.post_merge_conv = L.ConvUnit(S, C, 'post_merge_conv', 7, 2 * F, F, pad='same', activation='leaky_relu')
+        self.post_merge_resnet = L.resnet(S, C, 'post_merge_resnet', F, 7, activation='leaky_relu')
+        # final convolutions (:78-96)
+        fc = copy.deepcopy(final_convolutions_config)
+        nst = len(fc['filters'])
+        fmode, fval = fc.pop('padding_mode', 'CONSTANT'), fc.pop('constant_padding_value', 0.0)
+        nreg = fc.pop('final_regular_conv_stages', 2)
+        self.final = []
+        cin = F
+        for k in range(nst - nreg):
+            a = get_init_arguments_from_config(fc, k, ['filters', 'kernel_sizes'], ['filters', 'kernel_size'])
+            act, ub = a.get('activation', 'linear'), a.get('use_bias', True)
+            self.final.append(L.ConvUnit(S, C, 'final/stage%d/conv' % k, a['kernel_size'], cin, a['filters'], padding_mode=fmode, pad_value=fval,
+                                         activation=act, use_bias=ub))
+            self.final.append(L.resnet(S, C, 'final/stage%d/res' % k, a['filters'], a['kernel_size'], padding_mode='constant', activation=act, use_bias=ub))
+            cin = a['filters']
+        for j, k in enumerate(range(nst - nreg, nst)):
+            self.final.append(L.ConvUnit(S, C, 'final/out%d' % j, fc['kernel_sizes'][k], cin, fc['filters'][k], pad='same', activation='linear',
+                                         use_bias=fc.get('use_bias', True)))
+            cin = fc['filters'][k]
+        if cin != 1:
+            raise ValueError('the last final convolution must have 1 filter')
+        # dx dense layers (:98-102)
+        units = [100, 100, F]
+        acts = ['leaky_relu', 'leaky_relu', 'linear']
+        self.dx_dense_layers = []
+        din = 3
+        for i, (u, a) in enumerate(zip(units, acts)):
+            self.dx_dense_layers.append(L.Dense(S, 'dx_dense%d' % i, din, u, a))
+            din = u
+        self.postsmoother = L.JacobiIterationLayer(postsmoother_iterations) if postsmoother_iterations > 0 else None
+        self.scaling = L.Scaling(S, C, 'scaling', **scaling_config) if use_scaling else None
+        S.finalize(self.device)
+        S.initialize(seed)
+        self.optimizer = None
+        self.loss_fn = None
+        self.grad_sync = None    # set by parallel.DataParallel: called with the flat gradient bucket before the optimizer step
+        self._acc = None
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def trainable_variables(self):
+        return [self.store.w[n] for n in self.store.trainable_names()]
+
+    @property
+    def weight_names(self):
+        return self.store.names
+
+    def get_weights(self):
+        return [self.store.w[n].detach().cpu().numpy().copy() for n in self.store.names]
+
+    def set_weights(self, weights):
+        if isinstance(weights, dict):
+            missing = set(self.store.names) - set(weights)
+            if missing:
+                raise ValueError('missing weights: %s' % sorted(missing)[:5])
+            weights = [weights[n] for n in self.store.names]
+        if len(weights) != len(self.store.names):
+            raise ValueError('expected %d weight arrays, got %d' % (len(self.store.names), len(weights)))
+        for n, v in zip(self.store.names, weights):
+            v = np.asarray(v, dtype=np.float32)
+            if tuple(v.shape) != tuple(self.store.w[n].shape):
+                raise ValueError('shape mismatch for %s: %s vs %s' % (n, v.shape, tuple(self.store.w[n].shape)))
+            self.store.w[n].copy_(torch.from_numpy(v))
+
+    def save_weights(self, path):
+        np.savez(path, **{n.replace('/', '.'): w for n, w in zip(self.store.names, self.get_weights())})
+
+    def load_weights(self, path):
+        with np.load(path if str(path).endswith('.npz') else str(path) + '.npz') as z:
+            self.set_weights({n: z[n.replace('/', '.')] for n in self.store.names})
+
+    def count_params(self):
+        return self.store.n_trainable
+
+    def summary(self, print_fn=print):
+        print_fn('Homogeneous_Poisson_NN_Legacy (MI355X / libpcnn)')
+        for name, shape, _, kind in self.store.specs:
+            print_fn('  %-44s %-20s %s' % (name, shape, 'trainable' if kind in ('w', 'bn_gamma', 'bn_beta') else 'non-trainable'))
+        print_fn('Trainable params: %d' % self.store.n_trainable)
+
+    # ------------------------------------------------------------------ forward
+    def __call__(self, inp, training=False):
+        return self.call(inp, training=training)
+
+    def call(self, inp, training=False):
+        """reference :183-257.  inp = [rhs (N,1,H,W), dx (N,1)]; returns (N,1,H,W) (torch CUDA tensor)."""
+        rhs, dx = inp
+        rhs = _as_device(rhs, self.device)
+        dx = _as_device(dx, self.device)
+        if rhs.dim() != 4 or rhs.shape[1] != 1:
+            raise ValueError('rhs must have shape (N,1,H,W)')
+        dx = dx.reshape(dx.shape[0], -1)[:, :1].contiguous()
+        N, _, H, W = rhs.shape
+        S = self.store
+        S.refresh_bn()
+        rhs_hw = rhs.view(N, H, W)
+        x = ops.assemble_input(rhs_hw, self.use_positional_embeddings)
+        # dense input [dx, Lx, Ly] (:193,:202): tiny (N,3) host-side assembly
+        dense_inp = torch.cat([dx, dx * float(H - 1), dx * float(W - 1)], 1).contiguous()
+        for c in self.pre:
+            x = c.forward(x, training=training)
+        initial = x
+        F = self.filters
+        cat = ops.empty((N, H, W, 2 * F), self.device)       # [non_bottleneck_conv | merged] (tf.concat axis=1, :224)
+        merged = cat[..., F:]
+        blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks
+        alpha = 1.0 / float(len(blocks) * F)                     # :222
+        for i, b in enumerate(blocks):
+            b.forward_into(initial, merged, alpha, 0.0 if i == 0 else 1.0, training=training)
+        self.non_bottleneck_conv.forward(initial, out=cat[..., :F], training=training)
+        x = self.post_merge_conv.forward(cat, training=training)
+        x = self.post_merge_resnet.forward(x, training=training)
+        d = dense_inp
+        for lyr in self.dx_dense_layers:
+            d = lyr.forward(d, training=training)
+        xs = ops.channel_scale_fwd(x, d)                          # :231
+        if training:
+            self._saved = {'initial': initial, 'scale_in': x, 'dx_info': d, 'shape': (N, H, W)}
+        x = xs
+        for lyr in self.final:
+            x = lyr.forward(x, training=training)
+        if self.scaling is not None:
+            x = self.scaling.forward(x, rhs_hw.view(N, H, W, 1), training=training)
+        x = ops.bc_ring_fwd(x, self.neumann)                      # :251
+        if self.postsmoother is not None:
+            dx2 = torch.cat([dx, dx], 1).contiguous()
+            x = self.postsmoother.forward(x, rhs_hw.view(N, H, W, 1), dx2, training=training)
+        return x.view(N, 1, H, W)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dpred):
+        """Back-propagates dL/dpred (N,1,H,W) through the graph saved by call(training=True); fills store.flat_g."""
+        sv = self._saved
+        self._saved = None
+        N, H, W = sv['shape']
+        F = self.filters
+        d = dpred.contiguous().view(N, H, W, 1)
+        if self.postsmoother is not None:
+            d = self.postsmoother.backward(d)
+        d = ops.bc_ring_bwd(d, self.neumann)
+        if self.scaling is not None:
+            d = self.scaling.backward(d)
+        for lyr in reversed(self.final):
+            d = lyr.backward(d, inplace=True)
+        d, ds = ops.channel_scale_bwd(sv['scale_in'], sv['dx_info'], d, ws=self.ctx.ws)
+        dd = ds
+        for i, lyr in enumerate(reversed(self.dx_dense_layers)):
+            dd = lyr.backward(dd, need_dx=(i < len(self.dx_dense_layers) - 1))
+        d = self.post_merge_resnet.backward(d, inplace=True)
+        dcat = self.post_merge_conv.backward(d, inplace=True)
+        d_initial = self.non_bottleneck_conv.backward(dcat[..., :F], inplace=False)
+        dmerged = dcat[..., F:]
+        blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks
+        alpha = 1.0 / float(len(blocks) * F)
+        for b in blocks:
+            b.backward_from(dmerged, alpha, d_initial)
+        d = d_initial
+        for i, c in enumerate(reversed(self.pre)):
+            d = c.backward(d, need_dx=(i < len(self.pre) - 1), inplace=True)
+        self.store.finish_bn_grads()
+
+    # ------------------------------------------------------------------ training (reference :259-296)
+    def compile(self, loss, optimizer):
+        self.optimizer = optimizer
+        self.loss_fn = loss
+        optimizer.bind(self.store)
+
+    def _loss_and_grads(self, rhs, dx, y_true):
+        pred = self.call([rhs, dx], training=True)
+        loss, dpred = self.loss_fn.value_and_grad(y_true, pred, rhs, torch.cat([dx, dx], 1))
+        self.backward(dpred)
+        return loss, pred
+
+    def train_step(self, data):
+        (rhs, dx), y_true = data
+        rhs, dx, y_true = _as_device(rhs, self.device), _as_device(dx, self.device), _as_device(y_true, self.device)
+        dx = dx.reshape(dx.shape[0], -1)[:, :1].contiguous()
+        S = self.store
+        if self.gradient_accumulation_steps is None:
+            loss, pred = self._loss_and_grads(rhs, dx, y_true)
+            gt = y_true
+        else:
+            from .utils import split_indices
+            steps = int(self.gradient_accumulation_steps)
+            idx = split_indices(rhs.shape[0], steps)
+            if self._acc is None:
+                self._acc = torch.zeros_like(S.flat_g)
+            for s in range(steps):
+                a, b = int(idx[s]), int(idx[s + 1])
+                loss, pred = self._loss_and_grads(rhs[a:b].contiguous(), dx[a:b].contiguous(), y_true[a:b].contiguous())
+                ops.axpby_flat(1.0 / steps, S.flat_g, 0.0 if s == 0 else 1.0, self._acc)     # grads = sum / steps (:287)
+                gt = y_true[a:b]
+            ops.axpby_flat(1.0, self._acc, 0.0, S.flat_g)
+        if self.grad_sync is not None:
+            self.grad_sync(S.flat_g)
+        self.optimizer.apply_gradients()
+        return {'loss': loss, 'mse': self.loss_fn.mse_metric(gt, pred), 'lr': self.optimizer.learning_rate}
+
+    def fit(self, dataset, epochs=1, callbacks=(), verbose=1, steps_per_epoch=None):
+        """Minimal Keras-style loop over a Sequence-like dataset (`__len__`, `__getitem__` -> ([rhs, dx], soln))."""
+        history = {'loss': [], 'mse': [], 'lr': []}
+        self.stop_training = False
+        for cb in callbacks:
+            cb.set_model(self)
+        for epoch in range(epochs):
+            n = steps_per_epoch if steps_per_epoch is not None else len(dataset)
+            agg = {'loss': 0.0, 'mse': 0.0}
+            for step in range(n):
+                inp, tar = dataset[step]
+                logs = self.train_step(((inp[0], inp[1]), tar))
+                logs = {k: (float(v) if not isinstance(v, float) else v) for k, v in logs.items()}
+                for k in agg:
+                    agg[k] += logs[k]
+                for cb in callbacks:
+                    cb.on_batch_end(step, logs)
+                if self.stop_training:
+                    break
+            logs = {'loss': agg['loss'] / max(step + 1, 1), 'mse': agg['mse'] / max(step + 1, 1), 'lr': self.optimizer.learning_rate}
+            for k in history:
+                history[k].append(logs[k])
+            if verbose:
+                print('Epoch %d/%d - loss: %.6g - mse: %.6g - lr: %.3g' % (epoch + 1, epochs, logs['loss'], logs['mse'], logs['lr']), flush=True)
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+            if hasattr(dataset, 'on_epoch_end'):
+                dataset.on_epoch_end()
+            if self.stop_training:
+                break
+        return history

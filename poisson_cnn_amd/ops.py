@@ -391,14 +391,14 @@ def loss_bwd(pred, target, G, c_mae, c_mse, c_int_, out=None):
 
 
 def pi_loss_partials(pred, rhs, kern):
-    N, H, W = pred.shape[0], pred.shape[-2] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[1], pred.shape[-1] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[2]
+    N, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]   # (N,1,H,W) or (N,H,W)
     out = empty((N,), pred.device)
     handle().call('pcnn_pi_loss_partials', c_int(N), c_int(H), c_int(W), c_int(kern.shape[-1]), _p(pred), _p(rhs), _p(kern), _p(out))
     return out
 
 
 def pi_loss_bwd(pred, rhs, kern, coef, dpred):
-    N, H, W = pred.shape[0], pred.shape[-2] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[1], pred.shape[-1] if pred.dim() == 4 and pred.shape[1] == 1 else pred.shape[2]
+    N, H, W = pred.shape[0], pred.shape[-2], pred.shape[-1]   # (N,1,H,W) or (N,H,W)
     handle().call('pcnn_pi_loss_bwd', c_int(N), c_int(H), c_int(W), c_int(kern.shape[-1]), _p(pred), _p(rhs), _p(kern), _p(coef), _p(dpred))
     return dpred
 

@@ -1,0 +1,71 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Replaces tf.distribute.MirroredStrategy(cross_device_ops=ReductionToOneDevice()) (train/hpnn_legacy_train.py:37-38):
+weights are replicated (identical seed, then a broadcast from rank 0), every global batch is split evenly by sample,
+each rank's loss is already divided by the GLOBAL batch size (losses/loss_wrapper.py:46-49), so ONE all-reduce(SUM) of the
+flat fp32 gradient bucket (5.56 M floats = 22.2 MB for hpnn.json) per optimizer step gives the mean gradient, followed by
+the identical Adam step on every rank.  No other collective is on the data path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, rank=0, world_size=1, local_rank=0, backend=None):
+        self.rank, self.world_size, self.local_rank, self.backend = rank, world_size, local_rank, backend
+
+    @classmethod
+    def from_env(cls, backend=None):
+        ws = int(os.environ.get('WORLD_SIZE', '1'))
+        rank = int(os.environ.get('RANK', '0'))
+        lr = int(os.environ.get('LOCAL_RANK', '0'))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(lr % max(torch.cuda.device_count(), 1))
+        if ws > 1 and not dist.is_initialized():
+            backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        return cls(rank, ws, lr, backend)
+
+    def local_batch(self, global_batch):
+        """Even split by sample; the reference requires the same (H,W) on all replicas per step, and so do we."""
+        if global_batch % self.world_size != 0:
+            raise ValueError('global batch %d is not divisible by %d ranks' % (global_batch, self.world_size))
+        return global_batch // self.world_size
+
+    def shard(self, t):
+        """This rank's slice of a global-batch tensor (dim 0)."""
+        n = self.local_batch(t.shape[0])
+        return t[self.rank * n:(self.rank + 1) * n]
+
+    def all_reduce_sum(self, flat):
+        if self.world_size > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    def broadcast(self, flat, src=0):
+        if self.world_size > 1:
+            dist.broadcast(flat, src=src)
+        return flat
+
+    def attach(self, model):
+        """Replicate rank 0's weights and hook the gradient all-reduce in front of the optimizer step."""
+        self.broadcast(model.store.flat_w)
+        self.broadcast(model.store.flat_stats)
+        model.grad_sync = self.all_reduce_sum
+        return model
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.world_size == 1:
+            return value
+        dev = 'cuda' if (self.backend == 'nccl') else 'cpu'
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())

@@ -1,0 +1,173 @@
+"""Optimizers, callbacks and the training entry point (drop-in for poisson_CNN/train/hpnn_legacy_train.py and train/utils.py).
+
+python -m poisson_cnn_amd.train config.json [--checkpoint_dir D] [--continue_from_checkpoint D] [--dataset_type analytical|numerical]
+                                            [--learning_rate X|from_json]
+Under `torchrun` (WORLD_SIZE > 1) the batch is sharded over ranks and gradients are all-reduced over RCCL
+(parallel.DataParallel), replacing the reference's tf.distribute.MirroredStrategy (train/hpnn_legacy_train.py:37-38).
+"""
+import argparse
+import json
+import math
+import os
+
+import numpy as np
+
+from . import ops
+
+
+class _Optimizer:
+    def bind(self, store):
+        self.store = store
+        self._init_state()
+
+    def _init_state(self):
+        pass
+
+
+class Adam(_Optimizer):
+    """tf.keras.optimizers.Adam defaults (train/utils.py:3-8; experiments/hpnn.json optimizer_parameters)."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, **unused):
+        if amsgrad:
+            raise NotImplementedError('amsgrad=True is not used by any shipped config')
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
+        self.iterations = 0
+
+    def _init_state(self):
+        import torch
+        self.m = torch.zeros_like(self.store.flat_w)
+        self.v = torch.zeros_like(self.store.flat_w)
+
+    def apply_gradients(self, grad_scale=1.0):
+        self.iterations += 1
+        s = self.store
+        ops.adam_step(s.flat_w, s.flat_g, self.m, self.v, self.learning_rate, self.beta_1, self.beta_2, self.epsilon, self.iterations, grad_scale)
+
+
+class SGD(_Optimizer):
+    def __init__(self, learning_rate=0.01, **unused):
+        self.learning_rate = float(learning_rate)
+        self.iterations = 0
+
+    def apply_gradients(self, grad_scale=1.0):
+        self.iterations += 1
+        ops.sgd_step(self.store.flat_w, self.store.flat_g, self.learning_rate, grad_scale)
+
+
+def choose_optimizer(name):
+    """train/utils.py:3-8."""
+    name = name.lower()
+    if name == 'adam':
+        return Adam
+    if name == 'sgd':
+        return SGD
+    raise ValueError('unknown optimizer ' + name)
+
+
+# ----------------------------------------------------------------------------- Keras-like callbacks (train/hpnn_legacy_train.py:46-50)
+class Callback:
+    def set_model(self, model):
+        self.model = model
+
+    def on_batch_end(self, batch, logs):
+        pass
+
+    def on_epoch_end(self, epoch, logs):
+        pass
+
+
+class ModelCheckpoint(Callback):
+    def __init__(self, filepath, save_weights_only=True, save_best_only=True, monitor='loss'):
+        self.filepath, self.best, self.monitor, self.save_best_only = filepath, math.inf, monitor, save_best_only
+
+    def on_epoch_end(self, epoch, logs):
+        v = logs[self.monitor]
+        if not self.save_best_only or v < self.best:
+            self.best = min(self.best, v)
+            if int(os.environ.get('RANK', '0')) == 0:
+                self.model.save_weights(self.filepath)
+
+
+class ReduceLROnPlateau(Callback):
+    def __init__(self, patience=4, monitor='loss', min_lr=0.0, factor=0.1):
+        self.patience, self.monitor, self.min_lr, self.factor = patience, monitor, min_lr, factor
+        self.best, self.wait = math.inf, 0
+
+    def on_epoch_end(self, epoch, logs):
+        v = logs[self.monitor]
+        if v < self.best:
+            self.best, self.wait = v, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                opt = self.model.optimizer
+                opt.learning_rate = max(opt.learning_rate * self.factor, self.min_lr)
+                self.wait = 0
+
+
+class TerminateOnNaN(Callback):
+    def on_batch_end(self, batch, logs):
+        if not math.isfinite(logs['loss']):
+            print('Batch %d: Invalid loss, terminating training' % batch)
+            self.model.stop_training = True
+
+
+def load_model_checkpoint(model, checkpoint_path, **unused):
+    """train/utils.py:10-29 (checkpoints are flat .npz in get_weights() order)."""
+    if checkpoint_path is not None:
+        path = checkpoint_path
+        if os.path.isdir(path):
+            path = os.path.join(path, 'chkpt.checkpoint.npz')
+        print('Attempting to load checkpoint from ' + path)
+        model.load_weights(path)
+
+
+def main(argv=None):
+    from . import configs
+    from .utils import convert_tf_object_names
+    from .models import Homogeneous_Poisson_NN_Legacy
+    from .losses import loss_wrapper
+    from .dataset import numerical_dataset_generator, reverse_poisson_dataset_generator, reverse_poisson_dataset_generator_homogeneous_neumann
+    from . import parallel
+    p = argparse.ArgumentParser(description='Train the Homogeneous Poisson NN')
+    p.add_argument('config', type=str)
+    p.add_argument('--checkpoint_dir', type=str, default='.')
+    p.add_argument('--continue_from_checkpoint', type=str, default=None)
+    p.add_argument('--dataset_type', type=lambda x: str(x).lower(), default='analytical')
+    p.add_argument('--learning_rate', type=str, default=None)
+    p.add_argument('--epochs', type=int, default=None)
+    args = p.parse_args(argv)
+    if args.dataset_type not in ('numerical', 'analytical'):
+        raise ValueError('Invalid dataset type. Received: ' + args.dataset_type)
+    config = convert_tf_object_names(configs.load_config(args.config))
+    if config['training'].get('precision', 'float32') != 'float32':
+        raise NotImplementedError('the HIP kernels compute in float32')
+    dp = parallel.DataParallel.from_env()
+    gbs = config['dataset']['batch_size']
+    dcfg = dict(config['dataset'])
+    dcfg['batch_size'] = dp.local_batch(gbs)
+    dcfg['seed'] = dcfg.get('seed', 0) + dp.rank
+    neumann = config['model'].get('bc_type', 'dirichlet').lower() == 'neumann'
+    if args.dataset_type == 'numerical':
+        dataset = numerical_dataset_generator(**dcfg)
+    elif neumann:
+        dataset = reverse_poisson_dataset_generator_homogeneous_neumann(**dcfg)
+    else:
+        dataset = reverse_poisson_dataset_generator(**dcfg)
+    model = Homogeneous_Poisson_NN_Legacy(**config['model'])
+    optimizer = choose_optimizer(config['training']['optimizer'])(**config['training']['optimizer_parameters'])
+    loss = loss_wrapper(global_batch_size=gbs, **config['training']['loss_parameters'])
+    model.compile(loss=loss, optimizer=optimizer)
+    dp.attach(model)
+    cb = [ModelCheckpoint(args.checkpoint_dir + '/chkpt.checkpoint'), ReduceLROnPlateau(patience=4, min_lr=config['training']['min_learning_rate']),
+          TerminateOnNaN()]
+    load_model_checkpoint(model, args.continue_from_checkpoint)
+    if args.learning_rate is not None:
+        model.optimizer.learning_rate = config['training']['optimizer_parameters']['learning_rate'] if args.learning_rate.lower() == 'from_json' else float(args.learning_rate)
+    if dp.rank == 0:
+        model.summary()
+    model.fit(dataset, epochs=args.epochs or config['training']['n_epochs'], callbacks=cb, verbose=1 if dp.rank == 0 else 0)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,83 @@
+"""CPU tests of host-side logic: parameter structure vs the oracle's, config handling, C-ABI symbol export."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import hpnn as ohpnn
+from poisson_cnn_amd import configs, utils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('cfgname', ['hpnn', 'hpnn_tiny', 'hpnn_neumann'])
+def test_parameter_structure_matches_oracle(cfgname):
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    cfg = getattr(configs, cfgname)()['model']
+    model = Homogeneous_Poisson_NN_Legacy(device='cpu', **cfg)
+    _, spec = ohpnn.build_structure(cfg)
+    assert model.weight_names == [s[0] for s in spec]
+    for (name, shape, _), w in zip(spec, model.get_weights()):
+        assert tuple(shape) == w.shape, name
+    if cfgname != 'hpnn_tiny':
+        assert model.count_params() == 5556956      # 5 556 956 trainable parameters
+    # Keras-default initialisation statistics
+    w = dict(zip(model.weight_names, model.get_weights()))
+    k = w['final/stage0/conv/kernel']
+    lim = utils.glorot_limit(k.shape)
+    assert np.abs(k).max() <= lim and np.abs(k).max() > 0.9 * lim
+    assert np.all(w['final/stage0/conv/bias'] == 0) and np.all(w['pre/bn0/gamma'] == 1) and np.all(w['pre/bn0/moving_variance'] == 1)
+    assert np.abs(w['deconv_f2/deconv/bias']).max() > 0     # deconv bias is Glorot-initialised (layers/deconvupscale.py:37-38)
+
+
+def test_set_get_weights_roundtrip_and_errors(tmp_path):
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    cfg = configs.hpnn_tiny()['model']
+    m = Homogeneous_Poisson_NN_Legacy(device='cpu', **cfg)
+    p = ohpnn.init_params(cfg, seed=3, randomize_all=True)
+    m.set_weights(p)
+    for n, w in zip(m.weight_names, m.get_weights()):
+        assert np.array_equal(w, p[n].astype(np.float32))
+    m.save_weights(str(tmp_path / 'w.npz'))
+    m2 = Homogeneous_Poisson_NN_Legacy(device='cpu', seed=9, **cfg)
+    m2.load_weights(str(tmp_path / 'w.npz'))
+    assert all(np.array_equal(a, b) for a, b in zip(m.get_weights(), m2.get_weights()))
+    with pytest.raises(ValueError):
+        m.set_weights(m.get_weights()[:-1])
+    with pytest.raises(ValueError):
+        Homogeneous_Poisson_NN_Legacy(device='cpu', **dict(cfg, bc_type='robin'))
+    with pytest.raises(ValueError):
+        Homogeneous_Poisson_NN_Legacy(device='cpu', **{k: v for k, v in cfg.items() if k != 'final_convolutions_config'})
+
+
+def test_config_helpers():
+    cfg = {'key1': 3, 'key2': [0, 1, 2, 3, 4], 'key3': [6, 7, 8, 9, 10]}
+    assert utils.get_init_arguments_from_config(cfg, 2, ['key2', 'key3'], ['key2p', 'key3p']) == {'key1': 3, 'key2p': 2, 'key3p': 8}
+    assert list(utils.split_indices(229, 4)) == [0, 58, 115, 172, 229]
+    assert utils.canonical_activation('tf.nn.leaky_relu') == 'leaky_relu' and utils.canonical_activation('tf.keras.activations.linear') == 'linear'
+    with pytest.raises(ValueError):
+        utils.convert_tf_object_names({'a': 'tf.nn.swish'})
+    c = utils.convert_tf_object_names(configs.hpnn())
+    assert c['model']['pre_bottleneck_convolutions_config']['activation'] == 'tf.nn.leaky_relu'
+    assert utils.advanced_pad_amounts(15) == (7, 7) and utils.advanced_pad_amounts(4) == (2, 1) and utils.same_pad_amounts(4) == (1, 2)
+
+
+def test_libpcnn_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'pcnn.h')).read()
+    declared = sorted(set(re.findall(r'\b(pcnn_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) > 40
+    lib = ctypes.CDLL(os.path.join(ROOT, 'poisson_cnn_amd', 'libpcnn.so'))
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, 'declared in include/pcnn.h but not exported: %s' % missing
+    assert lib.pcnn_version() >= 100
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'poisson_cnn_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
