@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grids/s of one full training step (forward + backward + loss + Adam [+ RCCL gradient all-reduce])
+of Homogeneous_Poisson_NN_Legacy(hpnn.json) on synthetic data resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W [--workload c4|c3]
+    c4 (default): 8 x 1024^2 Dirichlet grids per GPU, data-parallel weak scaling (BASELINE.json configs[3])
+    c3          : 32 x 512^2 grids per GPU (BASELINE.json configs[2])
+For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL).  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fp32-MFMA conv kernel used for the
+forward and the data-gradient convolutions): algorithmic FLOP of all its launches in the timed region / their summed
+duration measured with HIP events on the launch stream.  `cpu_baseline` times the oracle's torch-CPU twin of the same
+graph (fp32, all host cores) on a bounded sample - a stand-in for the reference's TF-CPU path, which cannot run here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def cpu_baseline(sample_hw=192, seed=0):
+    """fwd+bwd of the identical layer graph on the host cores (oracle twin, fp32) for ONE sample_hw^2 grid."""
+    from oracle import hpnn as ohpnn, torch_twin, loss as oloss
+    from poisson_cnn_amd import configs
+    full = configs.hpnn()
+    cfg = full['model']
+    torch_twin.set_dtype(torch.float32)
+    try:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        p = ohpnn.init_params(cfg, seed=seed)
+        pt = {k: torch.tensor(v, dtype=torch.float32, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in p.items()}
+        rng = np.random.default_rng(seed)
+        H = W = sample_hw
+        rhs = torch.tensor(rng.uniform(-1, 1, (1, 1, H, W)), dtype=torch.float32)
+        dx = torch.tensor(rng.uniform(5e-3, 5e-2, (1, 1)), dtype=torch.float32)
+        tgt = torch.tensor(rng.standard_normal((1, 1, H, W)) * 0.1, dtype=torch.float32)
+        L = oloss.loss_wrapper(global_batch_size=1, **full['training']['loss_parameters'])
+
+        def step():
+            for v in pt.values():
+                v.grad = None
+            pred = ohpnn.forward(torch_twin, cfg, pt, rhs, dx)
+            loss = L(tgt, pred, rhs, np.concatenate([dx.numpy(), dx.numpy()], 1))
+            loss.backward()
+        step()                      # warm-up (oneDNN primitive creation)
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+            step()
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+    finally:
+        torch_twin.set_dtype(torch.float64)
+    px_per_s = H * W / dt
+    return {'value': px_per_s / (1024.0 * 1024.0), 'unit': 'grids/s (1024^2-grid equivalents, fwd+bwd)', 'cores': cores, 'kind': 'port',
+            'sample': '%d reps of fwd+bwd on one %dx%d grid (%.2f s each), oracle torch-CPU twin in fp32 - stand-in for TF-CPU' % (reps, H, W, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c4', choices=['c4', 'c3', 'small'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from poisson_cnn_amd import configs, ops, parallel
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import Adam
+
+    dp = parallel.DataParallel.from_env()
+    if dp.world_size != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, dp.world_size, args.gpus))
+    per_gpu, H = {'c4': (8, 1024), 'c3': (32, 512), 'small': (2, 256)}[args.workload]
+    W = H
+    full = configs.hpnn()
+    model = Homogeneous_Poisson_NN_Legacy(**full['model'])
+    gbs = per_gpu * dp.world_size
+    model.compile(loss=loss_wrapper(global_batch_size=gbs, **full['training']['loss_parameters']),
+                  optimizer=Adam(**full['training']['optimizer_parameters']))
+    dp.attach(model)
+    g = torch.Generator(device='cpu').manual_seed(4 + dp.rank)
+    rhs = (torch.rand((per_gpu, 1, H, W), generator=g) * 2 - 1).cuda()
+    rhs = rhs / rhs.abs().amax(dim=(1, 2, 3), keepdim=True)
+    dx = (torch.rand((per_gpu, 1), generator=g) * 4.5e-2 + 5e-3).cuda()
+    target = (torch.randn((per_gpu, 1, H, W), generator=g) * 0.1).cuda()
+    batch = ((rhs, dx), target)
+
+    for _ in range(args.warmup):
+        model.train_step(batch)
+    prof = ops.KernelTimer()
+    dp.barrier()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logs = model.train_step(batch)
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    elapsed = dp.max_over_ranks(elapsed)
+    loss = float(logs['loss'])
+
+    if dp.rank == 0:
+        flops, secs, calls = prof.totals('conv_fwd')
+        wf, ws_, wc = prof.totals('conv_wgrad')
+        out = {
+            'metric': 'grids/sec (fwd+bwd) at %d^2' % H, 'value': gbs * args.steps / elapsed, 'unit': 'grids/s',
+            'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: Homogeneous_Poisson_NN_Legacy(hpnn.json) full train step (fwd+bwd+loss+Adam%s), %d x %dx%d Dirichlet grids per GPU'
+                                   % (args.workload, '+RCCL all-reduce' if dp.world_size > 1 else '', per_gpu, H, W),
+                       'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'final_loss': loss},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_kernel<1> (fused pad+conv fwd and data-gradient)', 'achieved': flops / secs / 1e12 if secs else None,
+                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS if secs else None,
+                         'traffic': None, 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,
+                         'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / PEAK_FP32_MFMA_TFLOPS if ws_ else None,
+                                          'launches': wc, 'avg_launch_ms': 1e3 * ws_ / wc if wc else None}},
+        }
+        if dp.world_size == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -11,7 +11,12 @@ import torch.nn.functional as F
 
 from . import np_ops
 
-DT = torch.float64
+DT = torch.float64   # bench.py's cpu_baseline leg switches this to float32 for timing (set_dtype)
+
+
+def set_dtype(dt):
+    global DT
+    DT = dt
 
 
 def asarray(x):

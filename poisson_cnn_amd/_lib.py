@@ -2,6 +2,10 @@
 fails, the product path raises."""
 import ctypes
 import os
+
+import torch  # noqa: F401  - MUST be imported before libpcnn.so is dlopen'ed: both then share torch's HIP runtime
+#                            (libamdhip64.so.7 is resolved by soname to the copy torch already loaded), so device pointers and
+#                            streams are valid on both sides.  Loading libpcnn first would start a second, separate runtime.
 from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

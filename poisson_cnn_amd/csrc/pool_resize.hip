@@ -253,6 +253,29 @@ extern "C" int pcnn_resize_tables(int method, int n_in, int n_out, int32_t* idx,
         for (int k = 0; k < 4; ++k) w4[k] *= inv;
       }
       for (int k = 0; k < 4; ++k) Wt[k] = w4[k];
+    } else if (method == PCNN_RESIZE_BICUBIC_LEGACY_ALIGN_CORNERS) {
+      // tf.compat.v1.image.resize_images(BICUBIC, align_corners=True): legacy scaler, a = -0.75, clamped taps
+      static std::vector<float> legacy;
+      if (legacy.empty()) {
+        const float a = -0.75f;
+        legacy.resize((1024 + 1) * 2);
+        for (int i = 0; i <= 1024; ++i) {
+          float x = (float)i * 1.0f / 1024.0f;
+          legacy[2 * i] = ((a + 2) * x - (a + 3)) * x * x + 1;
+          x += 1.0f;
+          legacy[2 * i + 1] = ((a * x - 5 * a) * x + 8 * a) * x - 4 * a;
+        }
+      }
+      const float sc = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : (float)n_in / (float)n_out;
+      const float src = (float)o * sc;
+      const int loc = (int)floorf(src);
+      const int off = (int)lrintf((src - (float)loc) * 1024.0f);
+      const float w4[4] = {legacy[off * 2 + 1], legacy[off * 2], legacy[(1024 - off) * 2], legacy[(1024 - off) * 2 + 1]};
+      for (int k = 0; k < 4; ++k) {
+        const int raw = loc - 1 + k;
+        I[k] = raw < 0 ? 0 : (raw > n_in - 1 ? n_in - 1 : raw);
+        Wt[k] = w4[k];
+      }
     } else {
       return 2;
     }

@@ -1,0 +1,82 @@
+"""ctypes wrappers of the dataset kernels of libpcnn (include/pcnn.h, "dataset" section)."""
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..ops import _p, handle
+
+_dst_cache = {}
+
+
+def dst_matrices(n, device):
+    """Device copies of the orthonormal DST-I matrix and eigenvalues for an n-point axis (cached per n: shapes change per batch)."""
+    key = (n, str(device))
+    if key not in _dst_cache:
+        m = n - 2
+        S = np.zeros((m, m), dtype=np.float64)
+        lam = np.zeros(m, dtype=np.float64)
+        rc = _lib.load().pcnn_dst_setup(c_int(n), S.ctypes.data_as(c_void_p), lam.ctypes.data_as(c_void_p))
+        if rc != 0:
+            raise RuntimeError('pcnn_dst_setup failed (%d)' % rc)
+        _dst_cache[key] = (torch.tensor(S, device=device), torch.tensor(lam, device=device))
+    return _dst_cache[key]
+
+
+def fd_poisson_dst(rhs, left, right, bottom, top, dx):
+    """rhs (N,H,W); left/right (N,W); bottom/top (N,H); dx (N,) -> soln (N,H,W), all fp32 CUDA tensors."""
+    N, H, W = rhs.shape
+    Sh, lh = dst_matrices(H, rhs.device)
+    Sw, lw = dst_matrices(W, rhs.device)
+    tmp = torch.empty(2 * N * (H - 2) * (W - 2), dtype=torch.float64, device=rhs.device)
+    soln = torch.empty_like(rhs)
+    handle().call('pcnn_fd_poisson_dst', c_int(N), c_int(H), c_int(W), _p(rhs), _p(left), _p(right), _p(bottom), _p(top), _p(dx),
+                  _p(Sh), _p(lh), _p(Sw), _p(lw), _p(tmp), _p(soln))
+    return soln
+
+
+def series_synthesis(coef, H, W, trig, out=None, accumulate=False):
+    """coef (N,ka,kb) -> (N,H,W): sum c[A,B] f((A+1)x) f((B+1)y), f = sin (trig=0) / cos (trig=1)."""
+    N, ka, kb = coef.shape
+    if out is None:
+        out = torch.empty((N, H, W), dtype=torch.float32, device=coef.device)
+        accumulate = False
+    handle().call('pcnn_series_synthesis', c_int(N), c_int(H), c_int(W), c_int(ka), c_int(kb), _p(coef.contiguous()), c_int(trig),
+                  c_int(1 if accumulate else 0), _p(out))
+    return out
+
+
+def separable_sum(U, V, out=None, accumulate=False):
+    """U (N,R,H), V (N,R,W) -> (N,H,W)"""
+    N, R, H = U.shape
+    W = V.shape[2]
+    if out is None:
+        out = torch.empty((N, H, W), dtype=torch.float32, device=U.device)
+        accumulate = False
+    handle().call('pcnn_separable_sum', c_int(N), c_int(H), c_int(W), c_int(R), _p(U.contiguous()), _p(V.contiguous()), c_int(1 if accumulate else 0), _p(out))
+    return out
+
+
+def set_max_magnitude(x, target):
+    """In place: x[n] *= target[n]/max|x[n]|; returns the factors."""
+    N = x.shape[0]
+    f = torch.empty((N,), dtype=torch.float32, device=x.device)
+    handle().call('pcnn_set_max_magnitude', c_int(N), c_int64(x.numel() // N), _p(target), _p(x), _p(f))
+    return f
+
+
+def scale_samples(x, s):
+    N = x.shape[0]
+    handle().call('pcnn_scale_samples', c_int(N), c_int64(x.numel() // N), _p(s), _p(x))
+    return x
+
+
+def max_abs_per_sample(x):
+    """max|x[n]| via the loss partial-sum kernel (column 3)."""
+    return ops.loss_partials(x, x, None)[:, 3].contiguous()
+
+
+def resize_legacy_bicubic(x, out_hw):
+    """tf.compat.v1.image.resize_images(BICUBIC, align_corners=True) of (N,h,w,C) (dataset/utils/image_resize.py:20)."""
+    return ops.resize_fwd(x, out_hw, 'bicubic_legacy')

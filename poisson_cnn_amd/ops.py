@@ -13,7 +13,7 @@ from ._lib import ConvDesc
 PAD_MODES = {'CONSTANT': 0, 'SYMMETRIC': 1, 'REFLECT': 2}
 ACTS = {'linear': 0, 'leaky_relu': 1, 'tanh': 2, 'relu': 3}
 POOLS = {'average': 0, 'avg': 0, 'max': 1}
-RESIZE = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
+RESIZE = {'nearest': 0, 'bilinear': 1, 'bicubic': 2, 'bicubic_legacy': 3}
 LEAKY_ALPHA = 0.2   # tf.nn.leaky_relu default
 BN_EPS = 1e-3       # tf.keras.layers.BatchNormalization default
 
@@ -89,6 +89,41 @@ class Workspace:
 _default_ws = Workspace()
 
 
+class KernelTimer:
+    """Live per-kernel timing for bench.py: HIP events (torch.cuda.Event on the launch stream) around every launch of the
+    MFMA kernels, with the algorithmic FLOP count of each launch."""
+
+    def __init__(self):
+        self.records = []   # (kind, flops, start_event, end_event)
+
+    def launch(self, kind, flops, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((kind, flops, s, e))
+
+    def totals(self, kind):
+        torch.cuda.synchronize()
+        sel = [r for r in self.records if r[0] == kind]
+        return sum(r[1] for r in sel), sum(r[2].elapsed_time(r[3]) for r in sel) * 1e-3, len(sel)
+
+
+_timer = None
+
+
+def set_kernel_timer(t):
+    global _timer
+    _timer = t
+
+
+def _launch(kind, flops, fn):
+    if _timer is None:
+        fn()
+    else:
+        _timer.launch(kind, flops, fn)
+
+
 # ----------------------------------------------------------------------------- convolution
 def conv_desc(x_shape, ldx, w_shape, out_hw, ldy, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, act='linear', ld_res=0, ld_act=0):
     N, H, W, Cin = x_shape
@@ -108,7 +143,8 @@ def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CON
         out = empty((N, Ho, Wo, Cout), x.device)
     d = conv_desc(x.shape, _ld(x), w.shape, (Ho, Wo), _ld(out), pad_top, pad_left, pad_mode, pad_value, act,
                   _ld(residual) if residual is not None else 0, _ld(act_out) if act_out is not None else 0)
-    handle().call('pcnn_conv2d_fwd', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out))
+    _launch('conv_fwd', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout,
+            lambda: handle().call('pcnn_conv2d_fwd', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out)))
     return out
 
 
@@ -128,7 +164,8 @@ def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_
     wsb = (ws or _default_ws).get(nbytes, x.device)
     dw = out if out is not None else empty(tuple(w_shape), x.device)
     assert dw.is_contiguous()
-    handle().call('pcnn_conv2d_wgrad', byref(d), _p(x), _p(dz), _p(dw), _p(wsb), c_size_t(wsb.numel() * 4))
+    _launch('conv_wgrad', 2.0 * N * Ho * Wo * w_shape[0] * w_shape[1] * w_shape[2] * w_shape[3],
+            lambda: handle().call('pcnn_conv2d_wgrad', byref(d), _p(x), _p(dz), _p(dw), _p(wsb), c_size_t(wsb.numel() * 4)))
     return dw
 
 
