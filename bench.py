@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
-def cpu_baseline(sample_hw=192, seed=0):
+def cpu_baseline(sample_hw=128, seed=0):
     """fwd+bwd of the identical layer graph on the host cores (oracle twin, fp32) for ONE sample_hw^2 grid."""
     from oracle import hpnn as ohpnn, torch_twin, loss as oloss
     from poisson_cnn_amd import configs
@@ -34,7 +34,8 @@ def cpu_baseline(sample_hw=192, seed=0):
     cfg = full['model']
     torch_twin.set_dtype(torch.float32)
     try:
-        cores = os.cpu_count() or 1
+        # the GPU box gives one GPU's job a 16-core CPU share; using every visible core of the host oversubscribes the cgroup
+        cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
         torch.set_num_threads(cores)
         p = ohpnn.init_params(cfg, seed=seed)
         pt = {k: torch.tensor(v, dtype=torch.float32, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in p.items()}
@@ -54,7 +55,7 @@ def cpu_baseline(sample_hw=192, seed=0):
         step()                      # warm-up (oneDNN primitive creation)
         t0 = time.perf_counter()
         reps = 0
-        while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+        while reps < 1 or (time.perf_counter() - t0 < 12.0 and reps < 20):
             step()
             reps += 1
         dt = (time.perf_counter() - t0) / reps
@@ -97,8 +98,15 @@ def main():
     target = (torch.randn((per_gpu, 1, H, W), generator=g) * 0.1).cuda()
     batch = ((rhs, dx), target)
 
+    def note(msg):
+        if dp.rank == 0:
+            print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+    note('model built, %d params; warm-up' % model.count_params())
     for _ in range(args.warmup):
         model.train_step(batch)
+    torch.cuda.synchronize()
+    note('warm-up done; timing %d steps' % args.steps)
     prof = ops.KernelTimer()
     dp.barrier()
     torch.cuda.synchronize()
@@ -111,6 +119,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     elapsed = dp.max_over_ranks(elapsed)
+    note('timed region: %.3f s' % elapsed)
     loss = float(logs['loss'])
 
     if dp.rank == 0:
@@ -130,6 +139,7 @@ def main():
                                           'launches': wc, 'avg_launch_ms': 1e3 * ws_ / wc if wc else None}},
         }
         if dp.world_size == 1 and not args.no_cpu_baseline:
+            note('cpu baseline (bounded sample) ...')
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
 

@@ -27,6 +27,7 @@ struct ConvParams {
   int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, pt, pl, pad_mode; float pad_value; int act; float alpha;
   int ld_res, ld_act;
   int tiles_x, tiles_y, CK, PS, vec_ok;
+  const float* wp;   // packed filter, see pack_weights_kernel
 };
 
 template <int NT>
@@ -86,43 +87,35 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvPara
     }
     __syncthreads();
 
-    // ---- K loop over (tap, 8-channel sub-chunk); B prefetched one step ahead
+    // ---- K loop over (tap, 8-channel sub-chunk).  The packed filter is consumed strictly sequentially ([tap][group]), so
+    // the B operand is a pointer that advances by one step; steps are unrolled by two with ping-pong registers so that the
+    // load of step s+1 stays in flight (counted vmcnt) under the 16 MFMAs of step s and no register copies are needed.
     const int nsub = ck >> 3;
+    const int nsub_tot = cin_pad >> 3;
     const int nsteps = p.kh * p.kw * nsub;
-    float bcur[NT][4], bnxt[NT][4];
-    auto load_b = [&](int tap, int sub, float (&b)[NT][4]) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int co = t * 32 + col;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ci = c0 + sub * 8 + 4 * half + j;
-          b[t][j] = (ci < p.Cin && co < p.Cout) ? p.w[((int64_t)tap * p.Cin + ci) * p.Cout + co] : 0.f;
-        }
-      }
-    };
-    load_b(0, 0, bcur);
+    const f32x4* wlane = reinterpret_cast<const f32x4*>(p.wp) + half * (NT * 32) + col;
     int tap = 0, sub = 0, ki = 0, kj = 0;
-    for (int s = 0; s < nsteps; ++s) {
+    auto load_b = [&](f32x4 (&b)[NT], int tp, int sb) {
+      const f32x4* src = wlane + (int64_t)(tp * nsub_tot + (c0 >> 3) + sb) * (2 * NT * 32);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = src[t * 32];
+    };
+    auto step = [&](const f32x4 (&bc)[NT], f32x4 (&bn)[NT], bool more) {
       int ntap = tap, nsb = sub + 1, nki = ki, nkj = kj;
       if (nsb == nsub) { nsb = 0; ntap = tap + 1; nkj = kj + 1; if (nkj == p.kw) { nkj = 0; nki = ki + 1; } }
-      if (s + 1 < nsteps) load_b(ntap, nsb, bnxt);
+      load_b(bn, ntap, nsb);   // unconditional (the scratch has one spare step past the end): keeps the in-flight count static
       const float* abase = &lds[((wave * MT + ki) * TC + (col + kj)) * PS + sub * 8 + 4 * half];
       f32x4 a[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(abase + m * TC * PS);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bcur[t][j], acc[m][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bcur[t][j] = bnxt[t][j];
-      if (nki != ki || s + 1 == nsteps) {   // end of a filter row: flush the block sum
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][j], bc[t][j], acc[m][t], 0, 0, 0);
+      if (nki != ki || !more) {   // end of a filter row: flush the block sum
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -131,7 +124,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvPara
             for (int i = 0; i < 16; ++i) { tot[m][t][i] += acc[m][t][i]; acc[m][t][i] = 0.f; }
       }
       tap = ntap; sub = nsb; ki = nki; kj = nkj;
+    };
+    f32x4 b0[NT], b1[NT];
+    load_b(b0, 0, 0);
+    int s = 0;
+    for (; s + 2 <= nsteps; s += 2) {
+      step(b0, b1, true);
+      step(b1, b0, s + 2 < nsteps);
     }
+    if (s < nsteps) step(b0, b1, false);
   }
 
   // ---- epilogue
@@ -159,6 +160,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvPara
         p.y[pix * p.ldy + co] = v;
       }
     }
+  }
+}
+
+// w (kh,kw,Cin,Cout) HWIO -> wp [tap][cin_pad/8][2][NT*32][4], zero padded: wp[...][g][h][co][j] = w[tap][8g + 4h + j][co]
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int Cin, int Cout, int cin_pad, int NT) {
+  const int64_t total = (int64_t)taps * cin_pad * NT * 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = i & 3; int64_t r = i >> 2; const int co = r % (NT * 32); r /= (NT * 32); const int h = r & 1; r >>= 1;
+    const int g = r % (cin_pad >> 3); const int tap = r / (cin_pad >> 3);
+    const int ci = 8 * g + 4 * h + j;
+    wp[i] = (ci < Cin && co < Cout) ? w[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
   }
 }
 
@@ -207,6 +219,22 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
   p.CK = CK; p.PS = ((CK / 4) % 2 == 0) ? CK + 4 : CK;
   const size_t lds = (size_t)TR * TC * p.PS * 4;
   PCNN_REQUIRE(h, lds <= 160 * 1024, "pcnn_conv2d_fwd: halo tile needs %zu B of LDS", lds);
+  {
+    const int NTh = d->Cout <= 32 ? 1 : 2;
+    const size_t need = ((size_t)d->kh * d->kw * cin_pad + 16) * NTh * 32 * sizeof(float);   // + spare K-steps for the prefetch past the end
+    if (h->scratch_bytes < need) {
+      // grown on demand; stream-ordered reuse is safe because pack and conv run back to back on the handle's stream
+      if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+      size_t cap = need < (4u << 20) ? (4u << 20) : need;
+      if (hipMalloc(&h->scratch, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_conv2d_fwd: cannot allocate %zu B of filter scratch", cap);
+      h->scratch_bytes = cap;
+    }
+    const int64_t total = (int64_t)d->kh * d->kw * cin_pad * NTh * 32;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(total, 256), 2048)), dim3(256), 0, h->stream, w,
+                       static_cast<float*>(h->scratch), d->kh * d->kw, d->Cin, d->Cout, cin_pad, NTh);
+    PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_fwd(pack)");
+    p.wp = static_cast<const float*>(h->scratch);
+  }
   const int64_t nblk = (int64_t)d->N * p.tiles_x * p.tiles_y;
   PCNN_REQUIRE(h, nblk < (1ll << 31), "pcnn_conv2d_fwd: grid too large");
   dim3 grid((unsigned)nblk), block(256);

@@ -114,23 +114,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       }
     }
     __syncthreads();
-    // ---- accumulate: K = pixels of the tile, two per MFMA
+    // ---- accumulate: K = pixels of the tile, two per MFMA.  Blocks of 8 pixel pairs: the dz fragments (B) are read once
+    // and reused by every filter column this wave owns; the x fragments (A) are read in batches of 8 so the MFMAs of a
+    // column issue back to back.  `ntw` is wave-uniform (scalar branch, no exec masking).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ntw = kwg > wv ? (kwg - wv + WAVES - 1) / WAVES : 0;
     for (int r = 0; r < WTH; ++r) {
-#pragma unroll 4
-      for (int xp = 0; xp < WTW; xp += 2) {
-        float b[NTC];
+      for (int xp0 = 0; xp0 < WTW; xp0 += 16) {
+        float b[8][NTC];
 #pragma unroll
-        for (int q = 0; q < NTC; ++q) b[q] = dzs[(r * WTW + xp + half) * p.Cout + q * 32 + col];
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int q = 0; q < NTC; ++q) b[u][q] = dzs[(r * WTW + xp0 + 2 * u + half) * p.Cout + q * 32 + col];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-          const int kj = wave + WAVES * t;
-          if (kj < kwg) {
+          if (t < ntw) {
+            const int kj = wv + WAVES * t;
+            float a[8][MTC];
 #pragma unroll
-            for (int m = 0; m < MTC; ++m) {
-              const float a = xs[(r * TCx + xp + half + kj) * p.Cin + m * 32 + col];
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
-              for (int q = 0; q < NTC; ++q) acc[t][m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[q], acc[t][m][q], 0, 0, 0);
-            }
+              for (int m = 0; m < MTC; ++m) a[u][m] = xs[(r * TCx + xp0 + 2 * u + half + kj) * p.Cin + m * 32 + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+              for (int m = 0; m < MTC; ++m)
+#pragma unroll
+                for (int q = 0; q < NTC; ++q) acc[t][m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[u][q], acc[t][m][q], 0, 0, 0);
           }
         }
       }
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   // ---- write partials ws[split][ki][kj][ci][co]
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
-    const int kj = wave + WAVES * t;
+    const int kj = __builtin_amdgcn_readfirstlane(wave) + WAVES * t;
     if (kj >= kwg) continue;
     float* dst = p.ws + (((int64_t)split * p.kh + ki) * p.kw + (kj0 + kj)) * p.Cin * p.Cout;
 #pragma unroll

@@ -16,6 +16,7 @@ extern "C" int pcnn_create(int device, void* hip_stream, pcnn_handle* out) {
 }
 
 extern "C" int pcnn_destroy(pcnn_handle h) {
+  if (h && h->scratch) (void)hipFree(h->scratch);
   delete h;
   return 0;
 }

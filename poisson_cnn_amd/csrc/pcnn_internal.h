@@ -10,6 +10,8 @@ struct pcnn_handle_s {
   int device;
   hipStream_t stream;
   std::string err;
+  void* scratch = nullptr;        // packed-filter scratch of the conv kernels (grown on demand, owned by the handle)
+  size_t scratch_bytes = 0;
 };
 
 #define PCNN_FAIL(h, ...)                                   \
