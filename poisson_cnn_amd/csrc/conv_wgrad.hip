@@ -18,32 +18,41 @@ constexpr int WTH = 8, WTW = 32, WAVES = 4;
 struct WgradParams {
   const float* x; const float* dz; float* ws;
   int N, H, W, Cin, ldx, Ho, Wo, Cout, lddz, kh, kw, pt, pl, pad_mode; float pad_value;
-  int tiles_x, tiles_y, ntiles, S, KWG;
+  int tiles_x, tiles_y, ntiles, S, KWG, lg;
   int vecx, vecdz;
 };
 
-struct WgradPlan { int S, KWG, TAPS, MTC, NTC, gz; size_t lds; int ntiles, tiles_x, tiles_y; };
+struct WgradPlan { int S, KWG, TAPS, MTC, NTC, gz, lg; size_t lds; int ntiles, tiles_x, tiles_y; };
 
 static WgradPlan make_plan(const pcnn_conv_desc* d) {
   WgradPlan pl;
-  pl.MTC = pcnn_cdiv(d->Cin, 32); pl.NTC = pcnn_cdiv(d->Cout, 32);
-  int maxTaps = 4 / (pl.MTC * pl.NTC);   // <= 4 accumulator tiles (+4 running totals) per wave: 128 VGPRs
-  if (maxTaps > 4) maxTaps = 4;
-  if (maxTaps < 1) maxTaps = 1;
-  pl.KWG = d->kw < 4 * maxTaps ? d->kw : 4 * maxTaps;
-  pl.TAPS = pcnn_cdiv(pl.KWG, WAVES);
+  // The (filter column, input channel) index space of one filter row is CONTIGUOUS in the dense NHWC x tile
+  // ((x + kj)*Cin + ci = x*Cin + (kj*Cin + ci)), so it is cut into 32-row MFMA tiles irrespective of Cin: no channel
+  // padding of the M dimension, and tiles are dealt round-robin to the 4 waves (<= 4 tiles + 4 running totals each).
+  pl.MTC = 1; pl.lg = 0;
+  pl.NTC = pcnn_cdiv(d->Cout, 32);
+  int maxTiles = 16 / pl.NTC;
+  if (maxTiles < 4) maxTiles = 4;
+  int kwg = (maxTiles * 32) / d->Cin;               // filter columns per workgroup
+  if (kwg < 1) kwg = 1;
+  pl.KWG = d->kw < kwg ? d->kw : kwg;
+  pl.TAPS = pcnn_cdiv(pcnn_cdiv(pl.KWG * d->Cin, 32), WAVES);
   pl.gz = pcnn_cdiv(d->kw, pl.KWG);
   pl.tiles_x = pcnn_cdiv(d->Wo, WTW); pl.tiles_y = pcnn_cdiv(d->Ho, WTH);
   pl.ntiles = d->N * pl.tiles_x * pl.tiles_y;
-  int S = pcnn_cdiv(2048, d->kh * pl.gz);
+  pl.lds = ((size_t)WTH * (WTW + pl.KWG - 1) * d->Cin + (size_t)WTH * WTW * d->Cout + 128) * 4;
+  // All workgroups of this grid run for about the same time, so the grid is sized to fill the chip's resident slots
+  // (256 CUs x workgroups per CU by LDS) an integral number of times: a 2055-workgroup grid on 512 slots costs 5 rounds.
+  const int per_cu = pl.lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int slots = 256 * per_cu, rounds = 4;
+  int S = (slots * rounds) / (d->kh * pl.gz);
   if (S > pl.ntiles) S = pl.ntiles;
   if (S < 1) S = 1;
   pl.S = S;
-  pl.lds = ((size_t)WTH * (WTW + pl.KWG - 1) * d->Cin + (size_t)WTH * WTW * d->Cout + 128) * 4;
   return pl;
 }
 
-template <int MTC, int NTC, int TAPS>
+template <int NTC, int TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -54,15 +63,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   float* dzs = lds + ((WTH * TCx * p.Cin + 64 + 3) & ~3);
 
   // blocked summation: `acc` holds one tile (256 pixels), `tot` the running sum over the workgroup's tiles
-  f32x16 acc[TAPS][MTC][NTC], tot[TAPS][MTC][NTC];
+  f32x16 acc[TAPS][NTC], tot[TAPS][NTC];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int m = 0; m < MTC; ++m)
+    for (int q = 0; q < NTC; ++q)
 #pragma unroll
-      for (int q = 0; q < NTC; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[t][m][q][i] = 0.f; tot[t][m][q][i] = 0.f; }
+      for (int i = 0; i < 16; ++i) { acc[t][q][i] = 0.f; tot[t][q][i] = 0.f; }
 
   for (int tile = split; tile < p.ntiles; tile += p.S) {
     int tt = tile;
@@ -73,43 +80,125 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
     const float* dzin = p.dz + (int64_t)n * p.Ho * p.Wo * p.lddz;
     __syncthreads();
-    // ---- stage x rows (shifted by the filter row) with the BC padding applied
-    {
-      const int V = p.vecx ? 4 : 1;
-      const int units = TCx * p.Cin / V;
+    // ---- stage x rows (shifted by the filter row, BC padding applied) and the dz tile (zero outside the image).
+    // Fast path (16-byte aligned channel runs): 8 loads per lane are issued back to back from always-valid (select-ed)
+    // addresses and only afterwards padded and written to LDS, so 8 global loads are in flight per lane instead of one
+    // load -> wait -> store round trip per element.  Slow path (Cin or Cout not a multiple of 4): scalar elements.
+    // Interior fast path: the whole x window of this tile lies inside the image and pixels are dense (ldx == Cin), so
+    // every tile row is one contiguous run of TCx*Cin floats in HBM and in LDS: no per-element index arithmetic at all.
+    const int wy0 = y0 + ki - p.pt, wx0 = x0 + kj0 - p.pl;
+    const bool fast_x = p.vecx && p.ldx == p.Cin && wy0 >= 0 && wy0 + WTH <= p.H && wx0 >= 0 && wx0 + TCx <= p.W;
+    if (fast_x) {
+      const int upr = (TCx * p.Cin) >> 2;
       for (int r = wave; r < WTH; r += WAVES) {
-        const int sy = pcnn_pad_index(y0 + r + ki - p.pt, p.H, p.pad_mode);
-        for (int u = lane; u < units; u += 64) {
-          const int e = u * V, c = e / p.Cin, ch = e - c * p.Cin;
+        const f32x4* src = reinterpret_cast<const f32x4*>(xin + ((int64_t)(wy0 + r) * p.W + wx0) * p.Cin);
+        f32x4* dst = reinterpret_cast<f32x4*>(xs + r * TCx * p.Cin);
+        for (int u0 = 0; u0 < upr; u0 += 64 * 8) {
+          f32x4 v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const int u = u0 + 64 * q + lane; v[q] = src[u < upr ? u : 0]; }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const int u = u0 + 64 * q + lane; if (u < upr) dst[u] = v[q]; }
+        }
+      }
+    } else if (p.vecx) {
+      const int G = p.Cin >> 2;                        // float4 units per pixel
+      const int upr = TCx * G;                         // units per tile row
+      const int total = WTH * upr;
+      const float inv_upr = 1.0f / (float)upr, inv_G = 1.0f / (float)G;   // exact small-integer division via (u + 0.5) * 1/d
+      for (int base = tid; base < total; base += 256 * 8) {
+        f32x4 v[8];
+        int off[8];                                     // LDS float offset, or -1: skip, or (-2 - offset): padding value
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int u = base + 256 * q;
+          const int uu = u < total ? u : 0;
+          const int r = (int)(((float)uu + 0.5f) * inv_upr);
+          const int w = uu - r * upr;
+          const int c = (int)(((float)w + 0.5f) * inv_G);
+          const int ch = (w - c * G) << 2;
+          const int sy = pcnn_pad_index(y0 + r + ki - p.pt, p.H, p.pad_mode);
           const int sx = pcnn_pad_index(x0 + c + kj0 - p.pl, p.W, p.pad_mode);
-          float* dst = &xs[(r * TCx + c) * p.Cin + ch];
-          if (sy < 0 || sx < 0) {
-            for (int q = 0; q < V; ++q) dst[q] = p.pad_value;
-          } else {
-            const float* src = xin + ((int64_t)sy * p.W + sx) * p.ldx + ch;
-            if (V == 4) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
-            else dst[0] = src[0];
+          const bool inimg = sy >= 0 && sx >= 0;
+          v[q] = *reinterpret_cast<const f32x4*>(xin + ((int64_t)(inimg ? sy : 0) * p.W + (inimg ? sx : 0)) * p.ldx + ch);
+          const int o = (r * TCx + c) * p.Cin + ch;
+          off[q] = u < total ? (inimg ? o : -2 - o) : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (off[q] != -1) {
+            f32x4 t = v[q];
+            int o = off[q];
+            if (o < 0) { o = -2 - o; const float pv = p.pad_value; t[0] = pv; t[1] = pv; t[2] = pv; t[3] = pv; }
+            *reinterpret_cast<f32x4*>(&xs[o]) = t;
           }
         }
       }
+    } else {
+      const int units = TCx * p.Cin;
+      for (int r = wave; r < WTH; r += WAVES) {
+        const int sy = pcnn_pad_index(y0 + r + ki - p.pt, p.H, p.pad_mode);
+        for (int e = lane; e < units; e += 64) {
+          const int c = e / p.Cin, ch = e - c * p.Cin;
+          const int sx = pcnn_pad_index(x0 + c + kj0 - p.pl, p.W, p.pad_mode);
+          xs[(r * TCx + c) * p.Cin + ch] = (sy < 0 || sx < 0) ? p.pad_value : xin[((int64_t)sy * p.W + sx) * p.ldx + ch];
+        }
+      }
     }
-    // ---- stage the dz tile (zero outside the image)
-    {
-      const int V = p.vecdz ? 4 : 1;
-      const int units = WTW * p.Cout / V;
+    const bool fast_dz = p.vecdz && p.lddz == p.Cout && y0 + WTH <= p.Ho && x0 + WTW <= p.Wo;
+    if (fast_dz) {
+      const int upr = (WTW * p.Cout) >> 2;
+      for (int r = wave; r < WTH; r += WAVES) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(dzin + ((int64_t)(y0 + r) * p.Wo + x0) * p.Cout);
+        f32x4* dst = reinterpret_cast<f32x4*>(dzs + r * WTW * p.Cout);
+        for (int u0 = 0; u0 < upr; u0 += 64 * 4) {
+          f32x4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int u = u0 + 64 * q + lane; v[q] = src[u < upr ? u : 0]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int u = u0 + 64 * q + lane; if (u < upr) dst[u] = v[q]; }
+        }
+      }
+    } else if (p.vecdz) {
+      const int G = p.Cout >> 2;
+      const int upr = WTW * G;
+      const int total = WTH * upr;
+      const float inv_upr = 1.0f / (float)upr, inv_G = 1.0f / (float)G;
+      for (int base = tid; base < total; base += 256 * 8) {
+        f32x4 v[8];
+        int off[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int u = base + 256 * q;
+          const int uu = u < total ? u : 0;
+          const int r = (int)(((float)uu + 0.5f) * inv_upr);
+          const int w = uu - r * upr;
+          const int c = (int)(((float)w + 0.5f) * inv_G);
+          const int ch = (w - c * G) << 2;
+          const int oy = y0 + r, ox = x0 + c;
+          const bool inimg = oy < p.Ho && ox < p.Wo;
+          v[q] = *reinterpret_cast<const f32x4*>(dzin + ((int64_t)(inimg ? oy : 0) * p.Wo + (inimg ? ox : 0)) * p.lddz + ch);
+          const int o = (r * WTW + c) * p.Cout + ch;
+          off[q] = u < total ? (inimg ? o : -2 - o) : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (off[q] != -1) {
+            f32x4 t = v[q];
+            int o = off[q];
+            if (o < 0) { o = -2 - o; t[0] = 0.f; t[1] = 0.f; t[2] = 0.f; t[3] = 0.f; }
+            *reinterpret_cast<f32x4*>(&dzs[o]) = t;
+          }
+        }
+      }
+    } else {
+      const int units = WTW * p.Cout;
       for (int r = wave; r < WTH; r += WAVES) {
         const int oy = y0 + r;
-        for (int u = lane; u < units; u += 64) {
-          const int e = u * V, c = e / p.Cout, ch = e - c * p.Cout;
+        for (int e = lane; e < units; e += 64) {
+          const int c = e / p.Cout, ch = e - c * p.Cout;
           const int ox = x0 + c;
-          float* dst = &dzs[(r * WTW + c) * p.Cout + ch];
-          if (oy >= p.Ho || ox >= p.Wo) {
-            for (int q = 0; q < V; ++q) dst[q] = 0.f;
-          } else {
-            const float* src = dzin + ((int64_t)oy * p.Wo + ox) * p.lddz + ch;
-            if (V == 4) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
-            else dst[0] = src[0];
-          }
+          dzs[(r * WTW + c) * p.Cout + ch] = (oy >= p.Ho || ox >= p.Wo) ? 0.f : dzin[((int64_t)oy * p.Wo + ox) * p.lddz + ch];
         }
       }
     }
@@ -118,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     // and reused by every filter column this wave owns; the x fragments (A) are read in batches of 8 so the MFMAs of a
     // column issue back to back.  `ntw` is wave-uniform (scalar branch, no exec masking).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int ntw = kwg > wv ? (kwg - wv + WAVES - 1) / WAVES : 0;
+    const int ntile = (kwg * p.Cin + 31) >> 5;                 // 32-row tiles over the flattened (column, channel) space
+    const int ntw = ntile > wv ? (ntile - wv + WAVES - 1) / WAVES : 0;
     for (int r = 0; r < WTH; ++r) {
       for (int xp0 = 0; xp0 < WTW; xp0 += 16) {
         float b[8][NTC];
@@ -129,18 +219,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
           if (t < ntw) {
-            const int kj = wv + WAVES * t;
-            float a[8][MTC];
+            const float* ap = &xs[(r * TCx + xp0 + half) * p.Cin + (wv + WAVES * t) * 32 + col];
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = ap[2 * u * p.Cin];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-              for (int m = 0; m < MTC; ++m) a[u][m] = xs[(r * TCx + xp0 + 2 * u + half + kj) * p.Cin + m * 32 + col];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-              for (int m = 0; m < MTC; ++m)
-#pragma unroll
-                for (int q = 0; q < NTC; ++q) acc[t][m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[u][q], acc[t][m][q], 0, 0, 0);
+              for (int q = 0; q < NTC; ++q) acc[t][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][q], acc[t][q], 0, 0, 0);
           }
         }
       }
@@ -148,29 +234,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-      for (int m = 0; m < MTC; ++m)
+      for (int q = 0; q < NTC; ++q)
 #pragma unroll
-        for (int q = 0; q < NTC; ++q)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { tot[t][m][q][i] += acc[t][m][q][i]; acc[t][m][q][i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { tot[t][q][i] += acc[t][q][i]; acc[t][q][i] = 0.f; }
   }
-  // ---- write partials ws[split][ki][kj][ci][co]
+  // ---- write partials ws[split][ki][kj][ci][co]; C row R of tile jt -> flattened index jt*32 + R = kj*Cin + ci
+  {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nflat = kwg * p.Cin;
+    float* dst = p.ws + (((int64_t)split * p.kh + ki) * p.kw + kj0) * p.Cin * p.Cout;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) {
-    const int kj = __builtin_amdgcn_readfirstlane(wave) + WAVES * t;
-    if (kj >= kwg) continue;
-    float* dst = p.ws + (((int64_t)split * p.kh + ki) * p.kw + (kj0 + kj)) * p.Cin * p.Cout;
-#pragma unroll
-    for (int m = 0; m < MTC; ++m)
+    for (int t = 0; t < TAPS; ++t) {
+      const int jt = wv + WAVES * t;
+      if (jt * 32 >= nflat) continue;
 #pragma unroll
       for (int q = 0; q < NTC; ++q) {
         const int co = q * 32 + col;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int ci = m * 32 + 8 * (i >> 2) + 4 * half + (i & 3);
-          if (ci < p.Cin && co < p.Cout) dst[ci * p.Cout + co] = tot[t][m][q][i];
+          const int R = jt * 32 + 8 * (i >> 2) + 4 * half + (i & 3);
+          if (R < nflat && co < p.Cout) dst[(int64_t)R * p.Cout + co] = tot[t][q][i];   // [kj][ci][co] is contiguous in R
         }
       }
+    }
   }
 }
 
@@ -182,10 +268,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
-template <int MTC, int NTC, int TAPS>
+template <int NTC, int TAPS>
 void launch_wgrad(pcnn_handle h, const WgradParams& p, const WgradPlan& pl) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<MTC, NTC, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((wgrad_kernel<MTC, NTC, TAPS>), dim3(pl.S, p.kh, pl.gz), dim3(256), pl.lds, h->stream, p);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<NTC, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((wgrad_kernel<NTC, TAPS>), dim3(pl.S, p.kh, pl.gz), dim3(256), pl.lds, h->stream, p);
 }
 
 }  // namespace
@@ -199,7 +285,7 @@ extern "C" size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d) {
 extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
                                  void* workspace, size_t workspace_bytes) {
   PCNN_REQUIRE(h, h && d && x && dz && dw && workspace, "pcnn_conv2d_wgrad: null argument");
-  PCNN_REQUIRE(h, d->Cin >= 1 && d->Cin <= 64 && d->Cout >= 1 && d->Cout <= 64, "pcnn_conv2d_wgrad: channels %d->%d unsupported (<=64)", d->Cin, d->Cout);
+  PCNN_REQUIRE(h, d->Cin >= 1 && d->Cin <= 128 && d->Cout >= 1 && d->Cout <= 64, "pcnn_conv2d_wgrad: channels %d->%d unsupported (<=64)", d->Cin, d->Cout);
   PCNN_REQUIRE(h, d->ldx >= d->Cin && d->ldy >= d->Cout, "pcnn_conv2d_wgrad: channel stride smaller than channel count");
   WgradPlan pl = make_plan(d);
   PCNN_REQUIRE(h, workspace_bytes >= pcnn_conv2d_wgrad_workspace(d), "pcnn_conv2d_wgrad: workspace too small");
@@ -208,13 +294,12 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
   p.x = x; p.dz = dz; p.ws = static_cast<float*>(workspace);
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.lddz = d->ldy;
   p.kh = d->kh; p.kw = d->kw; p.pt = d->pad_top; p.pl = d->pad_left; p.pad_mode = d->pad_mode; p.pad_value = d->pad_value;
-  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S; p.KWG = pl.KWG;
+  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S; p.KWG = pl.KWG; p.lg = pl.lg;
   p.vecx = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   p.vecdz = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
-#define PCNN_WG(M, Q, T) if (pl.MTC == M && pl.NTC == Q && pl.TAPS == T) { launch_wgrad<M, Q, T>(h, p, pl); } else
-  PCNN_WG(1, 1, 1) PCNN_WG(1, 1, 2) PCNN_WG(1, 1, 3) PCNN_WG(1, 1, 4)
-  PCNN_WG(2, 1, 1) PCNN_WG(2, 1, 2) PCNN_WG(1, 2, 1) PCNN_WG(1, 2, 2) PCNN_WG(2, 2, 1)
-  { PCNN_FAIL(h, "pcnn_conv2d_wgrad: no kernel for MTC=%d NTC=%d TAPS=%d", pl.MTC, pl.NTC, pl.TAPS); }
+#define PCNN_WG(Q, T) if (pl.NTC == Q && pl.TAPS == T) { launch_wgrad<Q, T>(h, p, pl); } else
+  PCNN_WG(1, 1) PCNN_WG(1, 2) PCNN_WG(1, 3) PCNN_WG(1, 4) PCNN_WG(2, 1) PCNN_WG(2, 2)
+  { PCNN_FAIL(h, "pcnn_conv2d_wgrad: no kernel for NTC=%d TAPS=%d", pl.NTC, pl.TAPS); }
 #undef PCNN_WG
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad");
   const int64_t nel = (int64_t)d->kh * d->kw * d->Cin * d->Cout;

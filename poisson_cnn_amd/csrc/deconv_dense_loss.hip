@@ -3,6 +3,14 @@
 #include <math.h>
 #include "pcnn_internal.h"
 
+// MFMA paths (deconv_mfma.hip): return -1 when the shape is outside their coverage
+int pcnn_deconv_fwd_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* x, int ldx, const float* k,
+                         const float* bias, float alpha, float beta, float* y, int ldy);
+int pcnn_deconv_bwd_data_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* dy, int lddy, const float* k,
+                              float alpha, float* dx, int lddx);
+int pcnn_deconv_bwd_filter_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* x, int ldx, const float* dy,
+                                int lddy, float* partial, int* S_out);
+
 namespace {
 
 static dim3 grid1d(int64_t total, int block = 256, int maxb = 16384) {
@@ -259,6 +267,10 @@ extern "C" int pcnn_deconv_fwd(pcnn_handle h, int N, int hc, int wc, int Cin, in
                                const float* bias, float alpha, float beta, float* y, int ldy) {
   PCNN_REQUIRE(h, h && x && k && y, "pcnn_deconv_fwd: null argument");
   PCNN_REQUIRE(h, f >= 1 && hc == pcnn_cdiv(H, f) && wc == pcnn_cdiv(W, f), "pcnn_deconv_fwd: input must be ceil(output/stride) (SAME transpose)");
+  {
+    const int rc = pcnn_deconv_fwd_mfma(h, N, hc, wc, Cin, H, W, Cout, f, x, ldx, k, bias, alpha, beta, y, ldy);
+    if (rc >= 0) return rc;
+  }
   const int py = (hc * f - H) / 2, px = (wc * f - W) / 2;
   hipLaunchKernelGGL(deconv_fwd_kernel, grid1d((int64_t)N * H * W * Cout), dim3(256), 0, h->stream, N, hc, wc, Cin, H, W, Cout, f, py, px, x, ldx, k, bias,
                      alpha, beta, y, ldy);
@@ -270,6 +282,10 @@ extern "C" int pcnn_deconv_bwd_data(pcnn_handle h, int N, int hc, int wc, int Ci
                                     const float* k, float alpha, float* dx, int lddx) {
   PCNN_REQUIRE(h, h && dy && k && dx, "pcnn_deconv_bwd_data: null argument");
   PCNN_REQUIRE(h, f >= 1 && hc == pcnn_cdiv(H, f) && wc == pcnn_cdiv(W, f), "pcnn_deconv_bwd_data: shape mismatch");
+  {
+    const int rc = pcnn_deconv_bwd_data_mfma(h, N, hc, wc, Cin, H, W, Cout, f, dy, lddy, k, alpha, dx, lddx);
+    if (rc >= 0) return rc;
+  }
   const int py = (hc * f - H) / 2, px = (wc * f - W) / 2;
   hipLaunchKernelGGL(deconv_bwd_data_kernel, grid1d((int64_t)N * hc * wc * Cin), dim3(256), 0, h->stream, N, hc, wc, Cin, H, W, Cout, f, py, px, dy, lddy, k,
                      alpha, dx, lddx);
@@ -293,8 +309,16 @@ extern "C" int pcnn_deconv_bwd_filter(pcnn_handle h, int N, int hc, int wc, int 
   int64_t npix = (int64_t)N * hc * wc;
   int S = (int)(npix < DECONV_SPLITS ? npix : DECONV_SPLITS);
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(deconv_bwd_filter_kernel, dim3(S, f * f), dim3(256), 0, h->stream, N, hc, wc, Cin, H, W, Cout, f, py, px, x, ldx, dy, lddy, partial);
-  PCNN_CHECK_LAUNCH(h, "pcnn_deconv_bwd_filter");
+  {
+    int Sm = 0;
+    const int rc = pcnn_deconv_bwd_filter_mfma(h, N, hc, wc, Cin, H, W, Cout, f, x, ldx, dy, lddy, partial, &Sm);
+    if (rc > 0) return rc;
+    if (rc == 0) S = Sm;
+    else {
+      hipLaunchKernelGGL(deconv_bwd_filter_kernel, dim3(S, f * f), dim3(256), 0, h->stream, N, hc, wc, Cin, H, W, Cout, f, py, px, x, ldx, dy, lddy, partial);
+      PCNN_CHECK_LAUNCH(h, "pcnn_deconv_bwd_filter");
+    }
+  }
   const int64_t nel = (int64_t)f * f * Cout * Cin;
   hipLaunchKernelGGL(reduce_splits_kernel, grid1d(nel), dim3(256), 0, h->stream, partial, dk, nel, S, alpha);
   PCNN_CHECK_LAUNCH(h, "pcnn_deconv_bwd_filter(reduce)");

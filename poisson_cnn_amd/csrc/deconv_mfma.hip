@@ -1,0 +1,264 @@
+// Transposed convolution with kernel == stride as per-tap 32x32 GEMMs on the fp32 matrix cores.
+//   fwd      : y[n, yc f+ty-py, xc f+tx-px, co] = beta*y + alpha*(bias[co] + sum_ci x[n,yc,xc,ci] K[ty,tx,co,ci])
+//   bwd data : dx[n,yc,xc,ci] = alpha * sum_{ty,tx,co} dy[fine(ty,tx)][co] K[ty,tx,co,ci]
+//   bwd filt : dK[ty,tx,co,ci] = alpha * sum_{n,yc,xc} dy[fine(ty,tx)][co] x[n,yc,xc,ci]
+// The op is HBM-bound (1024 MAC per output pixel, AI ~ 15 FLOP/B): every kernel streams the full-resolution tensor exactly
+// once with 128-byte rows per pixel and keeps the coarse tensor / filter in registers or L2; no LDS staging is needed
+// because the MFMA operand fragments are contiguous channel runs of single pixels.
+// One wave owns 32 consecutive coarse pixels of one coarse row (fwd / bwd data) so all index arithmetic is wave-uniform.
+#include "pcnn_internal.h"
+
+namespace {
+
+struct DeconvParams {
+  int N, hc, wc, Cin, H, W, Cout, f, py, px;
+  const float* x; int ldx;         // coarse tensor (fwd input / bwd-filter input)
+  const float* wp;                 // packed filter
+  const float* bias;
+  float alpha, beta;
+  float* y; int ldy;               // fine tensor (fwd output)
+  const float* dy; int lddy;       // fine gradient
+  float* dx; int lddx;             // coarse gradient
+  float* partial;                  // bwd-filter partials [S][f*f][Cout][Cin]
+  int tiles_x, S;
+};
+
+// K (f,f,Cout,Cin) -> [tap][g][h][co32][4]: element j = K[tap][co][8g+4h+j]            (B operand of fwd: k = ci, n = co)
+__global__ void pack_deconv_fwd_kernel(const float* __restrict__ k, float* __restrict__ wp, int taps, int Cin, int Cout, int ng) {
+  const int64_t total = (int64_t)taps * ng * 2 * 32 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = i & 3; int64_t r = i >> 2; const int co = r & 31; r >>= 5; const int h = r & 1; r >>= 1; const int g = r % ng; const int tap = r / ng;
+    const int ci = 8 * g + 4 * h + j;
+    wp[i] = (ci < Cin && co < Cout) ? k[((int64_t)tap * Cout + co) * Cin + ci] : 0.f;
+  }
+}
+// K (f,f,Cout,Cin) -> [tap][g][h][ci32][4]: element j = K[tap][8g+4h+j][ci]            (B operand of bwd data: k = co, n = ci)
+__global__ void pack_deconv_bwd_kernel(const float* __restrict__ k, float* __restrict__ wp, int taps, int Cin, int Cout, int ng) {
+  const int64_t total = (int64_t)taps * ng * 2 * 32 * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = i & 3; int64_t r = i >> 2; const int ci = r & 31; r >>= 5; const int h = r & 1; r >>= 1; const int g = r % ng; const int tap = r / ng;
+    const int co = 8 * g + 4 * h + j;
+    wp[i] = (ci < Cin && co < Cout) ? k[((int64_t)tap * Cout + co) * Cin + ci] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);               // wave -> (n, yc, x tile)
+  const int total = p.N * p.hc * p.tiles_x;
+  if (wid >= total) return;
+  const int tx0 = wid % p.tiles_x; wid /= p.tiles_x;
+  const int yc = wid % p.hc, n = wid / p.hc;
+  const int x0 = tx0 * 32;
+  const int ng = (p.Cin + 7) >> 3;
+  // A fragments: this lane's coarse pixel, 4 channels per 8-channel group (lane half selects which 4)
+  f32x4 a[4];
+  const int xc_l = x0 + col;
+  const bool pv = xc_l < p.wc;
+  const float* xsrc = p.x + (((int64_t)n * p.hc + yc) * p.wc + (pv ? xc_l : p.wc - 1)) * p.ldx;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int ch = 8 * g + 4 * half;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (g < ng && pv && ch < p.Cin) v = *reinterpret_cast<const f32x4*>(xsrc + ch);
+    a[g] = v;
+  }
+  const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
+  const f32x4* wl = reinterpret_cast<const f32x4*>(p.wp) + half * 32 + col;
+  for (int ty = 0; ty < p.f; ++ty) {
+    const int Y = yc * p.f + ty - p.py;
+    if (Y < 0 || Y >= p.H) continue;
+    for (int tx = 0; tx < p.f; ++tx) {
+      const int tap = ty * p.f + tx;
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < ng) {
+          const f32x4 b = wl[(int64_t)(tap * ng + g) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][j], b[j], acc, 0, 0, 0);
+        }
+      }
+      if (col < p.Cout) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
+          const int X = xc * p.f + tx - p.px;
+          if (xc < p.wc && X >= 0 && X < p.W) {
+            float* dst = p.y + (((int64_t)n * p.H + Y) * p.W + X) * p.ldy + col;
+            const float v = p.alpha * (acc[i] + bias);
+            *dst = p.beta == 0.f ? v : p.beta * *dst + v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward data
+__global__ __launch_bounds__(256) void deconv_bwd_data_mfma_kernel(DeconvParams p) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int total = p.N * p.hc * p.tiles_x;
+  if (wid >= total) return;
+  const int tx0 = wid % p.tiles_x; wid /= p.tiles_x;
+  const int yc = wid % p.hc, n = wid / p.hc;
+  const int x0 = tx0 * 32;
+  const int ng = (p.Cout + 7) >> 3;       // K dimension = co
+  const int xc_l = x0 + col;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const f32x4* wl = reinterpret_cast<const f32x4*>(p.wp) + half * 32 + col;
+  for (int ty = 0; ty < p.f; ++ty) {
+    const int Y = yc * p.f + ty - p.py;
+    if (Y < 0 || Y >= p.H) continue;
+    for (int tx = 0; tx < p.f; ++tx) {
+      const int tap = ty * p.f + tx;
+      const int X = xc_l * p.f + tx - p.px;
+      const bool v = xc_l < p.wc && X >= 0 && X < p.W;
+      const float* src = p.dy + (((int64_t)n * p.H + Y) * p.W + (v ? X : 0)) * p.lddy;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < ng) {
+          const int ch = 8 * g + 4 * half;
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          if (v && ch < p.Cout) a = *reinterpret_cast<const f32x4*>(src + ch);
+          const f32x4 b = wl[(int64_t)(tap * ng + g) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (col < p.Cin) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
+      if (xc < p.wc) p.dx[(((int64_t)n * p.hc + yc) * p.wc + xc) * p.lddx + col] = p.alpha * acc[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward filter
+// grid (S, f*f); each wave walks coarse rows r = (split*4 + wave), +4S, ... ; M = co, N = ci, K = coarse pixels (2 per MFMA)
+__global__ __launch_bounds__(256) void deconv_bwd_filter_mfma_kernel(DeconvParams p) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31, wave = threadIdx.x >> 6;
+  const int tap = blockIdx.y, ty = tap / p.f, tx = tap % p.f;
+  const int rows = p.N * p.hc;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += p.S * 4) {
+    const int yc = r % p.hc, n = r / p.hc;
+    const int Y = yc * p.f + ty - p.py;
+    if (Y < 0 || Y >= p.H) continue;
+    const float* dyrow = p.dy + ((int64_t)n * p.H + Y) * p.W * p.lddy;
+    const float* xrow = p.x + ((int64_t)n * p.hc + yc) * p.wc * p.ldx;
+    for (int xc0 = 0; xc0 < p.wc; xc0 += 8) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int xc = xc0 + 2 * u + half;
+        const int X = xc * p.f + tx - p.px;
+        const bool v = xc < p.wc && X >= 0 && X < p.W;
+        a[u] = (v && col < p.Cout) ? dyrow[(int64_t)X * p.lddy + col] : 0.f;
+        b[u] = (v && col < p.Cin) ? xrow[(int64_t)xc * p.ldx + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+  }
+  // cross-wave sum (fixed order) and store: row = co, col = ci
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+  __syncthreads();
+  if (wave == 0) {
+    float* dst = p.partial + ((int64_t)blockIdx.x * p.f * p.f + tap) * p.Cout * p.Cin;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float s = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+      const int co = 8 * (i >> 2) + 4 * half + (i & 3);
+      if (co < p.Cout && col < p.Cin) dst[co * p.Cin + col] = s;
+    }
+  }
+}
+
+static bool ensure_scratch(pcnn_handle h, size_t need) {
+  if (h->scratch_bytes >= need) return true;
+  if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+  const size_t cap = need < (4u << 20) ? (4u << 20) : need;
+  if (hipMalloc(&h->scratch, cap) != hipSuccess) return false;
+  h->scratch_bytes = cap;
+  return true;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// Returns 0 on success, -1 if the shape is outside what the MFMA path covers (caller falls back), >0 on error.
+int pcnn_deconv_fwd_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* x, int ldx, const float* k,
+                         const float* bias, float alpha, float beta, float* y, int ldy) {
+  if (Cin > 32 || Cout > 32 || Cin % 4 || ldx % 4 || !aligned16(x)) return -1;
+  const int ng = (Cin + 7) >> 3;
+  const size_t need = (size_t)f * f * ng * 64 * 4 * sizeof(float);
+  if (!ensure_scratch(h, need)) PCNN_FAIL(h, "pcnn_deconv_fwd: cannot allocate filter scratch");
+  const int64_t tot = (int64_t)f * f * ng * 64 * 4;
+  hipLaunchKernelGGL(pack_deconv_fwd_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(tot, 256), 1024)), dim3(256), 0, h->stream, k,
+                     static_cast<float*>(h->scratch), f * f, Cin, Cout, ng);
+  DeconvParams p{};
+  p.N = N; p.hc = hc; p.wc = wc; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.f = f; p.py = (hc * f - H) / 2; p.px = (wc * f - W) / 2;
+  p.x = x; p.ldx = ldx; p.wp = static_cast<const float*>(h->scratch); p.bias = bias; p.alpha = alpha; p.beta = beta; p.y = y; p.ldy = ldy;
+  p.tiles_x = pcnn_cdiv(wc, 32);
+  const int64_t waves = (int64_t)N * hc * p.tiles_x;
+  hipLaunchKernelGGL(deconv_fwd_mfma_kernel, dim3((unsigned)pcnn_cdiv64(waves, 4)), dim3(256), 0, h->stream, p);
+  PCNN_CHECK_LAUNCH(h, "pcnn_deconv_fwd(mfma)");
+  return 0;
+}
+
+int pcnn_deconv_bwd_data_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* dy, int lddy, const float* k,
+                              float alpha, float* dx, int lddx) {
+  if (Cin > 32 || Cout > 32 || Cout % 4 || lddy % 4 || !aligned16(dy)) return -1;
+  const int ng = (Cout + 7) >> 3;
+  const size_t need = (size_t)f * f * ng * 64 * 4 * sizeof(float);
+  if (!ensure_scratch(h, need)) PCNN_FAIL(h, "pcnn_deconv_bwd_data: cannot allocate filter scratch");
+  const int64_t tot = (int64_t)f * f * ng * 64 * 4;
+  hipLaunchKernelGGL(pack_deconv_bwd_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(tot, 256), 1024)), dim3(256), 0, h->stream, k,
+                     static_cast<float*>(h->scratch), f * f, Cin, Cout, ng);
+  DeconvParams p{};
+  p.N = N; p.hc = hc; p.wc = wc; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.f = f; p.py = (hc * f - H) / 2; p.px = (wc * f - W) / 2;
+  p.dy = dy; p.lddy = lddy; p.wp = static_cast<const float*>(h->scratch); p.alpha = alpha; p.dx = dx; p.lddx = lddx;
+  p.tiles_x = pcnn_cdiv(wc, 32);
+  const int64_t waves = (int64_t)N * hc * p.tiles_x;
+  hipLaunchKernelGGL(deconv_bwd_data_mfma_kernel, dim3((unsigned)pcnn_cdiv64(waves, 4)), dim3(256), 0, h->stream, p);
+  PCNN_CHECK_LAUNCH(h, "pcnn_deconv_bwd_data(mfma)");
+  return 0;
+}
+
+// partial must hold S*f*f*Cout*Cin floats with S = pcnn_deconv_bwd_filter_splits(...)
+int pcnn_deconv_bwd_filter_splits(int N, int hc, int f) {
+  int S = 1024 / (f * f);
+  const int rows4 = (N * hc + 3) / 4;
+  if (S > rows4) S = rows4;
+  if (S < 1) S = 1;
+  if (S > 256) S = 256;
+  return S;
+}
+
+int pcnn_deconv_bwd_filter_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, int W, int Cout, int f, const float* x, int ldx, const float* dy,
+                                int lddy, float* partial, int* S_out) {
+  if (Cin > 32 || Cout > 32) return -1;
+  DeconvParams p{};
+  p.N = N; p.hc = hc; p.wc = wc; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.f = f; p.py = (hc * f - H) / 2; p.px = (wc * f - W) / 2;
+  p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy; p.partial = partial;
+  p.S = pcnn_deconv_bwd_filter_splits(N, hc, f);
+  *S_out = p.S;
+  hipLaunchKernelGGL(deconv_bwd_filter_mfma_kernel, dim3(p.S, f * f), dim3(256), 0, h->stream, p);
+  PCNN_CHECK_LAUNCH(h, "pcnn_deconv_bwd_filter(mfma)");
+  return 0;
+}

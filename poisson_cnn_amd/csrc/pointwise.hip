@@ -40,15 +40,24 @@ __global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_kernel(int64_t npix, in
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* o0, float* o1, float* o2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float* outs[3] = {o0, o1, o2};
-  for (int k = 0; k < 3; ++k) {
-    if (!outs[k]) continue;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[((int64_t)b * 3 + k) * C + c];
-    outs[k][c] = s;
+// one workgroup per channel: the (<= 1024) block partials of each of the 3 sums are tree-reduced in a fixed order
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* o0, float* o1, float* o2) {
+  __shared__ float red[3][256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int b = t; b < nblk; b += 256)
+    for (int k = 0; k < 3; ++k) s[k] += partial[((int64_t)b * 3 + k) * C + c];
+  for (int k = 0; k < 3; ++k) red[k][t] = s[k];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st)
+      for (int k = 0; k < 3; ++k) red[k][t] += red[k][t + st];
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (o0) o0[c] = red[0][0];
+    if (o1) o1[c] = red[1][0];
+    if (o2) o2[c] = red[2][0];
   }
 }
 
@@ -316,7 +325,7 @@ extern "C" int pcnn_conv2d_epilogue_bwd(pcnn_handle h, int64_t npix, int C, cons
                      dz, lddz, partial);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_epilogue_bwd");
   if (dbias || dsum_dy_a || dsum_dy) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(pcnn_cdiv(C, 64)), dim3(64), 0, h->stream, partial, nb, C, dbias, dsum_dy_a, dsum_dy);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, h->stream, partial, nb, C, dbias, dsum_dy_a, dsum_dy);
     PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_epilogue_bwd(final)");
   }
   return 0;
