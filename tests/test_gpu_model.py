@@ -157,3 +157,18 @@ def test_hpnn_train_step_gradients(activation, tol):
     print('flat rel', rel(flat, flat_ref), 'worst tensors', worst, 'last layer', errs['final/out1/kernel'])
     assert errs['final/out1/kernel'] < 2e-5 and errs['scaling/dense2/kernel'] < 2e-5
     assert rel(flat, flat_ref) < tol
+
+
+def test_forward_matches_committed_golden_vectors():
+    """HIP forward vs the committed oracle fixtures (tests/golden/make_model_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'hpnn_forward_golden.npz'))
+    cfg = configs.hpnn()['model']
+    model, _ = build(cfg, 11)
+    y = model([g['hpnn_rhs'], g['hpnn_dx']]).cpu().numpy()
+    assert rel(y, g['hpnn_out']) < TOL_FWD
+    cfg = configs.hpnn_tiny()['model']
+    cfg['bc_type'] = 'neumann'
+    model, _ = build(cfg, 5)
+    y = model([g['tiny_rhs'], g['tiny_dx']]).cpu().numpy()
+    assert rel(y, g['tiny_out']) < TOL_FWD

@@ -81,3 +81,37 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+
+
+def test_integral_weight_map_matches_oracle():
+    import torch
+    from oracle import loss as oloss
+    from poisson_cnn_amd.losses import integral_loss, build_fd_coefficients
+    from oracle import np_ops
+    il = integral_loss(47, ndims=2)
+    for H, W in [(40, 52), (128, 96), (513, 300)]:
+        G = il.weight_map(H, W, torch.device('cpu')).numpy()
+        ref = oloss.integral_weight_map((H, W), 47)
+        assert np.allclose(G, ref, rtol=1e-6, atol=1e-9)
+        assert abs(G.sum() - 4.0) < 1e-5          # integrates the constant 1 over [-1,1]^2
+    assert np.allclose(build_fd_coefficients([5, 5], 2, 2), np_ops.build_fd_coefficients([5, 5], 2, 2))
+    assert np.allclose(build_fd_coefficients(3, [2, 2], 2), np_ops.build_fd_coefficients([3, 3], [2, 2], 2))
+
+
+def test_dataset_host_samplers():
+    from poisson_cnn_amd import dataset as ds
+    rng = np.random.default_rng(0)
+    osr = [[192, 384], [192, 384]]
+    ar = ds.generate_uniformly_distributed_aspect_ratios(osr, None, samples=2000, rng=rng)
+    assert ar.shape == (2000, 1) and ar.min() >= 191 / 383 - 1e-9 and ar.max() <= 383 / 191 + 1e-9
+    # roughly half of the aspect ratios fall under 1 for a symmetric range
+    assert 0.4 < (ar < 1).mean() < 0.6
+    for _ in range(20):
+        a = ds.generate_uniformly_distributed_aspect_ratios(osr, None, samples=4, rng=rng)
+        shape, dx = ds.generate_output_shapes_and_grid_spacings_from_aspect_ratios(a, osr, [[5e-3, 5e-2], [5e-3, 5e-2]], constant_dx=True, samples=4, rng=rng)
+        assert shape.shape == (2,) and np.all(shape <= 384) and np.all(shape >= 96)
+        assert dx.shape == (4, 2) and np.all(dx[:, 0] == dx[:, 1]) and dx.min() >= 5e-3 and dx.max() <= 5e-2
+    n = ds._process_normalizations({'rhs_max_magnitude': True, 'max_domain_size_squared': True})
+    assert n == {'rhs_max_magnitude': 1.0, 'max_domain_size_squared': True, 'soln_max_magnitude': False}
+    with pytest.raises(AssertionError):
+        ds._range2([3, 1], 2)

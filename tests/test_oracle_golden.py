@@ -35,3 +35,15 @@ def test_integral_loss_known_answer():
     val = oloss.integral_lp(t, np.zeros_like(t), (25, 13, 28), p=2, dx=dx)
     assert val.shape == (1, 1)
     assert abs(val[0, 0] - 4.84711) / 4.84711 < 0.01
+
+
+def test_oracle_reproduces_committed_model_vectors():
+    """The CPU oracle against the committed forward fixtures (tiny model; the full hpnn case is checked on the GPU box)."""
+    from oracle import hpnn as ohpnn
+    from poisson_cnn_amd import configs
+    g = np.load(os.path.join(GOLD, 'hpnn_forward_golden.npz'))
+    cfg = configs.hpnn_tiny()['model']
+    cfg['bc_type'] = 'neumann'
+    p = ohpnn.init_params(cfg, seed=5, gain=1.6, randomize_all=True)
+    y = ohpnn.forward(np_ops, cfg, p, g['tiny_rhs'].astype(np.float64), g['tiny_dx'].astype(np.float64))
+    assert np.linalg.norm(y - g['tiny_out']) / np.linalg.norm(g['tiny_out']) < 1e-6
