@@ -61,28 +61,56 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvPara
     const int ck = min(p.CK, cin_pad - c0);
     const int G = ck >> 2;   // float4 groups per pixel in this chunk
     __syncthreads();         // previous chunk fully consumed
-    // ---- stage the halo tile (padding applied here)
-    for (int r = wave; r < TR; r += WAVES) {
-      const int sy = pcnn_pad_index(y0 + r - p.pt, p.H, p.pad_mode);
-      const int nel = TC * G;
-      for (int e = lane; e < nel; e += 64) {
-        const int c = e / G, g = e - c * G;
-        const int sx = pcnn_pad_index(x0 + c - p.pl, p.W, p.pad_mode);
-        const int ch = c0 + 4 * g;
-        f32x4 v;
-        if (sy < 0 || sx < 0) {
-          v[0] = ch + 0 < p.Cin ? p.pad_value : 0.f; v[1] = ch + 1 < p.Cin ? p.pad_value : 0.f;
-          v[2] = ch + 2 < p.Cin ? p.pad_value : 0.f; v[3] = ch + 3 < p.Cin ? p.pad_value : 0.f;
-        } else {
-          const float* src = xin + ((int64_t)sy * p.W + sx) * p.ldx + ch;
-          if (p.vec_ok && ch + 3 < p.Cin) {
-            v = *reinterpret_cast<const f32x4*>(src);
-          } else {
-            v[0] = ch + 0 < p.Cin ? src[0] : 0.f; v[1] = ch + 1 < p.Cin ? src[1] : 0.f;
-            v[2] = ch + 2 < p.Cin ? src[2] : 0.f; v[3] = ch + 3 < p.Cin ? src[3] : 0.f;
+    // ---- stage the halo tile (padding applied here).  Units of 4 channels; 8 loads per lane are issued back to back from
+    // always-valid (select-ed) addresses and only then padded and written to LDS, so a lane keeps 8 global loads in flight
+    // instead of paying one full memory round trip per element.
+    {
+      const int upr = TC * G, total = TR * upr;
+      const float inv_upr = 1.0f / (float)upr, inv_G = 1.0f / (float)G;   // exact small-integer division via (u + 0.5) / d
+      const bool vec = p.vec_ok != 0;
+      for (int base = tid; base < total; base += 256 * 8) {
+        f32x4 v[8];
+        int off[8];   // LDS float offset; -1: nothing to do; <= -2: out-of-image (constant padding), offset = -2 - off
+        int chs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int u = base + 256 * q;
+          const int uu = u < total ? u : 0;
+          const int r = (int)(((float)uu + 0.5f) * inv_upr);
+          const int w = uu - r * upr;
+          const int c = (int)(((float)w + 0.5f) * inv_G);
+          const int g = w - c * G;
+          const int sy = pcnn_pad_index(y0 + r - p.pt, p.H, p.pad_mode);
+          const int sx = pcnn_pad_index(x0 + c - p.pl, p.W, p.pad_mode);
+          const bool inimg = sy >= 0 && sx >= 0;
+          const int ch = c0 + 4 * g;
+          const float* src = xin + ((int64_t)(inimg ? sy : 0) * p.W + (inimg ? sx : 0)) * p.ldx;
+          if (vec && ch + 3 < p.Cin) {
+            v[q] = *reinterpret_cast<const f32x4*>(src + ch);
+          } else {   // ragged / unaligned channel tail: clamp every element's address, mask afterwards
+            v[q][0] = src[ch + 0 < p.Cin ? ch + 0 : p.Cin - 1]; v[q][1] = src[ch + 1 < p.Cin ? ch + 1 : p.Cin - 1];
+            v[q][2] = src[ch + 2 < p.Cin ? ch + 2 : p.Cin - 1]; v[q][3] = src[ch + 3 < p.Cin ? ch + 3 : p.Cin - 1];
+          }
+          const int o = (r * TC + c) * PS + 4 * g;
+          off[q] = u < total ? (inimg ? o : -2 - o) : -1;
+          chs[q] = ch;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (off[q] != -1) {
+            f32x4 t = v[q];
+            int o = off[q];
+            if (o < 0) { o = -2 - o; const float pv = p.pad_value; t[0] = pv; t[1] = pv; t[2] = pv; t[3] = pv; }
+            const int ch = chs[q];
+            if (ch + 3 >= p.Cin) {   // zero the channels beyond Cin (K padding)
+              if (ch + 0 >= p.Cin) t[0] = 0.f;
+              if (ch + 1 >= p.Cin) t[1] = 0.f;
+              if (ch + 2 >= p.Cin) t[2] = 0.f;
+              t[3] = 0.f;
+            }
+            *reinterpret_cast<f32x4*>(&lds[o]) = t;
           }
         }
-        *reinterpret_cast<f32x4*>(&lds[(r * TC + c) * PS + 4 * g]) = v;
       }
     }
     __syncthreads();

@@ -365,3 +365,28 @@ class numerical_dataset_generator:
             keys = _BOUNDARY_KEYS if (not self.exclude_zero_boundaries or 'nonzero_boundaries' not in nda) else nda['nonzero_boundaries']
             inp[loc:loc] = [b[k] for k in keys]
         return inp, out
+
+
+# ----------------------------------------------------------------------------- solver entry points (dataset/solvers)
+def multigrid_poisson_solve(rhses, boundaries, dx, dy=None, system_matrix=None, tol=1e-10, solver_init_parameters=None, solver_run_parameters=None,
+                            use_pyamgx=False, initial_guesses=None, device=None):
+    """Drop-in for dataset/solvers/multigrid.py:98-150: solves pyamg.gallery.poisson((H-2, W-2)) u = poisson_RHS(rhses, boundaries, dx)
+    and writes the Dirichlet values - by the direct DST-I diagonalisation on the GPU instead of Ruge-Stuben V-cycles / AMGX
+    (tol, solver parameters and initial guesses are accepted and irrelevant for a direct solve; like the reference only `dx` is used).
+    rhses (N,1,H,W) or (N,H,W); boundaries: dict with 'left'/'right' (N,W) and 'bottom'/'top' (N,H) (extra singleton dims allowed)."""
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(device=dev, dtype=torch.float32)
+    r = t(rhses)
+    if r.dim() == 4:
+        r = r[:, 0]
+    N, H, W = r.shape
+    b = {k: t(boundaries[k]).reshape(-1, W if k in ('left', 'right') else H).expand(N, -1).contiguous() for k in _BOUNDARY_KEYS}
+    d = t(dx).reshape(-1)
+    d = d.expand(N).contiguous() if d.numel() == 1 else d.reshape(N, -1)[:, 0].contiguous()   # (N,), (N,1) or (N,2): first column
+    out = K.fd_poisson_dst(r.contiguous(), b['left'], b['right'], b['bottom'], b['top'], d)
+    return out.view(N, 1, H, W)
+
+
+def cholesky_poisson_solve(rhses, boundaries, h, system_matrix=None, system_matrix_is_decomposed=False, device=None):
+    """dataset/solvers/cholesky.py:122-186 (dense Cholesky of the same 5-point matrix): same system, same direct DST-I solve."""
+    return multigrid_poisson_solve(rhses, boundaries, h, device=device)

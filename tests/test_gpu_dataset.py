@@ -149,3 +149,17 @@ def test_numerical_generator_solves_the_fd_system():
     for n in range(N):
         res = ods.five_point_laplacian(ref[n], dx[n, 0]) - rhs[n, 0, 1:-1, 1:-1]
         assert np.abs(res).max() < 1e-7 * np.abs(rhs[n]).max() / dx[n, 0] ** 2 * dx[n, 0] ** 2 + 1e-6
+
+
+def test_multigrid_poisson_solve_entry_point():
+    from poisson_cnn_amd.dataset import multigrid_poisson_solve, cholesky_poisson_solve
+    rng = np.random.default_rng(2)
+    N, H, W = 2, 40, 31
+    rhs = rng.standard_normal((N, 1, H, W)).astype(np.float32)
+    bc = {'left': rng.standard_normal((N, 1, W)).astype(np.float32), 'right': rng.standard_normal((N, 1, W)).astype(np.float32),
+          'bottom': rng.standard_normal((N, 1, H)).astype(np.float32), 'top': rng.standard_normal((N, 1, H)).astype(np.float32)}
+    dx = rng.uniform(0.01, 0.05, (N, 1)).astype(np.float32)
+    ref = ods.multigrid_poisson_solve(rhs[:, 0].astype(np.float64), {k: v[:, 0].astype(np.float64) for k, v in bc.items()}, dx[:, 0].astype(np.float64))
+    got = multigrid_poisson_solve(rhs, bc, dx, tol=1e-10).cpu().numpy()
+    assert got.shape == (N, 1, H, W) and rel(got[:, 0], ref) < 2e-7
+    assert rel(cholesky_poisson_solve(rhs, bc, dx).cpu().numpy()[:, 0], ref) < 2e-7
