@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import hpnn as ohpnn, np_ops
 from poisson_cnn_amd import configs
 from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy

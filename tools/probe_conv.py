@@ -4,7 +4,7 @@ import time
 
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from poisson_cnn_amd import ops
 
 
