@@ -96,6 +96,21 @@ int pcnn_bn_fold(pcnn_handle h, int n, const float* gamma, const float* beta, co
 int pcnn_bn_fold_bwd(pcnn_handle h, int n, const float* s_dy_a, const float* s_dy, const float* mean, const float* var, float eps,
                      float* dgamma, float* dbeta);
 
+/* Training-mode BatchNormalization (fused semantics; optional - the reference's train_step most likely runs BN in inference
+ * mode).  Forward: the conv writes the activation a; sum_a / sum_a2 come from pcnn_conv2d_epilogue_bwd(dy=a, a=a,
+ * act=linear) (its s_dy and s_dy_a sums); pcnn_bn_train_finalize turns them into batch mean / 1/sqrt(var_biased+eps) / scale /
+ * shift and updates the moving statistics (momentum; unbiased variance); pcnn_channel_affine applies y = a*scale + shift (+residual).
+ * Backward: given S1 = sum dy*a, S2 = sum dy:  dgamma = inv_std*(S1 - mean*S2), dbeta = S2,
+ *   da = scale * (dy - S2/n - xhat * dgamma/n),  xhat = (a - mean)*inv_std.   scratch_2C: 2*C floats. */
+int pcnn_channel_affine(pcnn_handle h, int64_t npix, int C, const float* x, int ldx, const float* scale, const float* shift,
+                        const float* residual, int ld_res, float* y, int ldy);
+int pcnn_bn_train_finalize(pcnn_handle h, int C, int64_t npix, const float* sum_a, const float* sum_a2, const float* gamma, const float* beta,
+                           float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* inv_std, float* scale,
+                           float* shift);
+int pcnn_bn_train_bwd(pcnn_handle h, int64_t npix, int C, const float* dy, int lddy, const float* a, int lda, const float* scale,
+                      const float* mean, const float* inv_std, const float* s_dy_a, const float* s_dy, float* dgamma, float* dbeta,
+                      float* scratch_2C, float* da, int ldda);
+
 /* ---- pooling: tf.keras.layers.{Average,Max}Pooling2D(pool_size=f, strides=f, padding='same') ----------------
  * (utils/get_pooling_method.py:3-6; blocks/bottleneck_block.py:36-37; layers/Scaling.py:29).
  * Ho = ceil(H/f); window origin o*f - (Ho*f-H)/2; the average divides by the number of valid elements. */

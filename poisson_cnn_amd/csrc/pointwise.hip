@@ -463,3 +463,85 @@ extern "C" int pcnn_bn_fold_bwd(pcnn_handle h, int n, const float* s_dy_a, const
   PCNN_CHECK_LAUNCH(h, "pcnn_bn_fold_bwd");
   return 0;
 }
+
+// ---- training-mode BatchNormalization (fused semantics: biased variance normalises, unbiased variance feeds the moving average)
+namespace {
+__global__ void channel_affine_kernel(int64_t npix, int C, const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, const float* __restrict__ res, int ld_res, float* __restrict__ y, int ldy) {
+  const int64_t total = npix * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; const int64_t pix = i / C;
+    float v = x[pix * ldx + c] * scale[c] + shift[c];
+    if (res) v += res[pix * ld_res + c];
+    y[pix * ldy + c] = v;
+  }
+}
+
+__global__ void bn_train_finalize_kernel(int C, float inv_n, float unbias, const float* sum_a, const float* sum_a2, const float* gamma, const float* beta,
+                                         float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* inv_std, float* scale,
+                                         float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = sum_a[c] * inv_n;
+  float v = sum_a2[c] * inv_n - m * m;
+  if (v < 0.f) v = 0.f;
+  const float is = 1.0f / sqrtf(v + eps);
+  mean[c] = m; inv_std[c] = is;
+  scale[c] = gamma[c] * is; shift[c] = beta[c] - m * gamma[c] * is;
+  moving_mean[c] = moving_mean[c] * momentum + m * (1.0f - momentum);
+  moving_var[c] = moving_var[c] * momentum + v * unbias * (1.0f - momentum);
+}
+
+__global__ void bn_train_bwd_finalize_kernel(int C, float inv_n, const float* s_dy_a, const float* s_dy, const float* mean, const float* inv_std,
+                                             float* dgamma, float* dbeta, float* c1, float* c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float dg = inv_std[c] * (s_dy_a[c] - mean[c] * s_dy[c]);   // sum dy * xhat
+  dgamma[c] = dg; dbeta[c] = s_dy[c];
+  c1[c] = s_dy[c] * inv_n; c2[c] = dg * inv_n;
+}
+
+__global__ void bn_train_bwd_kernel(int64_t npix, int C, const float* __restrict__ dy, int lddy, const float* __restrict__ a, int lda,
+                                    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ inv_std,
+                                    const float* __restrict__ c1, const float* __restrict__ c2, float* __restrict__ da, int ldda) {
+  const int64_t total = npix * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = i % C; const int64_t pix = i / C;
+    const float xh = (a[pix * lda + c] - mean[c]) * inv_std[c];
+    da[pix * ldda + c] = scale[c] * (dy[pix * lddy + c] - c1[c] - xh * c2[c]);
+  }
+}
+}  // namespace
+
+extern "C" int pcnn_channel_affine(pcnn_handle h, int64_t npix, int C, const float* x, int ldx, const float* scale, const float* shift,
+                                   const float* residual, int ld_res, float* y, int ldy) {
+  PCNN_REQUIRE(h, h && x && scale && shift && y, "pcnn_channel_affine: null argument");
+  hipLaunchKernelGGL(channel_affine_kernel, grid1d(npix * C), dim3(256), 0, h->stream, npix, C, x, ldx, scale, shift, residual, ld_res, y, ldy);
+  PCNN_CHECK_LAUNCH(h, "pcnn_channel_affine");
+  return 0;
+}
+
+extern "C" int pcnn_bn_train_finalize(pcnn_handle h, int C, int64_t npix, const float* sum_a, const float* sum_a2, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* moving_mean, float* moving_var, float* mean, float* inv_std, float* scale,
+                                      float* shift) {
+  PCNN_REQUIRE(h, h && sum_a && sum_a2 && gamma && beta && moving_mean && moving_var && mean && inv_std && scale && shift && npix > 0,
+               "pcnn_bn_train_finalize: bad argument");
+  const float unbias = npix > 1 ? (float)((double)npix / (double)(npix - 1)) : 1.0f;
+  hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(pcnn_cdiv(C, 64)), dim3(64), 0, h->stream, C, (float)(1.0 / (double)npix), unbias, sum_a, sum_a2, gamma,
+                     beta, eps, momentum, moving_mean, moving_var, mean, inv_std, scale, shift);
+  PCNN_CHECK_LAUNCH(h, "pcnn_bn_train_finalize");
+  return 0;
+}
+
+extern "C" int pcnn_bn_train_bwd(pcnn_handle h, int64_t npix, int C, const float* dy, int lddy, const float* a, int lda, const float* scale,
+                                 const float* mean, const float* inv_std, const float* s_dy_a, const float* s_dy, float* dgamma, float* dbeta,
+                                 float* scratch_2C, float* da, int ldda) {
+  PCNN_REQUIRE(h, h && dy && a && scale && mean && inv_std && s_dy_a && s_dy && dgamma && dbeta && scratch_2C && da, "pcnn_bn_train_bwd: null argument");
+  float* c1 = scratch_2C; float* c2 = scratch_2C + C;
+  hipLaunchKernelGGL(bn_train_bwd_finalize_kernel, dim3(pcnn_cdiv(C, 64)), dim3(64), 0, h->stream, C, (float)(1.0 / (double)npix), s_dy_a, s_dy, mean, inv_std,
+                     dgamma, dbeta, c1, c2);
+  PCNN_CHECK_LAUNCH(h, "pcnn_bn_train_bwd(finalize)");
+  hipLaunchKernelGGL(bn_train_bwd_kernel, grid1d(npix * C), dim3(256), 0, h->stream, npix, C, dy, lddy, a, lda, scale, mean, inv_std, c1, c2, da, ldda);
+  PCNN_CHECK_LAUNCH(h, "pcnn_bn_train_bwd");
+  return 0;
+}

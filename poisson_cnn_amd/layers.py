@@ -110,7 +110,7 @@ class ParamStore:
             ops.bn_fold(self.gamma_all, self.beta_all, self.mean_all, self.var_all, self.bn_scale, self.bn_shift)
 
     def finish_bn_grads(self):
-        if self.nbn:
+        if self.nbn and not getattr(self, 'bn_training', False):
             ops.bn_fold_bwd(self.bn_s1, self.bn_s2, self.mean_all, self.var_all, self.dgamma_all, self.dbeta_all)
 
 
@@ -164,20 +164,32 @@ class ConvUnit:
         N, H, W, _ = x.shape
         if out is None:
             out = ops.empty((N, H, W, self.cout), x.device)
+        if self.bn_name is not None and training and getattr(self.store, 'bn_training', False):
+            # training-mode BatchNormalization: batch statistics need the whole activation first (two passes)
+            a = ops.empty((N, H, W, self.cout), x.device)
+            ops.conv2d_fwd(x, w, b, pad_top=self.pads[0], pad_left=self.pads[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act, out=a)
+            sw = self.store.w
+            _, stats = ops.bn_train_forward(a, sw[self.bn_name + '/gamma'], sw[self.bn_name + '/beta'], sw[self.bn_name + '/moving_mean'],
+                                            sw[self.bn_name + '/moving_variance'], residual=residual, out=out, ws=self.ctx.ws)
+            self.saved = (x, a, stats)
+            return out
         need_a = training and (sc is not None or residual is not None)
         a = ops.empty((N, H, W, self.cout), x.device) if need_a else None
         ops.conv2d_fwd(x, w, b, pad_top=self.pads[0], pad_left=self.pads[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
                        bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a)
         if training:
-            self.saved = (x, a if a is not None else out)   # without BN/residual the output itself is the activation
+            self.saved = (x, a if a is not None else out, None)   # without BN/residual the output itself is the activation
         return out
 
     def backward(self, dy, need_dx=True, inplace=False):
-        x, a = self.saved
+        x, a, bn_stats = self.saved
         self.saved = None
         s, g = self.store, self.store.g
         N, H, W, _ = x.shape
         sc, _ = self._bn()
+        if bn_stats is not None:   # training-mode BN: da first, then the plain conv epilogue
+            dy = ops.bn_train_backward(dy, a, bn_stats, g[self.bn_name + '/gamma'], g[self.bn_name + '/beta'], ws=self.ctx.ws)
+            sc, inplace = None, True
         dense = ops._ld(dy) == self.cout
         dz = dy if (inplace and dense) else ops.empty((N, H, W, self.cout), dy.device)
         s1 = s.bn_s1[self.bn_off:self.bn_off + self.cout] if sc is not None else None

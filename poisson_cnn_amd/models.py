@@ -47,7 +47,7 @@ class Homogeneous_Poisson_NN_Legacy:
     def __init__(self, data_format='channels_first', final_convolutions_config=None, pre_bottleneck_convolutions_config=None,
                  bottleneck_deconv_config=None, bottleneck_multilinear_config=None, input_normalization=None, output_scaling=None,
                  use_batchnorm=False, postsmoother_iterations=5, use_scaling=False, use_positional_embeddings=True, scaling_config=None,
-                 gradient_accumulation_steps=None, bc_type='dirichlet', device=None, seed=0):
+                 gradient_accumulation_steps=None, bc_type='dirichlet', device=None, seed=0, batchnorm_training=False):
         if data_format != 'channels_first':
             raise NotImplementedError('only data_format="channels_first" (all shipped configs) is supported at the API')
         if pre_bottleneck_convolutions_config is None:
@@ -71,6 +71,9 @@ class Homogeneous_Poisson_NN_Legacy:
         self.use_positional_embeddings = use_positional_embeddings
         self.neumann = bc_type.lower() == 'neumann'
         self.store = S = L.ParamStore()
+        # BatchNormalization mode inside train_step: False = moving statistics (what the reference's train_step most likely does,
+        # SURVEY.md row H4), True = batch statistics + moving-average update (Keras training=True semantics, per replica)
+        S.bn_training = bool(batchnorm_training)
         self.ctx = C = L.Context()
 
         # pre-bottleneck convolutions (reference :41-57)

@@ -198,6 +198,38 @@ def bn_fold_bwd(s1, s2, mean, var, dgamma, dbeta, eps=BN_EPS):
     handle().call('pcnn_bn_fold_bwd', c_int(s1.numel()), _p(s1), _p(s2), _p(mean), _p(var), c_float(eps), _p(dgamma), _p(dbeta))
 
 
+def channel_affine(x, scale, shift, residual=None, out=None):
+    N, H, W, C = x.shape
+    y = out if out is not None else empty((N, H, W, C), x.device)
+    handle().call('pcnn_channel_affine', c_int64(N * H * W), c_int(C), _p(x), c_int(_ld(x)), _p(scale), _p(shift), _p(residual),
+                  c_int(_ld(residual) if residual is not None else 0), _p(y), c_int(_ld(y)))
+    return y
+
+
+def bn_train_forward(a, gamma, beta, moving_mean, moving_var, residual=None, out=None, momentum=0.99, eps=BN_EPS, ws=None):
+    """Batch statistics of `a` (N,H,W,C), moving-average update, y = BN(a) (+ residual).  Returns (y, (mean, inv_std, scale))."""
+    N, H, W, C = a.shape
+    st = empty((6, C), a.device)
+    sum_a2, sum_a, mean, inv_std, scale, shift = st[0], st[1], st[2], st[3], st[4], st[5]
+    epilogue_bwd(a, a, act='linear', s_dy_a=sum_a2, s_dy=sum_a, ws=ws)      # s_dy_a = sum a*a, s_dy = sum a
+    handle().call('pcnn_bn_train_finalize', c_int(C), c_int64(N * H * W), _p(sum_a), _p(sum_a2), _p(gamma), _p(beta), c_float(eps), c_float(momentum),
+                  _p(moving_mean), _p(moving_var), _p(mean), _p(inv_std), _p(scale), _p(shift))
+    y = channel_affine(a, scale, shift, residual=residual, out=out)
+    return y, (mean, inv_std, scale)
+
+
+def bn_train_backward(dy, a, stats, dgamma, dbeta, ws=None):
+    """da for y = BN_train(a); writes dgamma / dbeta."""
+    N, H, W, C = dy.shape
+    mean, inv_std, scale = stats
+    tmp = empty((4, C), dy.device)
+    epilogue_bwd(dy, a, act='linear', s_dy_a=tmp[0], s_dy=tmp[1], ws=ws)
+    da = empty((N, H, W, C), dy.device)
+    handle().call('pcnn_bn_train_bwd', c_int64(N * H * W), c_int(C), _p(dy), c_int(_ld(dy)), _p(a), c_int(_ld(a)), _p(scale), _p(mean), _p(inv_std),
+                  _p(tmp[0]), _p(tmp[1]), _p(dgamma), _p(dbeta), _p(tmp[2:]), _p(da), c_int(C))
+    return da
+
+
 # ----------------------------------------------------------------------------- pooling / deconv / resize
 def pool_out(n, f):
     return -(-n // f)

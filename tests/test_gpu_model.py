@@ -172,3 +172,46 @@ def test_forward_matches_committed_golden_vectors():
     model, _ = build(cfg, 5)
     y = model([g['tiny_rhs'], g['tiny_dx']]).cpu().numpy()
     assert rel(y, g['tiny_out']) < TOL_FWD
+
+
+def test_training_mode_batchnorm_train_step():
+    """batchnorm_training=True: batch statistics in the forward pass, their gradient in the backward pass, moving-average update."""
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import Adam
+    full = configs.hpnn_tiny()
+    cfg = full['model']
+    for st in ('pre_bottleneck_convolutions_config',):
+        cfg[st]['activation'] = 'tf.nn.tanh'
+    cfg['bottleneck_deconv_config']['conv_activation'] = 'tf.nn.tanh'
+    cfg['bottleneck_multilinear_config']['conv_activation'] = 'tf.nn.tanh'
+    lossp = dict(full['training']['loss_parameters'])
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    model = Homogeneous_Poisson_NN_Legacy(batchnorm_training=True, **cfg)
+    p = ohpnn.init_params(cfg, seed=51, gain=1.3, randomize_all=True)
+    model.set_weights(p)
+    rhs, dx = make_inputs(3, 48, 40, 53)
+    target = np.random.default_rng(4).standard_normal(rhs.shape).astype(np.float32).astype(np.float64) * 0.1
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in p.items()}
+    pred = ohpnn.forward(torch_twin, cfg, pt, torch.tensor(rhs), torch.tensor(dx), bn_training=True)
+    L = oloss.loss_wrapper(global_batch_size=3, **lossp)
+    loss = L(target, pred, torch.tensor(rhs), np.concatenate([dx, dx], 1))
+    loss.backward()
+    model.compile(loss=loss_wrapper(global_batch_size=3, **lossp), optimizer=Adam(learning_rate=0.0))
+    w0 = dict(zip(model.weight_names, model.get_weights()))
+    logs = model.train_step(((rhs, dx), target))
+    assert abs(float(logs['loss']) - float(loss.detach())) < 5e-5 * abs(float(loss.detach()))
+    names = model.store.trainable_names()
+    flat = np.concatenate([model.store.g[n].cpu().numpy().ravel() for n in names])
+    flat_ref = np.concatenate([pt[n].grad.numpy().ravel() for n in names])
+    assert rel(flat, flat_ref) < 5e-4
+    for n in ('pre/bn0/gamma', 'pre/bn0/beta', 'deconv_f3/res0/bn1/gamma'):
+        assert rel(model.store.g[n].cpu().numpy(), pt[n].grad.numpy()) < 2e-3, n
+    # moving statistics moved towards the batch statistics with momentum 0.99
+    w1 = dict(zip(model.weight_names, model.get_weights()))
+    x0 = ohpnn.forward(np_ops, cfg, p, rhs, dx, bn_training=True, taps={})   # oracle batch stats of the first BN input
+    a0 = np_ops.padded_conv2d(np.concatenate([rhs, ohpnn.position_embeddings(np_ops, 3, 48, 40)], 1), p['pre/conv0/kernel'], p['pre/conv0/bias'],
+                              cfg['pre_bottleneck_convolutions_config']['padding_mode'], 0.0, 'tf.nn.tanh')
+    bm, bv = a0.mean((0, 2, 3)), a0.var((0, 2, 3))
+    n = a0.size / a0.shape[1]
+    assert np.allclose(w1['pre/bn0/moving_mean'], 0.99 * w0['pre/bn0/moving_mean'] + 0.01 * bm, rtol=1e-4, atol=1e-6)
+    assert np.allclose(w1['pre/bn0/moving_variance'], 0.99 * w0['pre/bn0/moving_variance'] + 0.01 * bv * n / (n - 1), rtol=1e-4, atol=1e-6)
