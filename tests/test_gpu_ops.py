@@ -233,3 +233,38 @@ def test_loss_partials_and_bwd():
     g = ops.loss_bwd(dev(yp), dev(yt), dev(G), dev(cm), dev(cs), dev(ci)).cpu().numpy()
     refg = cm[:, None, None, None] * np.sign(d) + 2 * d * (cs[:, None, None, None] + ci[:, None, None, None] * G)
     assert rel(g, refg) < TOL
+
+
+@pytest.mark.parametrize('padding,mode', [('same', 'SYMMETRIC'), ('same', 'CONSTANT'), ('valid', 'constant')])
+def test_metalearning_conv_forward_backward(padding, mode):
+    """Per-sample hyper-network filters (layers/metalearning_conv.py): forward and all gradients vs autograd of the oracle twin."""
+    from poisson_cnn_amd.metalearning import metalearning_conv
+    rng = np.random.default_rng(21)
+    N, H, W, Cin, Cout, k, F = 3, 21, 19, 8, 12, 5, 3
+    lay = metalearning_conv(Cout, k, Cin, F, padding=padding, padding_mode=mode, constant_padding_value=0.2, conv_activation='tf.nn.leaky_relu',
+                            dense_activations='tf.nn.tanh', pre_output_dense_units=[8, 16], seed=4)
+    x = f32(rng.standard_normal((N, Cin, H, W))); di = f32(rng.standard_normal((N, F)))
+    names = lay.store.names
+    wts = {n: lay.store.w[n].cpu().numpy().astype(np.float64) for n in names}
+    wt = {n: torch.tensor(v, requires_grad=True) for n, v in wts.items()}
+    xt, dit = torch.tensor(x, requires_grad=True), torch.tensor(di, requires_grad=True)
+    kb = dit
+    for i in range(3):
+        kb = torch_twin.dense(kb, wt['metalearning_conv/dense%d/kernel' % i], wt['metalearning_conv/dense%d/bias' % i], 'tanh')
+    nk = k * k * Cin * Cout
+    outs = []
+    for n in range(N):
+        kern = kb[n, :nk].reshape(k, k, Cin, Cout); bias = kb[n, nk:]
+        if padding == 'same':
+            outs.append(torch_twin.padded_conv2d(xt[n:n + 1], kern, bias, mode, 0.2, 'leaky_relu'))
+        else:
+            outs.append(torch_twin.activation(torch_twin.conv2d_valid(xt[n:n + 1], kern, bias), 'leaky_relu'))
+    yt = torch.cat(outs, 0)
+    dy = f32(rng.standard_normal(tuple(yt.shape)))
+    (yt * torch.tensor(dy)).sum().backward()
+    y = lay.forward(nhwc(x), dev(di))
+    assert rel(nchw(y), yt.detach().numpy()) < TOL
+    dx, ddi = lay.backward(nhwc(dy))
+    assert rel(nchw(dx), xt.grad.numpy()) < 5e-6 and rel(ddi.cpu().numpy(), dit.grad.numpy()) < 2e-5
+    for n in names:
+        assert rel(lay.store.g[n].cpu().numpy(), wt[n].grad.numpy()) < 2e-5, n
