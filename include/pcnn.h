@@ -38,6 +38,16 @@ int pcnn_sync(pcnn_handle h);
 const char* pcnn_last_error(pcnn_handle h);
 int pcnn_version(void);
 
+/* Arithmetic of the convolution GEMMs.
+ *   PCNN_MATH_FP32      (default): v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulate.
+ *   PCNN_MATH_SPLIT_F16 : every fp32 operand is split into two fp16 halves (hi + lo, 22 significant bits, per-tile power-of-two
+ *                         scaling) and a*b is accumulated in fp32 as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16: 5.3x fewer
+ *                         matrix-pipe cycles at an accuracy that is measured to be BETTER than the fp32 fmaf chain
+ *                         (tools/split_f16_test.hip: 5.4e-7 vs 1.5e-6 rel-L2 against fp64 at K = 7200). */
+enum { PCNN_MATH_FP32 = 0, PCNN_MATH_SPLIT_F16 = 1 };
+int pcnn_set_math_mode(pcnn_handle h, int mode);
+int pcnn_get_math_mode(pcnn_handle h);
+
 /* ---- 2-D convolution: tf.pad + tf.nn.conv2d(VALID) + bias + activation (+ BN affine) (+ residual) ----------
  * Replaces pad_and_apply_convolution (utils/apply_advanced_padding_and_call_conv_layer.py:16-20), Keras
  * Conv2D(padding='same') (models/Homogeneous_Poisson_NN_Legacy.py:71,75,95; layers/Scaling.py:28), the fused

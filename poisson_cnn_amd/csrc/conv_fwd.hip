@@ -16,6 +16,9 @@
 //     arbitrary channel stride (so a conv can write straight into a channel slice of a concat buffer).
 #include "pcnn_internal.h"
 
+int pcnn_conv2d_fwd_split(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
+                          const float* bn_shift, const float* residual, float* y, float* act_out);   // conv_fwd_split.hip
+
 namespace {
 
 constexpr int TH = 16, TW = 32, WAVES = 4, MT = TH / WAVES;
@@ -228,6 +231,10 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
     const int pb = d->Ho - 1 - d->pad_top + d->kh - 1 - (d->H - 1), pr = d->Wo - 1 - d->pad_left + d->kw - 1 - (d->W - 1);
     PCNN_REQUIRE(h, d->pad_top <= lim_y && pb <= lim_y && d->pad_left <= lim_x && pr <= lim_x,
                  "pcnn_conv2d_fwd: padding exceeds what tf.pad allows for a %dx%d image", d->H, d->W);
+  }
+  if (h->math_mode == PCNN_MATH_SPLIT_F16) {
+    const int rc = pcnn_conv2d_fwd_split(h, d, x, w, bias, bn_scale, bn_shift, residual, y, act_out);
+    if (rc >= 0) return rc;   // -1: shape not covered by the split kernel -> exact fp32 path below
   }
   ConvParams p;
   p.x = x; p.w = w; p.bias = bias; p.bn_scale = bn_scale; p.bn_shift = bn_shift; p.res = residual; p.y = y; p.act_out = act_out;

@@ -35,3 +35,12 @@ extern "C" int pcnn_sync(pcnn_handle h) {
 }
 
 extern "C" const char* pcnn_last_error(pcnn_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int pcnn_set_math_mode(pcnn_handle h, int mode) {
+  if (!h) return 1;
+  PCNN_REQUIRE(h, mode == PCNN_MATH_FP32 || mode == PCNN_MATH_SPLIT_F16, "pcnn_set_math_mode: unknown mode %d", mode);
+  h->math_mode = mode;
+  return 0;
+}
+
+extern "C" int pcnn_get_math_mode(pcnn_handle h) { return h ? h->math_mode : -1; }

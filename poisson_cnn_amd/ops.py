@@ -18,6 +18,21 @@ LEAKY_ALPHA = 0.2   # tf.nn.leaky_relu default
 BN_EPS = 1e-3       # tf.keras.layers.BatchNormalization default
 
 _handles = {}
+MATH_MODES = {'fp32': 0, 'split_f16': 1}
+_math_mode = MATH_MODES[__import__('os').environ.get('PCNN_MATH', 'fp32')]
+
+
+def set_math_mode(mode):
+    """'fp32' (default: exact fp32 MFMA) or 'split_f16' (3 x fp16 split MFMA, fp32 accumulate; include/pcnn.h PCNN_MATH_SPLIT_F16).
+    Also selectable with the environment variable PCNN_MATH."""
+    global _math_mode
+    _math_mode = MATH_MODES[mode]
+    for h in _handles.values():
+        h.call('pcnn_set_math_mode', c_int(_math_mode))
+
+
+def get_math_mode():
+    return [k for k, v in MATH_MODES.items() if v == _math_mode][0]
 
 
 def handle():
@@ -28,6 +43,7 @@ def handle():
     if h is None:
         h = _lib.Handle(dev, st)
         h._stream = st
+        h.call('pcnn_set_math_mode', c_int(_math_mode))
         _handles[dev] = h
     elif h._stream != st:
         h.set_stream(st)

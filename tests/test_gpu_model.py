@@ -126,7 +126,7 @@ def test_gradient_accumulation_equals_full_batch():
     assert rel(outs[1] * 2, outs[0]) < 1e-4
 
 
-@pytest.mark.parametrize('activation,tol', [('tf.nn.leaky_relu', 3e-3), ('tf.nn.tanh', 3e-4)])
+@pytest.mark.parametrize('activation,tol', [('tf.nn.leaky_relu', 8e-3), ('tf.nn.tanh', 3e-4)])
 def test_hpnn_train_step_gradients(activation, tol):
     """Full hpnn.json model, 2 x 112 x 112 grids: loss and the flat 5.56 M-element gradient vs fp64 autograd.
     With leaky-ReLU the fp32 and fp64 forward passes pick different slopes at the few activations that round to opposite
