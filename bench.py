@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_SPLIT_TFLOPS = 2500.0 / 3  # 3 fp16 MFMA FLOP per algorithmic fp32 FLOP at the ~2.5 PFLOP/s dense fp16 peak
 
 
 def cpu_baseline(sample_hw=128, seed=0):
@@ -73,6 +74,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c4', choices=['c4', 'c3', 'small'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--math', default='split_f16', choices=['split_f16', 'fp32'],
+                    help='convolution GEMM arithmetic: 3 x fp16 split MFMA with fp32 accumulate (fp32-accurate, default) or plain fp32 MFMA')
     args = ap.parse_args()
 
     from poisson_cnn_amd import configs, ops, parallel
@@ -81,6 +84,7 @@ def main():
     from poisson_cnn_amd.train import Adam
 
     dp = parallel.DataParallel.from_env()
+    ops.set_math_mode(args.math)
     if dp.world_size != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, dp.world_size, args.gpus))
     per_gpu, H = {'c4': (8, 1024), 'c3': (32, 512), 'small': (2, 256)}[args.workload]
@@ -127,22 +131,25 @@ def main():
         # cannot be combined with the timed run); the committed summary is reported for the workload it was measured on.
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'r01_c4_pmc_summary.json')
-        if args.workload == 'c4' and os.path.exists(pmc):
+        if args.workload == 'c4' and args.math == 'fp32' and os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f)['kernels']['conv_fwd<1>']['traffic_bytes_per_launch']
+        peak = PEAK_FP32_MFMA_TFLOPS if args.math == 'fp32' else PEAK_SPLIT_TFLOPS
         flops, secs, calls = prof.totals('conv_fwd')
         wf, ws_, wc = prof.totals('conv_wgrad')
         out = {
             'metric': 'grids/sec (fwd+bwd) at %d^2' % H, 'value': gbs * args.steps / elapsed, 'unit': 'grids/s',
             'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.math == 'fp32' else 'f32 (operands split into 2 x fp16, 3 MFMA products, fp32 accumulate; parity-tested at the fp32 tolerances)',
+            'data': 'synthetic',
             'config': {'workload': '%s: Homogeneous_Poisson_NN_Legacy(hpnn.json) full train step (fwd+bwd+loss+Adam%s), %d x %dx%d Dirichlet grids per GPU'
                                    % (args.workload, '+RCCL all-reduce' if dp.world_size > 1 else '', per_gpu, H, W),
-                       'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'final_loss': loss},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_fwd_kernel<1> (fused pad+conv fwd and data-gradient)', 'achieved': flops / secs / 1e12 if secs else None,
-                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / secs / 1e12 / PEAK_FP32_MFMA_TFLOPS if secs else None,
+                       'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': args.math, 'final_loss': loss},
+            'roofline': {'bound': 'mfma', 'kernel': ('conv_fwd_kernel<1>' if args.math == 'fp32' else 'conv_fwd_split_kernel<1>') + ' (fused pad+conv fwd and data-gradient)', 'achieved': flops / secs / 1e12 if secs else None,
+                         'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)', 'frac': flops / secs / 1e12 / peak if secs else None,
                          'traffic': traffic, 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_c4_pmc_summary.json)', 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,
-                         'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / PEAK_FP32_MFMA_TFLOPS if ws_ else None,
+                         'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / peak if ws_ else None,
                                           'launches': wc, 'avg_launch_ms': 1e3 * ws_ / wc if wc else None}},
         }
         if dp.world_size == 1 and not args.no_cpu_baseline:

@@ -274,6 +274,187 @@ void launch_wgrad(pcnn_handle h, const WgradParams& p, const WgradPlan& pl) {
   hipLaunchKernelGGL((wgrad_kernel<NTC, TAPS>), dim3(pl.S, p.kh, pl.gz), dim3(256), pl.lds, h->stream, p);
 }
 
+
+// ============================================================================================================================
+// 3 x fp16 split variant (PCNN_MATH_SPLIT_F16; numerics: conv_fwd_split.hip).  The reduction runs over pixels, so both MFMA
+// operands need 8 consecutive K values = 8 pixels per lane.  The tile (8 rows x 32 columns) is therefore staged TRANSPOSED:
+// one 16-byte LDS unit = the 8 rows of one (column, channel) as fp16, units ordered [column][channel] - which keeps the
+// flattened (filter column, channel) trick: unit(x, R) = x*Cin + R is contiguous in R, so an A fragment is 32 consecutive
+// units (conflict-free ds_read_b128) and no channel padding is needed.  One K step (16 pixels) = 2 columns x 8 rows: lanes
+// 0-31 take column 2t, lanes 32-63 column 2t+1.  Each loader task gathers the 8 rows of 4 channels of one column (8 dwordx4
+// loads), converts to hi/lo and writes 4 + 4 units.  x and dz are scaled per tile by powers of two (block max), the tile's
+// accumulator is rescaled when folded into the running total.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float wg_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
+  int e = 0;
+  if (mx > 0.f) (void)frexpf(mx, &e);
+  s = mx > 0.f ? ldexpf(1.0f, 13 - e) : 1.0f;
+  inv_s = mx > 0.f ? ldexpf(1.0f, e - 13) : 1.0f;
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  const int split = blockIdx.x, ki = blockIdx.y, kj0 = blockIdx.z * p.KWG;
+  const int kwg = min(p.KWG, p.kw - kj0);
+  const int TCx = WTW + p.KWG - 1;
+  // units per plane; fragment over-reads (< 32 units past a plane, garbage rows/columns that are discarded) land in the next
+  // plane, only the last plane needs 512 B of slack - every byte counts: k = 15, 32 channels must fit twice into 160 KiB
+  const int nux = TCx * p.Cin, nudz = WTW * p.Cout;
+  f16x8* xh = reinterpret_cast<f16x8*>(lds);
+  f16x8* xl = xh + nux;
+  f16x8* zh = xl + nux;
+  f16x8* zl = zh + nudz;
+  float* red = reinterpret_cast<float*>(zl + nudz + 32);             // 8 floats, after the over-read slack
+
+  f32x16 acc[TAPS], tot[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[t][i] = 0.f; tot[t][i] = 0.f; }
+
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int ntile = (kwg * p.Cin + 31) >> 5;
+  const int ntw = ntile > wv ? (ntile - wv + WAVES - 1) / WAVES : 0;
+  const int GX = p.Cin >> 2, GZ = p.Cout >> 2;                        // channel quads
+  const int ntask_x = TCx * GX, ntask_z = WTW * GZ;
+
+  for (int tile = split; tile < p.ntiles; tile += p.S) {
+    int tt = tile;
+    const int tx = tt % p.tiles_x; tt /= p.tiles_x;
+    const int ty = tt % p.tiles_y;
+    const int n = tt / p.tiles_y;
+    const int y0 = ty * WTH, x0 = tx * WTW;
+    const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
+    const float* dzin = p.dz + (int64_t)n * p.Ho * p.Wo * p.lddz;
+    // source row offsets (wave-uniform): x rows are shifted by the filter row, BC padding applied
+    int64_t xrow[WTH]; bool xrow_in[WTH];
+#pragma unroll
+    for (int r = 0; r < WTH; ++r) {
+      const int sy = pcnn_pad_index(y0 + r + ki - p.pt, p.H, p.pad_mode);
+      xrow_in[r] = sy >= 0;
+      xrow[r] = (int64_t)(sy >= 0 ? sy : 0) * p.W;
+    }
+    // ---- pass 1: block maxima of the x window and the dz tile
+    float mxx = 0.f, mxz = 0.f;
+    for (int task = tid; task < ntask_x; task += 256) {
+      const int c = task / GX, ch = (task - c * GX) << 2;
+      const int sx = pcnn_pad_index(x0 + c + kj0 - p.pl, p.W, p.pad_mode);
+#pragma unroll
+      for (int r = 0; r < WTH; ++r) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xin + (xrow[r] + (sx >= 0 ? sx : 0)) * p.ldx + ch);
+        if (!(xrow_in[r] && sx >= 0)) { const float pv = p.pad_value; v = (f32x4){pv, pv, pv, pv}; }
+        mxx = fmaxf(mxx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      }
+    }
+    for (int task = tid; task < ntask_z; task += 256) {
+      const int c = task / GZ, ch = (task - c * GZ) << 2;
+      const int ox = x0 + c;
+#pragma unroll
+      for (int r = 0; r < WTH; ++r) {
+        const bool in = y0 + r < p.Ho && ox < p.Wo;
+        f32x4 v = *reinterpret_cast<const f32x4*>(dzin + ((int64_t)(in ? y0 + r : 0) * p.Wo + (in ? ox : 0)) * p.lddz + ch);
+        if (in) mxz = fmaxf(mxz, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      }
+    }
+    mxx = wg_wave_max(mxx); mxz = wg_wave_max(mxz);
+    __syncthreads();                                   // previous tile's fragment reads are done
+    if (lane == 0) { red[wave] = mxx; red[4 + wave] = mxz; }
+    __syncthreads();
+    mxx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mxz = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    float sx_, isx, sz_, isz;
+    pow2_scale(mxx, sx_, isx); pow2_scale(mxz, sz_, isz);
+    // ---- pass 2: reload (L1/L2 hits), split into fp16 hi/lo, write transposed units
+    for (int task = tid; task < ntask_x; task += 256) {
+      const int c = task / GX, ch = (task - c * GX) << 2;
+      const int sx = pcnn_pad_index(x0 + c + kj0 - p.pl, p.W, p.pad_mode);
+      f32x4 v[WTH];
+#pragma unroll
+      for (int r = 0; r < WTH; ++r) {
+        v[r] = *reinterpret_cast<const f32x4*>(xin + (xrow[r] + (sx >= 0 ? sx : 0)) * p.ldx + ch);
+        if (!(xrow_in[r] && sx >= 0)) { const float pv = p.pad_value; v[r] = (f32x4){pv, pv, pv, pv}; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f16x8 h8, l8;
+#pragma unroll
+        for (int r = 0; r < WTH; ++r) { const float a = v[r][j] * sx_; const _Float16 ah = (_Float16)a; h8[r] = ah; l8[r] = (_Float16)(a - (float)ah); }
+        xh[c * p.Cin + ch + j] = h8; xl[c * p.Cin + ch + j] = l8;
+      }
+    }
+    for (int task = tid; task < ntask_z; task += 256) {
+      const int c = task / GZ, ch = (task - c * GZ) << 2;
+      const int ox = x0 + c;
+      f32x4 v[WTH];
+#pragma unroll
+      for (int r = 0; r < WTH; ++r) {
+        const bool in = y0 + r < p.Ho && ox < p.Wo;
+        v[r] = *reinterpret_cast<const f32x4*>(dzin + ((int64_t)(in ? y0 + r : 0) * p.Wo + (in ? ox : 0)) * p.lddz + ch);
+        if (!in) v[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f16x8 h8, l8;
+#pragma unroll
+        for (int r = 0; r < WTH; ++r) { const float a = v[r][j] * sz_; const _Float16 ah = (_Float16)a; h8[r] = ah; l8[r] = (_Float16)(a - (float)ah); }
+        zh[c * p.Cout + ch + j] = h8; zl[c * p.Cout + ch + j] = l8;
+      }
+    }
+    __syncthreads();
+    // ---- accumulate: 16 K steps of 2 columns x 8 rows
+#pragma unroll 2
+    for (int xp = 0; xp < WTW / 2; ++xp) {
+      const int cx = 2 * xp + half;
+      const f16x8 bh = zh[cx * p.Cout + col], bl = zl[cx * p.Cout + col];
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        if (t < ntw) {
+          const int u = cx * p.Cin + (wv + WAVES * t) * 32 + col;
+          const f16x8 ah = xh[u], al = xl[u];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    const float rs = isx * isz;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { tot[t][i] = fmaf(acc[t][i], rs, tot[t][i]); acc[t][i] = 0.f; }
+  }
+  // ---- write partials (same layout as the fp32 kernel)
+  {
+    const int nflat = kwg * p.Cin;
+    float* dst = p.ws + (((int64_t)split * p.kh + ki) * p.kw + kj0) * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int jt = wv + WAVES * t;
+      if (jt * 32 >= nflat) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int R = jt * 32 + 8 * (i >> 2) + 4 * half + (i & 3);
+        if (R < nflat && col < p.Cout) dst[(int64_t)R * p.Cout + col] = tot[t][i];
+      }
+    }
+  }
+}
+
+template <int TAPS>
+void launch_wgrad_split(pcnn_handle h, const WgradParams& p, const WgradPlan& pl, size_t lds) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((wgrad_split_kernel<TAPS>), dim3(pl.S, p.kh, pl.gz), dim3(256), lds, h->stream, p);
+}
+
 }  // namespace
 
 extern "C" size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d) {
@@ -297,6 +478,16 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S; p.KWG = pl.KWG; p.lg = pl.lg;
   p.vecx = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   p.vecdz = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+  const bool split_ok = h->math_mode == PCNN_MATH_SPLIT_F16 && p.vecx && p.vecdz && pl.NTC == 1;
+  if (split_ok) {
+    const size_t lds = ((size_t)(WTW + pl.KWG - 1) * d->Cin + (size_t)WTW * d->Cout) * 32 + 512 + 64;
+    switch (pl.TAPS) {
+      case 1: launch_wgrad_split<1>(h, p, pl, lds); break;
+      case 2: launch_wgrad_split<2>(h, p, pl, lds); break;
+      case 3: launch_wgrad_split<3>(h, p, pl, lds); break;
+      default: launch_wgrad_split<4>(h, p, pl, lds); break;
+    }
+  } else
 #define PCNN_WG(Q, T) if (pl.NTC == Q && pl.TAPS == T) { launch_wgrad<Q, T>(h, p, pl); } else
   PCNN_WG(1, 1) PCNN_WG(1, 2) PCNN_WG(1, 3) PCNN_WG(1, 4) PCNN_WG(2, 1) PCNN_WG(2, 2)
   { PCNN_FAIL(h, "pcnn_conv2d_wgrad: no kernel for NTC=%d TAPS=%d", pl.NTC, pl.TAPS); }

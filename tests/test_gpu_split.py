@@ -1,0 +1,71 @@
+"""The same parity checks with the convolution GEMMs in PCNN_MATH_SPLIT_F16 mode (3 x fp16 split MFMA, fp32 accumulate):
+forward / data-gradient / filter-gradient kernels and the whole model against the fp64 oracle, at the SAME tolerances as the
+exact-fp32 mode."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def split_mode():
+    from poisson_cnn_amd import ops
+    prev = ops.get_math_mode()
+    ops.set_math_mode('split_f16')
+    yield
+    ops.set_math_mode(prev)
+
+
+def test_mode_is_active():
+    from poisson_cnn_amd import ops
+    ops.handle()
+    assert ops.get_math_mode() == 'split_f16' and ops.handle().lib.pcnn_get_math_mode(ops.handle()._h) == 1
+
+
+def test_conv_forward_cases():
+    import test_gpu_conv as t
+    for case in t.CASES:
+        t.test_padded_conv_matches_oracle(*case)
+    t.test_conv_epilogue_bn_residual_slices()
+    t.test_flip_transpose_and_data_gradient()
+
+
+def test_conv_backward_cases():
+    import test_gpu_ops as t
+    for case in t.BWD_CASES:
+        t.test_conv_backward_matches_autograd(*case)
+
+
+def test_wide_dynamic_range_inputs():
+    """Per-tile power-of-two scaling: activations spanning e^(+-9) in magnitude and a tiny-valued filter must not lose accuracy
+    (fp16 has a 5-bit exponent; without the scaling these inputs overflow / flush to zero)."""
+    from oracle import np_ops
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(3)
+    N, C, H, W, k = 2, 16, 40, 45, 7
+    x = (rng.standard_normal((N, C, H, W)) * np.exp(9.0 * rng.uniform(-1, 1, (N, 1, H, W)))).astype(np.float32)
+    x[0, :, :8, :8] = 0.0                                   # an all-zero tile corner
+    w = (rng.standard_normal((k, k, C, 24)) * 1e-6).astype(np.float32)
+    ref = np_ops.padded_conv2d(x.astype(np.float64), w.astype(np.float64), None, 'SYMMETRIC', 0.0, 'linear')
+    xt = torch.tensor(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), device='cuda')
+    y = ops.conv2d_fwd(xt, torch.tensor(w, device='cuda'), None, pad_top=3, pad_left=3, pad_mode='SYMMETRIC')
+    got = y.cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.isfinite(got).all()
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-6
+    dz = (rng.standard_normal((N, 24, H, W)) * np.exp(9.0 * rng.uniform(-1, 1, (N, 1, H, W)))).astype(np.float32)
+    dw = ops.conv2d_wgrad(xt, torch.tensor(np.ascontiguousarray(dz.transpose(0, 2, 3, 1)), device='cuda'), w.shape, pad_top=3, pad_left=3, pad_mode='SYMMETRIC')
+    xp = np_ops.pad2d(x.astype(np.float64), ((3, 3), (3, 3)), 'SYMMETRIC')
+    refw = np.zeros(w.shape)
+    for i in range(k):
+        for j in range(k):
+            refw[i, j] = np.einsum('nchw,nohw->co', xp[:, :, i:i + H, j:j + W], dz.astype(np.float64))
+    assert np.linalg.norm(dw.cpu().numpy() - refw) / np.linalg.norm(refw) < 5e-6
+
+
+def test_model_forward_and_train_step():
+    import test_gpu_model as t
+    t.test_hpnn_forward_matches_oracle('dirichlet')
+    t.test_forward_matches_committed_golden_vectors()
+    t.test_tiny_model_train_step('neumann', 6e-4)
+    t.test_hpnn_train_step_gradients('tf.nn.tanh', 3e-4)
