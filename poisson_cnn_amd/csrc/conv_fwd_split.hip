@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_split_kernel(Sp
   const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
   const float inv_sw = p.wscale[0];
 
+  // two-level summation: `acc` sums one 8-channel chunk (in units of that chunk's activation scale), `tot` the chunks
   f32x16 acc[MT][NT], tot[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -107,7 +108,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_split_kernel(Sp
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     int e = 0;
     if (mx > 0.f) (void)frexpf(mx, &e);    // mx = m * 2^e, m in [0.5, 1)
-    const float s = mx > 0.f ? ldexpf(1.0f, 13 - e) : 1.0f, inv_s = mx > 0.f ? ldexpf(1.0f, e - 13) : 1.0f;
+    const bool okx = mx > 0.f && e > -100 && e < 100;
+    const float s = okx ? ldexpf(1.0f, 13 - e) : 1.0f, inv_s = okx ? ldexpf(1.0f, e - 13) : 1.0f;
 #pragma unroll
     for (int q = 0; q < MAXPIX; ++q) {
       const int u = tid + 256 * q;
@@ -133,16 +135,29 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_split_kernel(Sp
       for (int t = 0; t < NT; ++t) { bh[t] = src[t * 32]; bl[t] = src[p.wplane + t * 32]; }
     };
     const int lane_pix = (wave * MT) * TC + col;       // pixel index of this lane's A row for tap (0,0), M-tile 0
-    int ki0 = 0, kj0 = 0;                              // tap 2*t2
-    auto step = [&](const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], f16x8 (&nbh)[NT], f16x8 (&nbl)[NT], int t2) {
-      load_b(nbh, nbl, t2 + 1);                        // unconditional: the packed filter has a spare step past the end
+    // A fragments: the hi halves of step t+1 are requested (LDS) before the MFMAs of step t, the lo halves at the start of
+    // their own step (first needed by the third MFMA); B fragments (L2) of step t+1 before the MFMAs of step t.  Registers:
+    // acc + tot (128) leave room for one extra hi set only.
+    int ki0 = 0, kj0 = 0;                              // first tap of the step whose hi fragments are loaded next
+    auto tap_offset = [&]() {
+      if (ki0 >= p.kh) { ki0 = 0; kj0 = 0; }           // prefetch past the last step: any valid offset, the values are unused
       int ki1 = ki0, kj1 = kj0 + 1;
       if (kj1 == p.kw) { kj1 = 0; ki1 = ki0 + 1; }
       if (ki1 >= p.kh) { ki1 = ki0; kj1 = kj0; }       // odd tap count: the pad tap reads a valid pixel (its filter is zero)
       const int off = half ? ki1 * TC + kj1 : ki0 * TC + kj0;
-      f16x8 ah[MT], al[MT];
+      kj0 += 2;
+      while (kj0 >= p.kw) { kj0 -= p.kw; ki0 += 1; }
+      return lane_pix + off;
+    };
+    auto step = [&](const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], const f16x8 (&ah)[MT], int a_cur,
+                    f16x8 (&nbh)[NT], f16x8 (&nbl)[NT], f16x8 (&nah)[MT], int& a_next, int t2) {
+      load_b(nbh, nbl, t2 + 1);                        // unconditional: the packed filter has spare zero steps past the end
+      f16x8 al[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) { ah[m] = hi_plane[lane_pix + off + m * TC]; al[m] = lo_plane[lane_pix + off + m * TC]; }
+      for (int m = 0; m < MT; ++m) al[m] = lo_plane[a_cur + m * TC];
+      a_next = tap_offset();
+#pragma unroll
+      for (int m = 0; m < MT; ++m) nah[m] = hi_plane[a_next + m * TC];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -151,18 +166,18 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_split_kernel(Sp
           acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
           acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[t], acc[m][t], 0, 0, 0);
         }
-      // advance to tap 2*(t2+1)
-      kj0 += 2;
-      while (kj0 >= p.kw) { kj0 -= p.kw; ki0 += 1; }
     };
-    f16x8 b0h[NT], b0l[NT], b1h[NT], b1l[NT];
+    f16x8 b0h[NT], b0l[NT], b1h[NT], b1l[NT], a0h[MT], a1h[MT];
+    int a0 = tap_offset(), a1 = 0;
     load_b(b0h, b0l, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a0h[m] = hi_plane[a0 + m * TC];
     int t2 = 0;
     for (; t2 + 2 <= nT2; t2 += 2) {
-      step(b0h, b0l, b1h, b1l, t2);
-      step(b1h, b1l, b0h, b0l, t2 + 1);
+      step(b0h, b0l, a0h, a0, b1h, b1l, a1h, a1, t2);
+      step(b1h, b1l, a1h, a1, b0h, b0l, a0h, a0, t2 + 1);
     }
-    if (t2 < nT2) step(b0h, b0l, b1h, b1l, t2);
+    if (t2 < nT2) step(b0h, b0l, a0h, a0, b1h, b1l, a1h, a1, t2);
     // ---- fold the chunk into the running total with its scale
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -245,7 +260,7 @@ int pcnn_conv2d_fwd_split(pcnn_handle h, const pcnn_conv_desc* d, const float* x
   if (TR * TC > 256 * MAXPIX) return -1;
   const int NT = d->Cout <= 32 ? 1 : 2;
   const int cin_pad = (d->Cin + 7) & ~7, ng = cin_pad >> 3, T = d->kh * d->kw, nT2 = (T + 1) >> 1;
-  const int64_t plane_halfs = ((int64_t)ng * nT2 + 2) * 2 * NT * 32 * 8;       // + spare steps for the prefetch past the end
+  const int64_t plane_halfs = ((int64_t)ng * nT2 + 4) * 2 * NT * 32 * 8;       // + spare steps for the prefetch past the end
   const size_t need = 256 + (size_t)plane_halfs * 2 * sizeof(_Float16);
   if (h->scratch_bytes < need) {
     if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }

@@ -18,7 +18,7 @@ constexpr int WTH = 8, WTW = 32, WAVES = 4;
 struct WgradParams {
   const float* x; const float* dz; float* ws;
   int N, H, W, Cin, ldx, Ho, Wo, Cout, lddz, kh, kw, pt, pl, pad_mode; float pad_value;
-  int tiles_x, tiles_y, ntiles, S, KWG, lg;
+  int tiles_x, tiles_y, ntiles, S, KWG, lg, gz;
   int vecx, vecdz;
 };
 
@@ -45,7 +45,9 @@ static WgradPlan make_plan(const pcnn_conv_desc* d) {
   // (256 CUs x workgroups per CU by LDS) an integral number of times: a 2055-workgroup grid on 512 slots costs 5 rounds.
   const int per_cu = pl.lds * 2 <= 160 * 1024 ? 2 : 1;
   const int slots = 256 * per_cu, rounds = 4;
-  int S = (slots * rounds) / (d->kh * pl.gz);
+  // splits are dealt round-robin to the 8 XCDs (see the kernels' index decode): a whole number of splits per XCD
+  int S = 8 * ((slots / 8 * rounds) / (d->kh * pl.gz));
+  if (S < 8) S = (slots * rounds) / (d->kh * pl.gz);
   if (S > pl.ntiles) S = pl.ntiles;
   if (S < 1) S = 1;
   pl.S = S;
@@ -56,7 +58,13 @@ template <int NTC, int TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
-  const int split = blockIdx.x, ki = blockIdx.y, kj0 = blockIdx.z * p.KWG;
+  // XCD-aware decode: the kh*gz workgroups that sweep the SAME tiles (one per filter row / column group) sit on one XCD next to
+  // each other in dispatch order, so the kh-fold re-read of every x tile is served by that XCD's L2 instead of the fabric
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nper = p.kh * p.gz;
+  const int lsplit = q / nper, rr = q - lsplit * nper;
+  const int split = lsplit * 8 + xcd;
+  if (split >= p.S) return;
+  const int ki = rr % p.kh, kj0 = (rr / p.kh) * p.KWG;
   const int kwg = min(p.KWG, p.kw - kj0);
   const int TCx = WTW + p.KWG - 1;
   float* xs = lds;
@@ -260,18 +268,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t nel, int S) {
+// maxbits != nullptr: the partials come from the split kernel - in its units (maxbits = {max|x|, max|dz|} as float bits) and
+// with its channel order (channel 4q + j of a pixel at position j*C/4 + q, for both Cin and Cout)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t nel, int S, const unsigned* __restrict__ maxbits,
+                                    int Cin, int Cout) {
+  float rs = 1.f;
+  if (maxbits) {
+    int ex = 0, ez = 0;
+    const float mx = __uint_as_float(maxbits[0]), mz = __uint_as_float(maxbits[1]);
+    if (mx > 0.f) (void)frexpf(mx, &ex);
+    if (mz > 0.f) (void)frexpf(mz, &ez);
+    const bool okx = mx > 0.f && ex > -100 && ex < 100, okz = mz > 0.f && ez > -100 && ez < 100;   // as pow2_scale()
+    rs = (okx ? ldexpf(1.0f, ex - 13) : 1.0f) * (okz ? ldexpf(1.0f, ez - 13) : 1.0f);
+  }
+  const int GX = Cin >> 2, GZ = Cout >> 2;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nel; e += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += ws[(int64_t)k * nel + e];
-    dw[e] = s;
+    int64_t o = e;
+    if (maxbits) {
+      const int pz = (int)(e % Cout); const int64_t t = e / Cout;
+      const int px = (int)(t % Cin); const int64_t tap = t / Cin;
+      o = (tap * Cin + 4 * (px % GX) + px / GX) * Cout + 4 * (pz % GZ) + pz / GZ;
+    }
+    dw[o] = s * rs;
   }
 }
 
 template <int NTC, int TAPS>
 void launch_wgrad(pcnn_handle h, const WgradParams& p, const WgradPlan& pl) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<NTC, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((wgrad_kernel<NTC, TAPS>), dim3(pl.S, p.kh, pl.gz), dim3(256), pl.lds, h->stream, p);
+  hipLaunchKernelGGL((wgrad_kernel<NTC, TAPS>), dim3(8 * pcnn_cdiv(pl.S, 8) * p.kh * pl.gz), dim3(256), pl.lds, h->stream, p);
 }
 
 
@@ -281,10 +308,14 @@ void launch_wgrad(pcnn_handle h, const WgradParams& p, const WgradPlan& pl) {
 // one 16-byte LDS unit = the 8 rows of one (column, channel) as fp16, units ordered [column][channel] - which keeps the
 // flattened (filter column, channel) trick: unit(x, R) = x*Cin + R is contiguous in R, so an A fragment is 32 consecutive
 // units (conflict-free ds_read_b128) and no channel padding is needed.  One K step (16 pixels) = 2 columns x 8 rows: lanes
-// 0-31 take column 2t, lanes 32-63 column 2t+1.  Each loader task gathers the 8 rows of 4 channels of one column (8 dwordx4
-// loads), converts to hi/lo and writes 4 + 4 units.  x and dz are scaled per tile by powers of two (block max), the tile's
-// accumulator is rescaled when folded into the running total.
+// 0-31 take column 2t, lanes 32-63 column 2t+1.
+//
+// Every x element is staged kh times (once per filter row), so the fp32 -> (hi, lo) conversion is hoisted out of the tile
+// loader: a pre-pass finds max|x| and max|dz| (one power-of-two scale per TENSOR - the weight gradient is a sum over the whole
+// batch, so errors relative to the tensor maximum are what fp32 itself delivers) and writes dense fp16 hi/lo planes into the
+// workspace; the tile loader is then 8-byte loads + an 8x4 register transpose (v_perm) + 16-byte LDS writes, no arithmetic.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wg_wave_max(float v) {
 #pragma unroll
@@ -295,15 +326,78 @@ __device__ __forceinline__ float wg_wave_max(float v) {
 __device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
   int e = 0;
   if (mx > 0.f) (void)frexpf(mx, &e);
-  s = mx > 0.f ? ldexpf(1.0f, 13 - e) : 1.0f;
-  inv_s = mx > 0.f ? ldexpf(1.0f, e - 13) : 1.0f;
+  const bool ok = mx > 0.f && e > -100 && e < 100;
+  s = ok ? ldexpf(1.0f, 13 - e) : 1.0f;
+  inv_s = ok ? ldexpf(1.0f, e - 13) : 1.0f;
 }
 
-template <int TAPS>
-__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
+struct SplitPlanes {
+  const float* src[2]; _Float16* hi[2]; _Float16* lo[2];
+  int64_t nquad[2]; int cq[2]; int ld[2];            // quads in total, quads per pixel, source channel stride
+  unsigned* maxbits;
+};
+
+// blockIdx.y: 0 = x, 1 = dz.  max|v| as float bits (non-negative floats order like unsigned integers)
+__global__ __launch_bounds__(256) void split_absmax_kernel(SplitPlanes sp) {
+  const int which = blockIdx.y;
+  const float* src = sp.src[which];
+  const int cq = sp.cq[which], ld = sp.ld[which];
+  float mx = 0.f;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < sp.nquad[which]; q += (int64_t)gridDim.x * 256) {
+    const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + pix * ld + ch);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  mx = wg_wave_max(mx);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (!(mx <= 3.0e38f)) mx = 3.0e38f;               // inf / nan: keep the scale finite, the result carries the nan anyway
+    atomicMax(sp.maxbits + which, __float_as_uint(mx));
+  }
+}
+
+__global__ __launch_bounds__(256) void split_convert_kernel(SplitPlanes sp) {
+  const int which = blockIdx.y;
+  const float* src = sp.src[which];
+  const int cq = sp.cq[which], ld = sp.ld[which];
+  float s, inv_s;
+  pow2_scale(__uint_as_float(sp.maxbits[which]), s, inv_s);
+  f16x4* hi = reinterpret_cast<f16x4*>(sp.hi[which]);
+  f16x4* lo = reinterpret_cast<f16x4*>(sp.lo[which]);
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < sp.nquad[which]; q += (int64_t)gridDim.x * 256) {
+    const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + pix * ld + ch);
+    f16x4 h4, l4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float a = v[j] * s; const _Float16 ah = (_Float16)a; h4[j] = ah; l4[j] = (_Float16)(a - (float)ah); }
+    hi[q] = h4; lo[q] = l4;
+  }
+}
+
+struct WgradSplitParams {
+  WgradParams b;
+  const _Float16* xh; const _Float16* xl; const _Float16* zh; const _Float16* zl;
+  const unsigned* maxbits;
+};
+
+// Software pipeline: the two co-resident workgroups of a CU run in lock-step (same work, same start), so their load and MFMA
+// phases do NOT overlap by themselves.  Each workgroup therefore prefetches its NEXT tile from the planes into registers
+// (XR task rounds for x, one for dz; 8-byte loads, in flight during the MFMA loop) and only the register transpose + LDS
+// writes sit between two MFMA loops.  Accumulators: one fp32 set per wave, folded into the workgroup's partial-sum slot in
+// global memory every FOLD tiles (blocked summation without a second register set - the registers hold the prefetch).
+template <int TAPS, int XR>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp) {
+  const WgradParams& p = sp.b;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
-  const int split = blockIdx.x, ki = blockIdx.y, kj0 = blockIdx.z * p.KWG;
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nper = p.kh * p.gz;
+  const int lsplit = q / nper, rr = q - lsplit * nper;
+  const int split = lsplit * 8 + xcd;
+  if (split >= p.S) return;
+  const int ki = rr % p.kh, kj0 = (rr / p.kh) * p.KWG;
   const int kwg = min(p.KWG, p.kw - kj0);
   const int TCx = WTW + p.KWG - 1;
   // units per plane; fragment over-reads (< 32 units past a plane, garbage rows/columns that are discarded) land in the next
@@ -313,13 +407,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
   f16x8* xl = xh + nux;
   f16x8* zh = xl + nux;
   f16x8* zl = zh + nudz;
-  float* red = reinterpret_cast<float*>(zl + nudz + 32);             // 8 floats, after the over-read slack
 
-  f32x16 acc[TAPS], tot[TAPS];
+  float sx_, isx, sz_, isz;
+  pow2_scale(__uint_as_float(sp.maxbits[0]), sx_, isx);
+  pow2_scale(__uint_as_float(sp.maxbits[1]), sz_, isz);
+  f16x4 padh, padl;                                                  // the constant-padding value in the planes' units
+  {
+    const float a = p.pad_value * sx_; const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
+    padh = (f16x4){ah, ah, ah, ah}; padl = (f16x4){al, al, al, al};
+  }
+  const f16x4 zero4 = (f16x4){0, 0, 0, 0};
+
+  f32x16 acc[TAPS];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[t][i] = 0.f; tot[t][i] = 0.f; }
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int ntile = (kwg * p.Cin + 31) >> 5;
@@ -327,140 +430,169 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradParams p) {
   const int GX = p.Cin >> 2, GZ = p.Cout >> 2;                        // channel quads
   const int ntask_x = TCx * GX, ntask_z = WTW * GZ;
 
-  for (int tile = split; tile < p.ntiles; tile += p.S) {
+  // this thread's tasks (fixed for all tiles): x task k -> column xc[k], first channel xch[k]; dz task -> column zc, channel zch
+  int xc[XR], xch[XR];
+#pragma unroll
+  for (int k = 0; k < XR; ++k) { const int task = min(tid + 256 * k, ntask_x - 1); xc[k] = task / GX; xch[k] = (task - xc[k] * GX) << 2; }
+  const int ztask = min(tid, ntask_z - 1);
+  const int zc = ztask / GZ, zch = (ztask - zc * GZ) << 2;
+
+  f16x4 pxh[XR][WTH], pxl[XR][WTH], pzh[WTH], pzl[WTH];               // the prefetched tile
+  unsigned xin_mask[XR], zin_mask = 0;                                // bit r: row r of the task is inside the image
+
+  // all plane addresses are (uniform base pointer) + (32-bit byte offset): hi and lo share the offset register
+  const char* const bxh = reinterpret_cast<const char*>(sp.xh); const char* const bxl = reinterpret_cast<const char*>(sp.xl);
+  const char* const bzh = reinterpret_cast<const char*>(sp.zh); const char* const bzl = reinterpret_cast<const char*>(sp.zl);
+  auto issue = [&](int tile) {                                        // global loads only: nothing here waits for them
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
     const int n = tt / p.tiles_y;
     const int y0 = ty * WTH, x0 = tx * WTW;
-    const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
-    const float* dzin = p.dz + (int64_t)n * p.Ho * p.Wo * p.lddz;
-    // source row offsets (wave-uniform): x rows are shifted by the filter row, BC padding applied
-    int64_t xrow[WTH]; bool xrow_in[WTH];
+    const unsigned xbase = (unsigned)n * p.H * p.W, zbase = (unsigned)n * p.Ho * p.Wo;   // pixels; planes are < 4 GiB (host check)
+    unsigned xrow[WTH]; unsigned rowmask = 0;                         // wave-uniform: x rows shifted by the filter row, BC applied
 #pragma unroll
     for (int r = 0; r < WTH; ++r) {
       const int sy = pcnn_pad_index(y0 + r + ki - p.pt, p.H, p.pad_mode);
-      xrow_in[r] = sy >= 0;
-      xrow[r] = (int64_t)(sy >= 0 ? sy : 0) * p.W;
+      if (sy >= 0) rowmask |= 1u << r;
+      xrow[r] = xbase + (unsigned)(sy >= 0 ? sy : 0) * p.W;
     }
-    // ---- pass 1: block maxima of the x window and the dz tile
-    float mxx = 0.f, mxz = 0.f;
-    for (int task = tid; task < ntask_x; task += 256) {
-      const int c = task / GX, ch = (task - c * GX) << 2;
-      const int sx = pcnn_pad_index(x0 + c + kj0 - p.pl, p.W, p.pad_mode);
+#pragma unroll
+    for (int k = 0; k < XR; ++k) {
+      const int sx = pcnn_pad_index(x0 + xc[k] + kj0 - p.pl, p.W, p.pad_mode);
+      xin_mask[k] = sx >= 0 ? rowmask : 0u;
 #pragma unroll
       for (int r = 0; r < WTH; ++r) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(xin + (xrow[r] + (sx >= 0 ? sx : 0)) * p.ldx + ch);
-        if (!(xrow_in[r] && sx >= 0)) { const float pv = p.pad_value; v = (f32x4){pv, pv, pv, pv}; }
-        mxx = fmaxf(mxx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        const unsigned e = ((xrow[r] + (unsigned)(sx >= 0 ? sx : 0)) * p.Cin + xch[k]) * 2u;
+        pxh[k][r] = *reinterpret_cast<const f16x4*>(bxh + e);
+        pxl[k][r] = *reinterpret_cast<const f16x4*>(bxl + e);
       }
     }
-    for (int task = tid; task < ntask_z; task += 256) {
-      const int c = task / GZ, ch = (task - c * GZ) << 2;
-      const int ox = x0 + c;
+    const int ox = x0 + zc;
+    zin_mask = 0;
 #pragma unroll
-      for (int r = 0; r < WTH; ++r) {
-        const bool in = y0 + r < p.Ho && ox < p.Wo;
-        f32x4 v = *reinterpret_cast<const f32x4*>(dzin + ((int64_t)(in ? y0 + r : 0) * p.Wo + (in ? ox : 0)) * p.lddz + ch);
-        if (in) mxz = fmaxf(mxz, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-      }
+    for (int r = 0; r < WTH; ++r) {
+      const bool in = y0 + r < p.Ho && ox < p.Wo;
+      if (in) zin_mask |= 1u << r;
+      const unsigned e = ((zbase + (unsigned)(in ? y0 + r : 0) * p.Wo + (unsigned)(in ? ox : 0)) * p.Cout + zch) * 2u;
+      pzh[r] = *reinterpret_cast<const f16x4*>(bzh + e);
+      pzl[r] = *reinterpret_cast<const f16x4*>(bzl + e);
     }
-    mxx = wg_wave_max(mxx); mxz = wg_wave_max(mxz);
-    __syncthreads();                                   // previous tile's fragment reads are done
-    if (lane == 0) { red[wave] = mxx; red[4 + wave] = mxz; }
-    __syncthreads();
-    mxx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    mxz = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-    float sx_, isx, sz_, isz;
-    pow2_scale(mxx, sx_, isx); pow2_scale(mxz, sz_, isz);
-    // ---- pass 2: reload (L1/L2 hits), split into fp16 hi/lo, write transposed units
-    for (int task = tid; task < ntask_x; task += 256) {
-      const int c = task / GX, ch = (task - c * GX) << 2;
-      const int sx = pcnn_pad_index(x0 + c + kj0 - p.pl, p.W, p.pad_mode);
-      f32x4 v[WTH];
+  };
+
+  auto stage = [&]() {                                                // register transpose (8 rows x 4 channels -> 4 units) + LDS writes
 #pragma unroll
-      for (int r = 0; r < WTH; ++r) {
-        v[r] = *reinterpret_cast<const f32x4*>(xin + (xrow[r] + (sx >= 0 ? sx : 0)) * p.ldx + ch);
-        if (!(xrow_in[r] && sx >= 0)) { const float pv = p.pad_value; v[r] = (f32x4){pv, pv, pv, pv}; }
-      }
+    for (int k = 0; k < XR; ++k) {
+      if (tid + 256 * k < ntask_x) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f16x8 h8, l8;
+        for (int r = 0; r < WTH; ++r)
+          if (!((xin_mask[k] >> r) & 1u)) { pxh[k][r] = padh; pxl[k][r] = padl; }
 #pragma unroll
-        for (int r = 0; r < WTH; ++r) { const float a = v[r][j] * sx_; const _Float16 ah = (_Float16)a; h8[r] = ah; l8[r] = (_Float16)(a - (float)ah); }
-        xh[c * p.Cin + ch + j] = h8; xl[c * p.Cin + ch + j] = l8;
-      }
-    }
-    for (int task = tid; task < ntask_z; task += 256) {
-      const int c = task / GZ, ch = (task - c * GZ) << 2;
-      const int ox = x0 + c;
-      f32x4 v[WTH];
+        for (int j = 0; j < 4; ++j) {
+          f16x8 h8, l8;
 #pragma unroll
-      for (int r = 0; r < WTH; ++r) {
-        const bool in = y0 + r < p.Ho && ox < p.Wo;
-        v[r] = *reinterpret_cast<const f32x4*>(dzin + ((int64_t)(in ? y0 + r : 0) * p.Wo + (in ? ox : 0)) * p.lddz + ch);
-        if (!in) v[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f16x8 h8, l8;
-#pragma unroll
-        for (int r = 0; r < WTH; ++r) { const float a = v[r][j] * sz_; const _Float16 ah = (_Float16)a; h8[r] = ah; l8[r] = (_Float16)(a - (float)ah); }
-        zh[c * p.Cout + ch + j] = h8; zl[c * p.Cout + ch + j] = l8;
-      }
-    }
-    __syncthreads();
-    // ---- accumulate: 16 K steps of 2 columns x 8 rows
-#pragma unroll 2
-    for (int xp = 0; xp < WTW / 2; ++xp) {
-      const int cx = 2 * xp + half;
-      const f16x8 bh = zh[cx * p.Cout + col], bl = zl[cx * p.Cout + col];
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        if (t < ntw) {
-          const int u = cx * p.Cin + (wv + WAVES * t) * 32 + col;
-          const f16x8 ah = xh[u], al = xl[u];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+          for (int r = 0; r < WTH; ++r) { h8[r] = pxh[k][r][j]; l8[r] = pxl[k][r][j]; }
+          const int u = xc[k] * p.Cin + (xch[k] >> 2) + j * GX;      // channel 4q + j sits at position j*GX + q of its column
+          xh[u] = h8; xl[u] = l8;
         }
       }
     }
-    const float rs = isx * isz;
+    if (tid < ntask_z) {
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+      for (int r = 0; r < WTH; ++r)
+        if (!((zin_mask >> r) & 1u)) { pzh[r] = zero4; pzl[r] = zero4; }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { tot[t][i] = fmaf(acc[t][i], rs, tot[t][i]); acc[t][i] = 0.f; }
-  }
-  // ---- write partials (same layout as the fp32 kernel)
-  {
-    const int nflat = kwg * p.Cin;
-    float* dst = p.ws + (((int64_t)split * p.kh + ki) * p.kw + kj0) * p.Cin * p.Cout;
+      for (int j = 0; j < 4; ++j) {
+        f16x8 h8, l8;
+#pragma unroll
+        for (int r = 0; r < WTH; ++r) { h8[r] = pzh[r][j]; l8[r] = pzl[r][j]; }
+        const int u = zc * p.Cout + (zch >> 2) + j * GZ;
+        zh[u] = h8; zl[u] = l8;
+      }
+    }
+  };
+
+  // partial sums of this (split, filter row, column group): same layout as the fp32 kernel's, still in the planes' units (the
+  // reduction kernel applies 1/(sx*sz))
+  const int nflat = kwg * p.Cin;
+  float* dst = p.ws + (((int64_t)split * p.kh + ki) * p.kw + kj0) * p.Cin * p.Cout;
+  auto fold = [&](bool first) {
+    // element offsets are rebuilt here from an opaque base: left to itself the compiler hoists all 16*TAPS 64-bit addresses out
+    // of the tile loop and keeps them in registers next to the prefetched tile
+    unsigned lane_off = (unsigned)((wv * 32 + 4 * half) * p.Cout + col);
+    asm volatile("" : "+v"(lane_off));
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int jt = wv + WAVES * t;
-      if (jt * 32 >= nflat) continue;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int R = jt * 32 + 8 * (i >> 2) + 4 * half + (i & 3);
-        if (R < nflat && col < p.Cout) dst[(int64_t)R * p.Cout + col] = tot[t][i];
+        if (R < nflat && col < p.Cout) {
+          // later folds: fire-and-forget adds (no return value, so no registers wait on memory); every address has exactly
+          // one writer thread, adding in program order - deterministic
+          float* o = dst + (lane_off + (unsigned)((WAVES * t * 32 + 8 * (i >> 2) + (i & 3)) * p.Cout));
+          if (first) *o = acc[t][i]; else (void)unsafeAtomicAdd(o, acc[t][i]);
+        }
+        acc[t][i] = 0.f;
       }
     }
+  };
+
+  // tiles are processed in groups of FOLD; the prefetch runs one tile ahead inside a group and restarts after the fold
+  constexpr int FOLD = 8;
+  int tile = split;
+  bool first = true;
+  issue(tile);
+  while (tile < p.ntiles) {
+    for (int g = 0; g < FOLD && tile < p.ntiles; ++g, tile += p.S) {
+      __syncthreads();                                 // previous tile's fragment reads are done
+      stage();
+      __syncthreads();
+      if (g + 1 < FOLD && tile + p.S < p.ntiles) issue(tile + p.S);   // in flight during the MFMA loop
+      // ---- accumulate: 16 K steps of 2 columns x 8 rows
+#pragma unroll 2
+      for (int xp = 0; xp < WTW / 2; ++xp) {
+        const int cx = 2 * xp + half;
+        const f16x8 bh = zh[cx * p.Cout + col], bl = zl[cx * p.Cout + col];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          if (t < ntw) {
+            const int u = cx * p.Cin + (wv + WAVES * t) * 32 + col;
+            const f16x8 ah = xh[u], al = xl[u];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (first) fold(true); else fold(false);
+    first = false;
+    if (tile < p.ntiles) issue(tile);
   }
 }
 
-template <int TAPS>
-void launch_wgrad_split(pcnn_handle h, const WgradParams& p, const WgradPlan& pl, size_t lds) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((wgrad_split_kernel<TAPS>), dim3(pl.S, p.kh, pl.gz), dim3(256), lds, h->stream, p);
+template <int TAPS, int XR>
+void launch_wgrad_split(pcnn_handle h, const WgradSplitParams& p, const WgradPlan& pl, size_t lds) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel<TAPS, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((wgrad_split_kernel<TAPS, XR>), dim3(8 * pcnn_cdiv(pl.S, 8) * p.b.kh * pl.gz), dim3(256), lds, h->stream, p);
 }
+
+// workspace = [split partials | 256 B: the two tensor maxima | x hi | x lo | dz hi | dz lo] (planes only for split-eligible shapes)
+size_t partials_bytes(const pcnn_conv_desc* d, const WgradPlan& pl) {
+  return (((size_t)pl.S * d->kh * d->kw * d->Cin * d->Cout * sizeof(float)) + 255) & ~(size_t)255;
+}
+bool split_eligible(const pcnn_conv_desc* d, const WgradPlan& pl) { return d->Cin % 4 == 0 && d->Cout % 4 == 0 && pl.NTC == 1; }
+size_t plane_elems_x(const pcnn_conv_desc* d) { return (((size_t)d->N * d->H * d->W * d->Cin) + 127) & ~(size_t)127; }
+size_t plane_elems_z(const pcnn_conv_desc* d) { return (((size_t)d->N * d->Ho * d->Wo * d->Cout) + 127) & ~(size_t)127; }
+size_t plane_bytes(const pcnn_conv_desc* d) { return 2 * sizeof(_Float16) * (plane_elems_x(d) + plane_elems_z(d)); }
 
 }  // namespace
 
 extern "C" size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d) {
   if (!d) return 0;
   WgradPlan pl = make_plan(d);
-  return (size_t)pl.S * d->kh * d->kw * d->Cin * d->Cout * sizeof(float);
+  return partials_bytes(d, pl) + (split_eligible(d, pl) ? 256 + plane_bytes(d) : 0);
 }
 
 extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
@@ -475,18 +607,37 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
   p.x = x; p.dz = dz; p.ws = static_cast<float*>(workspace);
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.lddz = d->ldy;
   p.kh = d->kh; p.kw = d->kw; p.pt = d->pad_top; p.pl = d->pad_left; p.pad_mode = d->pad_mode; p.pad_value = d->pad_value;
-  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S; p.KWG = pl.KWG; p.lg = pl.lg;
+  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S; p.KWG = pl.KWG; p.lg = pl.lg; p.gz = pl.gz;
   p.vecx = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   p.vecdz = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
-  const bool split_ok = h->math_mode == PCNN_MATH_SPLIT_F16 && p.vecx && p.vecdz && pl.NTC == 1;
+  const int xr = pcnn_cdiv((WTW + pl.KWG - 1) * (d->Cin >> 2), 256);      // x prefetch rounds of the split kernel (<= 3 held in registers)
+  const bool split_ok = h->math_mode == PCNN_MATH_SPLIT_F16 && p.vecx && p.vecdz && pl.NTC == 1 && xr >= 1 && xr <= 3 &&
+                        pl.TAPS <= 4 && WTW * (d->Cout >> 2) <= 256 &&
+                        plane_elems_x(d) * 2 < ((size_t)1 << 32) && plane_elems_z(d) * 2 < ((size_t)1 << 32);
   if (split_ok) {
-    const size_t lds = ((size_t)(WTW + pl.KWG - 1) * d->Cin + (size_t)WTW * d->Cout) * 32 + 512 + 64;
-    switch (pl.TAPS) {
-      case 1: launch_wgrad_split<1>(h, p, pl, lds); break;
-      case 2: launch_wgrad_split<2>(h, p, pl, lds); break;
-      case 3: launch_wgrad_split<3>(h, p, pl, lds); break;
-      default: launch_wgrad_split<4>(h, p, pl, lds); break;
-    }
+    char* base = static_cast<char*>(workspace) + partials_bytes(d, pl);
+    SplitPlanes pp;
+    pp.maxbits = reinterpret_cast<unsigned*>(base);
+    _Float16* planes = reinterpret_cast<_Float16*>(base + 256);
+    pp.src[0] = x; pp.src[1] = dz;
+    pp.hi[0] = planes; pp.lo[0] = planes + plane_elems_x(d);
+    pp.hi[1] = pp.lo[0] + plane_elems_x(d); pp.lo[1] = pp.hi[1] + plane_elems_z(d);
+    pp.cq[0] = d->Cin >> 2; pp.cq[1] = d->Cout >> 2; pp.ld[0] = d->ldx; pp.ld[1] = d->ldy;
+    pp.nquad[0] = (int64_t)d->N * d->H * d->W * pp.cq[0]; pp.nquad[1] = (int64_t)d->N * d->Ho * d->Wo * pp.cq[1];
+    (void)hipMemsetAsync(pp.maxbits, 0, 8, h->stream);
+    const int64_t nq = std::max(pp.nquad[0], pp.nquad[1]);
+    const unsigned gx = (unsigned)std::min<int64_t>(pcnn_cdiv64(nq, 256 * 4), 8192);
+    hipLaunchKernelGGL(split_absmax_kernel, dim3(gx, 2), dim3(256), 0, h->stream, pp);
+    hipLaunchKernelGGL(split_convert_kernel, dim3(gx, 2), dim3(256), 0, h->stream, pp);
+    PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(split planes)");
+    WgradSplitParams sp;
+    sp.b = p; sp.xh = pp.hi[0]; sp.xl = pp.lo[0]; sp.zh = pp.hi[1]; sp.zl = pp.lo[1]; sp.maxbits = pp.maxbits;
+    const size_t lds = ((size_t)(WTW + pl.KWG - 1) * d->Cin + (size_t)WTW * d->Cout) * 32 + 512;
+#define PCNN_WGS(T, R) if (pl.TAPS == T && xr == R) launch_wgrad_split<T, R>(h, sp, pl, lds); else
+    PCNN_WGS(1, 1) PCNN_WGS(1, 2) PCNN_WGS(1, 3) PCNN_WGS(2, 1) PCNN_WGS(2, 2) PCNN_WGS(2, 3)
+    PCNN_WGS(3, 1) PCNN_WGS(3, 2) PCNN_WGS(3, 3) PCNN_WGS(4, 1) PCNN_WGS(4, 2) PCNN_WGS(4, 3)
+    { PCNN_FAIL(h, "pcnn_conv2d_wgrad: no split kernel for TAPS=%d XR=%d", pl.TAPS, xr); }
+#undef PCNN_WGS
   } else
 #define PCNN_WG(Q, T) if (pl.NTC == Q && pl.TAPS == T) { launch_wgrad<Q, T>(h, p, pl); } else
   PCNN_WG(1, 1) PCNN_WG(1, 2) PCNN_WG(1, 3) PCNN_WG(1, 4) PCNN_WG(2, 1) PCNN_WG(2, 2)
@@ -495,7 +646,7 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad");
   const int64_t nel = (int64_t)d->kh * d->kw * d->Cin * d->Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(nel, 256), 2048)), dim3(256), 0, h->stream,
-                     p.ws, dw, nel, pl.S);
+                     p.ws, dw, nel, pl.S, split_ok ? reinterpret_cast<const unsigned*>(static_cast<char*>(workspace) + partials_bytes(d, pl)) : nullptr, d->Cin, d->Cout);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(reduce)");
   return 0;
 }
