@@ -268,10 +268,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 }
 
-// maxbits != nullptr: the partials come from the split kernel - in its units (maxbits = {max|x|, max|dz|} as float bits) and
-// with its channel order (channel 4q + j of a pixel at position j*C/4 + q, for both Cin and Cout)
+// maxbits != nullptr: the partials come from the split kernel - in its units (maxbits = {max|x|, max|dz|} as float bits), with
+// channels padded to multiples of 4 (Cip, Cop) and in its channel order (channel 4q + j of a pixel at position j*Cp/4 + q).
+// nel counts the partials' elements (kh*kw*Cip*Cop), dw is dense [kh*kw][Cin][Cout].
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t nel, int S, const unsigned* __restrict__ maxbits,
-                                    int Cin, int Cout) {
+                                    int Cin, int Cout, int Cip, int Cop) {
   float rs = 1.f;
   if (maxbits) {
     int ex = 0, ez = 0;
@@ -281,16 +282,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     const bool okx = mx > 0.f && ex > -100 && ex < 100, okz = mz > 0.f && ez > -100 && ez < 100;   // as pow2_scale()
     rs = (okx ? ldexpf(1.0f, ex - 13) : 1.0f) * (okz ? ldexpf(1.0f, ez - 13) : 1.0f);
   }
-  const int GX = Cin >> 2, GZ = Cout >> 2;
+  const int GX = Cip >> 2, GZ = Cop >> 2;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nel; e += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += ws[(int64_t)k * nel + e];
     int64_t o = e;
     if (maxbits) {
-      const int pz = (int)(e % Cout); const int64_t t = e / Cout;
-      const int px = (int)(t % Cin); const int64_t tap = t / Cin;
-      o = (tap * Cin + 4 * (px % GX) + px / GX) * Cout + 4 * (pz % GZ) + pz / GZ;
+      const int pz = (int)(e % Cop); const int64_t t = e / Cop;
+      const int px = (int)(t % Cip); const int64_t tap = t / Cip;
+      const int ci = 4 * (px % GX) + px / GX, co = 4 * (pz % GZ) + pz / GZ;
+      if (ci >= Cin || co >= Cout) continue;
+      o = (tap * Cin + ci) * Cout + co;
     }
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += ws[(int64_t)k * nel + e];
     dw[o] = s * rs;
   }
 }
@@ -333,19 +336,29 @@ __device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
 
 struct SplitPlanes {
   const float* src[2]; _Float16* hi[2]; _Float16* lo[2];
-  int64_t nquad[2]; int cq[2]; int ld[2];            // quads in total, quads per pixel, source channel stride
+  int64_t nquad[2]; int cq[2]; int C[2]; int ld[2]; int vec[2];     // quads in total, quads per pixel, channels, source channel stride, float4-loadable
   unsigned* maxbits;
 };
+
+// channels 4q .. 4q+3 of one pixel; channels past C read as zero (the planes are padded to a multiple of 4 channels)
+__device__ __forceinline__ f32x4 load_quad(const float* __restrict__ src, int64_t pix, int ch, int C, int ld, int vec) {
+  const float* q = src + pix * ld + ch;
+  if (vec) return *reinterpret_cast<const f32x4*>(q);
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = ch + j < C ? q[j] : 0.f;
+  return v;
+}
 
 // blockIdx.y: 0 = x, 1 = dz.  max|v| as float bits (non-negative floats order like unsigned integers)
 __global__ __launch_bounds__(256) void split_absmax_kernel(SplitPlanes sp) {
   const int which = blockIdx.y;
   const float* src = sp.src[which];
-  const int cq = sp.cq[which], ld = sp.ld[which];
+  const int cq = sp.cq[which], ld = sp.ld[which], C = sp.C[which], vec = sp.vec[which];
   float mx = 0.f;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < sp.nquad[which]; q += (int64_t)gridDim.x * 256) {
     const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + pix * ld + ch);
+    const f32x4 v = load_quad(src, pix, ch, C, ld, vec);
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
   mx = wg_wave_max(mx);
@@ -362,14 +375,14 @@ __global__ __launch_bounds__(256) void split_absmax_kernel(SplitPlanes sp) {
 __global__ __launch_bounds__(256) void split_convert_kernel(SplitPlanes sp) {
   const int which = blockIdx.y;
   const float* src = sp.src[which];
-  const int cq = sp.cq[which], ld = sp.ld[which];
+  const int cq = sp.cq[which], ld = sp.ld[which], C = sp.C[which], vec = sp.vec[which];
   float s, inv_s;
   pow2_scale(__uint_as_float(sp.maxbits[which]), s, inv_s);
   f16x4* hi = reinterpret_cast<f16x4*>(sp.hi[which]);
   f16x4* lo = reinterpret_cast<f16x4*>(sp.lo[which]);
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < sp.nquad[which]; q += (int64_t)gridDim.x * 256) {
     const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + pix * ld + ch);
+    const f32x4 v = load_quad(src, pix, ch, C, ld, vec);
     f16x4 h4, l4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const float a = v[j] * s; const _Float16 ah = (_Float16)a; h4[j] = ah; l4[j] = (_Float16)(a - (float)ah); }
@@ -578,21 +591,37 @@ void launch_wgrad_split(pcnn_handle h, const WgradSplitParams& p, const WgradPla
   hipLaunchKernelGGL((wgrad_split_kernel<TAPS, XR>), dim3(8 * pcnn_cdiv(pl.S, 8) * p.b.kh * pl.gz), dim3(256), lds, h->stream, p);
 }
 
-// workspace = [split partials | 256 B: the two tensor maxima | x hi | x lo | dz hi | dz lo] (planes only for split-eligible shapes)
+// workspace = [split partials | 256 B: the two tensor maxima | x hi | x lo | dz hi | dz lo]; the planes exist for shapes the
+// split kernel takes: it sees the layer with both channel counts padded to multiples of 4 (the planes are private copies)
 size_t partials_bytes(const pcnn_conv_desc* d, const WgradPlan& pl) {
   return (((size_t)pl.S * d->kh * d->kw * d->Cin * d->Cout * sizeof(float)) + 255) & ~(size_t)255;
 }
-bool split_eligible(const pcnn_conv_desc* d, const WgradPlan& pl) { return d->Cin % 4 == 0 && d->Cout % 4 == 0 && pl.NTC == 1; }
-size_t plane_elems_x(const pcnn_conv_desc* d) { return (((size_t)d->N * d->H * d->W * d->Cin) + 127) & ~(size_t)127; }
-size_t plane_elems_z(const pcnn_conv_desc* d) { return (((size_t)d->N * d->Ho * d->Wo * d->Cout) + 127) & ~(size_t)127; }
-size_t plane_bytes(const pcnn_conv_desc* d) { return 2 * sizeof(_Float16) * (plane_elems_x(d) + plane_elems_z(d)); }
+pcnn_conv_desc padded_desc(const pcnn_conv_desc* d) {
+  pcnn_conv_desc pd = *d;
+  pd.Cin = (d->Cin + 3) & ~3; pd.Cout = (d->Cout + 3) & ~3;
+  return pd;
+}
+size_t plane_elems_x(const pcnn_conv_desc* pd) { return (((size_t)pd->N * pd->H * pd->W * pd->Cin) + 127) & ~(size_t)127; }
+size_t plane_elems_z(const pcnn_conv_desc* pd) { return (((size_t)pd->N * pd->Ho * pd->Wo * pd->Cout) + 127) & ~(size_t)127; }
+size_t plane_bytes(const pcnn_conv_desc* pd) { return 2 * sizeof(_Float16) * (plane_elems_x(pd) + plane_elems_z(pd)); }
+int split_xr(const pcnn_conv_desc* pd, const WgradPlan& pls) { return pcnn_cdiv((WTW + pls.KWG - 1) * (pd->Cin >> 2), 256); }
+size_t split_lds(const pcnn_conv_desc* pd, const WgradPlan& pls) { return ((size_t)(WTW + pls.KWG - 1) * pd->Cin + (size_t)WTW * pd->Cout) * 32 + 512; }
+bool split_eligible(const pcnn_conv_desc* pd, const WgradPlan& pls) {      // pd, pls: the padded layer and its plan
+  const int xr = split_xr(pd, pls);
+  return pls.NTC == 1 && xr >= 1 && xr <= 3 && pls.TAPS <= 4 && WTW * (pd->Cout >> 2) <= 256 && split_lds(pd, pls) <= 160 * 1024 &&
+         plane_elems_x(pd) * 2 < ((size_t)1 << 32) && plane_elems_z(pd) * 2 < ((size_t)1 << 32);
+}
 
 }  // namespace
 
 extern "C" size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d) {
   if (!d) return 0;
-  WgradPlan pl = make_plan(d);
-  return partials_bytes(d, pl) + (split_eligible(d, pl) ? 256 + plane_bytes(d) : 0);
+  const WgradPlan pl = make_plan(d);
+  const pcnn_conv_desc pd = padded_desc(d);
+  const WgradPlan pls = make_plan(&pd);
+  const size_t plain = partials_bytes(d, pl);
+  const size_t split = split_eligible(&pd, pls) ? partials_bytes(&pd, pls) + 256 + plane_bytes(&pd) : 0;
+  return plain > split ? plain : split;
 }
 
 extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
@@ -600,29 +629,31 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
   PCNN_REQUIRE(h, h && d && x && dz && dw && workspace, "pcnn_conv2d_wgrad: null argument");
   PCNN_REQUIRE(h, d->Cin >= 1 && d->Cin <= 128 && d->Cout >= 1 && d->Cout <= 64, "pcnn_conv2d_wgrad: channels %d->%d unsupported (<=64)", d->Cin, d->Cout);
   PCNN_REQUIRE(h, d->ldx >= d->Cin && d->ldy >= d->Cout, "pcnn_conv2d_wgrad: channel stride smaller than channel count");
-  WgradPlan pl = make_plan(d);
   PCNN_REQUIRE(h, workspace_bytes >= pcnn_conv2d_wgrad_workspace(d), "pcnn_conv2d_wgrad: workspace too small");
-  PCNN_REQUIRE(h, pl.lds <= 160 * 1024, "pcnn_conv2d_wgrad: tile needs %zu B of LDS", pl.lds);
+  const pcnn_conv_desc pd = padded_desc(d);
+  const WgradPlan pls = make_plan(&pd);
+  const bool split_ok = h->math_mode == PCNN_MATH_SPLIT_F16 && split_eligible(&pd, pls);
+  const pcnn_conv_desc* ud = split_ok ? &pd : d;                       // the layer as the chosen kernel sees it
+  const WgradPlan pl = split_ok ? pls : make_plan(d);
+  PCNN_REQUIRE(h, split_ok || pl.lds <= 160 * 1024, "pcnn_conv2d_wgrad: tile needs %zu B of LDS", pl.lds);
   WgradParams p;
   p.x = x; p.dz = dz; p.ws = static_cast<float*>(workspace);
-  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.lddz = d->ldy;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = ud->Cin; p.ldx = d->ldx; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = ud->Cout; p.lddz = d->ldy;
   p.kh = d->kh; p.kw = d->kw; p.pt = d->pad_top; p.pl = d->pad_left; p.pad_mode = d->pad_mode; p.pad_value = d->pad_value;
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.S = pl.S; p.KWG = pl.KWG; p.lg = pl.lg; p.gz = pl.gz;
   p.vecx = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   p.vecdz = (d->Cout % 4 == 0) && (d->ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
-  const int xr = pcnn_cdiv((WTW + pl.KWG - 1) * (d->Cin >> 2), 256);      // x prefetch rounds of the split kernel (<= 3 held in registers)
-  const bool split_ok = h->math_mode == PCNN_MATH_SPLIT_F16 && p.vecx && p.vecdz && pl.NTC == 1 && xr >= 1 && xr <= 3 &&
-                        pl.TAPS <= 4 && WTW * (d->Cout >> 2) <= 256 &&
-                        plane_elems_x(d) * 2 < ((size_t)1 << 32) && plane_elems_z(d) * 2 < ((size_t)1 << 32);
+  const int xr = split_xr(&pd, pls);
   if (split_ok) {
-    char* base = static_cast<char*>(workspace) + partials_bytes(d, pl);
+    char* base = static_cast<char*>(workspace) + partials_bytes(&pd, pl);
     SplitPlanes pp;
     pp.maxbits = reinterpret_cast<unsigned*>(base);
     _Float16* planes = reinterpret_cast<_Float16*>(base + 256);
     pp.src[0] = x; pp.src[1] = dz;
-    pp.hi[0] = planes; pp.lo[0] = planes + plane_elems_x(d);
-    pp.hi[1] = pp.lo[0] + plane_elems_x(d); pp.lo[1] = pp.hi[1] + plane_elems_z(d);
-    pp.cq[0] = d->Cin >> 2; pp.cq[1] = d->Cout >> 2; pp.ld[0] = d->ldx; pp.ld[1] = d->ldy;
+    pp.hi[0] = planes; pp.lo[0] = planes + plane_elems_x(&pd);
+    pp.hi[1] = pp.lo[0] + plane_elems_x(&pd); pp.lo[1] = pp.hi[1] + plane_elems_z(&pd);
+    pp.cq[0] = pd.Cin >> 2; pp.cq[1] = pd.Cout >> 2; pp.C[0] = d->Cin; pp.C[1] = d->Cout; pp.ld[0] = d->ldx; pp.ld[1] = d->ldy;
+    pp.vec[0] = p.vecx; pp.vec[1] = p.vecdz;
     pp.nquad[0] = (int64_t)d->N * d->H * d->W * pp.cq[0]; pp.nquad[1] = (int64_t)d->N * d->Ho * d->Wo * pp.cq[1];
     (void)hipMemsetAsync(pp.maxbits, 0, 8, h->stream);
     const int64_t nq = std::max(pp.nquad[0], pp.nquad[1]);
@@ -632,7 +663,7 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
     PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(split planes)");
     WgradSplitParams sp;
     sp.b = p; sp.xh = pp.hi[0]; sp.xl = pp.lo[0]; sp.zh = pp.hi[1]; sp.zl = pp.lo[1]; sp.maxbits = pp.maxbits;
-    const size_t lds = ((size_t)(WTW + pl.KWG - 1) * d->Cin + (size_t)WTW * d->Cout) * 32 + 512;
+    const size_t lds = split_lds(&pd, pl);
 #define PCNN_WGS(T, R) if (pl.TAPS == T && xr == R) launch_wgrad_split<T, R>(h, sp, pl, lds); else
     PCNN_WGS(1, 1) PCNN_WGS(1, 2) PCNN_WGS(1, 3) PCNN_WGS(2, 1) PCNN_WGS(2, 2) PCNN_WGS(2, 3)
     PCNN_WGS(3, 1) PCNN_WGS(3, 2) PCNN_WGS(3, 3) PCNN_WGS(4, 1) PCNN_WGS(4, 2) PCNN_WGS(4, 3)
@@ -644,9 +675,10 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
   { PCNN_FAIL(h, "pcnn_conv2d_wgrad: no kernel for NTC=%d TAPS=%d", pl.NTC, pl.TAPS); }
 #undef PCNN_WG
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad");
-  const int64_t nel = (int64_t)d->kh * d->kw * d->Cin * d->Cout;
+  const int64_t nel = (int64_t)d->kh * d->kw * ud->Cin * ud->Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(nel, 256), 2048)), dim3(256), 0, h->stream,
-                     p.ws, dw, nel, pl.S, split_ok ? reinterpret_cast<const unsigned*>(static_cast<char*>(workspace) + partials_bytes(d, pl)) : nullptr, d->Cin, d->Cout);
+                     p.ws, dw, nel, pl.S, split_ok ? reinterpret_cast<const unsigned*>(static_cast<char*>(workspace) + partials_bytes(&pd, pl)) : nullptr,
+                     d->Cin, d->Cout, ud->Cin, ud->Cout);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(reduce)");
   return 0;
 }

@@ -95,38 +95,80 @@ __global__ void zero_strided_kernel(int64_t npix, int C, float* __restrict__ y, 
 }
 
 // ---------------------------------------------------------------- resize
-__global__ void resize_fwd_kernel(int N, int hc, int wc, int C, int Ho, int Wo, const float* __restrict__ x, int ldx,
+// V = channels per thread (4: float4 accesses when C, the channel strides and the base pointers allow it; 1: any layout)
+template <int V> struct ChanVec;
+template <> struct ChanVec<1> {
+  float v[1];
+  __device__ static ChanVec load(const float* p) { ChanVec r; r.v[0] = *p; return r; }
+  __device__ void store(float* p) const { *p = v[0]; }
+};
+template <> struct ChanVec<4> {
+  float v[4];
+  __device__ static ChanVec load(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    ChanVec r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+  }
+  __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(int N, int hc, int wc, int C, int Ho, int Wo, const float* __restrict__ x, int ldx,
                                   const int32_t* __restrict__ iy, const float* __restrict__ wy, const int32_t* __restrict__ ix,
                                   const float* __restrict__ wx, float alpha, float beta, float* __restrict__ y, int ldy) {
-  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int CV = C / V;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = i % C; int64_t r = i / C; const int ox = r % Wo; r /= Wo; const int oy = r % Ho; const int n = r / Ho;
-    float acc = 0.f;
+    const int c = (int)(i % CV) * V; int64_t r = i / CV; const int ox = r % Wo; r /= Wo; const int oy = r % Ho; const int n = r / Ho;
+    float wxb[4]; int ixb[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { wxb[b] = wx[ox * 4 + b]; ixb[b] = ix[ox * 4 + b]; }
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const float wya = wy[oy * 4 + a];
       if (wya == 0.f) continue;
-      const float* row = x + ((int64_t)n * hc + iy[oy * 4 + a]) * wc * ldx;
-      float t = 0.f;
+      const float* row = x + ((int64_t)n * hc + iy[oy * 4 + a]) * wc * ldx + c;
+      float t[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) t[j] = 0.f;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const float wxb = wx[ox * 4 + b];
-        if (wxb != 0.f) t += wxb * row[(int64_t)ix[ox * 4 + b] * ldx + c];
+        if (wxb[b] != 0.f) {
+          const ChanVec<V> q = ChanVec<V>::load(row + (int64_t)ixb[b] * ldx);
+#pragma unroll
+          for (int j = 0; j < V; ++j) t[j] += wxb[b] * q.v[j];
+        }
       }
-      acc += wya * t;
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += wya * t[j];
     }
     float* dst = &y[(((int64_t)n * Ho + oy) * Wo + ox) * ldy + c];
-    *dst = beta == 0.f ? alpha * acc : beta * *dst + alpha * acc;
+    ChanVec<V> o;
+    if (beta == 0.f) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.v[j] = alpha * acc[j];
+    } else {
+      const ChanVec<V> old = ChanVec<V>::load(dst);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o.v[j] = beta * old.v[j] + alpha * acc[j];
+    }
+    o.store(dst);
   }
 }
 
 // pass 1 of the adjoint: tmp[n, yc, X, c] = sum_Y Ry[Y, yc] dy[n, Y, X, c]
-__global__ void resize_bwd_rows_kernel(int N, int hc, int C, int Ho, int Wo, const float* __restrict__ dy, int lddy,
+template <int V>
+__global__ __launch_bounds__(256) void resize_bwd_rows_kernel(int N, int hc, int C, int Ho, int Wo, const float* __restrict__ dy, int lddy,
                                        const int32_t* __restrict__ iy, const float* __restrict__ wy, float* __restrict__ tmp) {
-  const int64_t total = (int64_t)N * hc * Wo * C;
+  const int CV = C / V;
+  const int64_t total = (int64_t)N * hc * Wo * CV;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = i % C; int64_t r = i / C; const int X = r % Wo; r /= Wo; const int yc = r % hc; const int n = r / hc;
-    float acc = 0.f;
+    const int c = (int)(i % CV) * V; int64_t r = i / CV; const int X = r % Wo; r /= Wo; const int yc = r % hc; const int n = r / hc;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
     // only output rows whose (<= 4) taps can reach yc: conservative window around yc * (Ho/hc)
     const float sc = (float)Ho / (float)hc;
     int Ya = (int)floorf(((float)yc - 2.5f) * sc) - 1, Yb = (int)ceilf(((float)yc + 3.5f) * sc) + 2;
@@ -136,19 +178,30 @@ __global__ void resize_bwd_rows_kernel(int N, int hc, int C, int Ho, int Wo, con
       float wsum = 0.f;
 #pragma unroll
       for (int a = 0; a < 4; ++a) wsum += (iy[Y * 4 + a] == yc) ? wy[Y * 4 + a] : 0.f;
-      if (wsum != 0.f) acc += wsum * dy[(((int64_t)n * Ho + Y) * Wo + X) * lddy + c];
+      if (wsum != 0.f) {
+        const ChanVec<V> q = ChanVec<V>::load(dy + (((int64_t)n * Ho + Y) * Wo + X) * lddy + c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += wsum * q.v[j];
+      }
     }
-    tmp[i] = acc;
+    ChanVec<V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = acc[j];
+    o.store(tmp + (((int64_t)n * hc + yc) * Wo + X) * C + c);
   }
 }
 
 // pass 2: dx[n, yc, xc, c] = alpha * sum_X Rx[X, xc] tmp[n, yc, X, c]
-__global__ void resize_bwd_cols_kernel(int N, int hc, int wc, int C, int Wo, const float* __restrict__ tmp, const int32_t* __restrict__ ix,
+template <int V>
+__global__ __launch_bounds__(256) void resize_bwd_cols_kernel(int N, int hc, int wc, int C, int Wo, const float* __restrict__ tmp, const int32_t* __restrict__ ix,
                                        const float* __restrict__ wx, float alpha, float* __restrict__ dx, int lddx) {
-  const int64_t total = (int64_t)N * hc * wc * C;
+  const int CV = C / V;
+  const int64_t total = (int64_t)N * hc * wc * CV;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = i % C; int64_t r = i / C; const int xc = r % wc; r /= wc; const int yc = r % hc; const int n = r / hc;
-    float acc = 0.f;
+    const int c = (int)(i % CV) * V; int64_t r = i / CV; const int xc = r % wc; r /= wc; const int yc = r % hc; const int n = r / hc;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
     const float sc = (float)Wo / (float)wc;
     int Xa = (int)floorf(((float)xc - 2.5f) * sc) - 1, Xb = (int)ceilf(((float)xc + 3.5f) * sc) + 2;
     if (Xa < 0) Xa = 0;
@@ -157,10 +210,21 @@ __global__ void resize_bwd_cols_kernel(int N, int hc, int wc, int C, int Wo, con
       float wsum = 0.f;
 #pragma unroll
       for (int b = 0; b < 4; ++b) wsum += (ix[X * 4 + b] == xc) ? wx[X * 4 + b] : 0.f;
-      if (wsum != 0.f) acc += wsum * tmp[(((int64_t)n * hc + yc) * Wo + X) * C + c];
+      if (wsum != 0.f) {
+        const ChanVec<V> q = ChanVec<V>::load(tmp + (((int64_t)n * hc + yc) * Wo + X) * C + c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += wsum * q.v[j];
+      }
     }
-    dx[(((int64_t)n * hc + yc) * wc + xc) * lddx + c] = alpha * acc;
+    ChanVec<V> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = alpha * acc[j];
+    o.store(dx + (((int64_t)n * hc + yc) * wc + xc) * lddx + c);
   }
+}
+
+static bool vec4_ok(int C, const void* a, int lda, const void* b, int ldb) {
+  return C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
 }
 
 static dim3 grid1d(int64_t total, int block = 256, int maxb = 16384) {
@@ -286,8 +350,12 @@ extern "C" int pcnn_resize_tables(int method, int n_in, int n_out, int32_t* idx,
 extern "C" int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* x, int ldx, const int32_t* idx_y,
                                const float* wt_y, const int32_t* idx_x, const float* wt_x, float alpha, float beta, float* y, int ldy) {
   PCNN_REQUIRE(h, h && x && y && idx_y && wt_y && idx_x && wt_x, "pcnn_resize_fwd: null argument");
-  hipLaunchKernelGGL(resize_fwd_kernel, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, N, hc, wc, C, Ho, Wo, x, ldx, idx_y, wt_y, idx_x, wt_x,
-                     alpha, beta, y, ldy);
+  if (vec4_ok(C, x, ldx, y, ldy))
+    hipLaunchKernelGGL(resize_fwd_kernel<4>, grid1d((int64_t)N * Ho * Wo * (C / 4)), dim3(256), 0, h->stream, N, hc, wc, C, Ho, Wo, x, ldx, idx_y, wt_y, idx_x,
+                       wt_x, alpha, beta, y, ldy);
+  else
+    hipLaunchKernelGGL(resize_fwd_kernel<1>, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, N, hc, wc, C, Ho, Wo, x, ldx, idx_y, wt_y, idx_x, wt_x,
+                       alpha, beta, y, ldy);
   PCNN_CHECK_LAUNCH(h, "pcnn_resize_fwd");
   return 0;
 }
@@ -295,9 +363,15 @@ extern "C" int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int 
 extern "C" int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* dy, int lddy, const int32_t* idx_y,
                                const float* wt_y, const int32_t* idx_x, const float* wt_x, float alpha, float* tmp, float* dx, int lddx) {
   PCNN_REQUIRE(h, h && dy && dx && tmp && idx_y && wt_y && idx_x && wt_x, "pcnn_resize_bwd: null argument");
-  hipLaunchKernelGGL(resize_bwd_rows_kernel, grid1d((int64_t)N * hc * Wo * C), dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
+  if (vec4_ok(C, dy, lddy, tmp, 4))
+    hipLaunchKernelGGL(resize_bwd_rows_kernel<4>, grid1d((int64_t)N * hc * Wo * (C / 4)), dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
+  else
+    hipLaunchKernelGGL(resize_bwd_rows_kernel<1>, grid1d((int64_t)N * hc * Wo * C), dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
   PCNN_CHECK_LAUNCH(h, "pcnn_resize_bwd(rows)");
-  hipLaunchKernelGGL(resize_bwd_cols_kernel, grid1d((int64_t)N * hc * wc * C), dim3(256), 0, h->stream, N, hc, wc, C, Wo, tmp, idx_x, wt_x, alpha, dx, lddx);
+  if (vec4_ok(C, tmp, 4, dx, lddx))
+    hipLaunchKernelGGL(resize_bwd_cols_kernel<4>, grid1d((int64_t)N * hc * wc * (C / 4)), dim3(256), 0, h->stream, N, hc, wc, C, Wo, tmp, idx_x, wt_x, alpha, dx, lddx);
+  else
+    hipLaunchKernelGGL(resize_bwd_cols_kernel<1>, grid1d((int64_t)N * hc * wc * C), dim3(256), 0, h->stream, N, hc, wc, C, Wo, tmp, idx_x, wt_x, alpha, dx, lddx);
   PCNN_CHECK_LAUNCH(h, "pcnn_resize_bwd(cols)");
   return 0;
 }
