@@ -350,16 +350,24 @@ __device__ __forceinline__ f32x4 load_quad(const float* __restrict__ src, int64_
   return v;
 }
 
-// blockIdx.y: 0 = x, 1 = dz.  max|v| as float bits (non-negative floats order like unsigned integers)
+// blockIdx.y: 0 = x, 1 = dz.  max|v| as float bits (non-negative floats order like unsigned integers).  Both pre-pass kernels
+// are pure streaming: 4 independent 16-byte loads in flight per thread.
 __global__ __launch_bounds__(256) void split_absmax_kernel(SplitPlanes sp) {
   const int which = blockIdx.y;
   const float* src = sp.src[which];
   const int cq = sp.cq[which], ld = sp.ld[which], C = sp.C[which], vec = sp.vec[which];
+  const int64_t nq = sp.nquad[which], stride = (int64_t)gridDim.x * 256;
   float mx = 0.f;
-  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < sp.nquad[which]; q += (int64_t)gridDim.x * 256) {
-    const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
-    const f32x4 v = load_quad(src, pix, ch, C, ld, vec);
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  for (int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = q0 + u * stride < nq ? q0 + u * stride : q0;
+      const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
+      v[u] = load_quad(src, pix, ch, C, ld, vec);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
   }
   mx = wg_wave_max(mx);
   __shared__ float red[4];
@@ -376,17 +384,28 @@ __global__ __launch_bounds__(256) void split_convert_kernel(SplitPlanes sp) {
   const int which = blockIdx.y;
   const float* src = sp.src[which];
   const int cq = sp.cq[which], ld = sp.ld[which], C = sp.C[which], vec = sp.vec[which];
+  const int64_t nq = sp.nquad[which], stride = (int64_t)gridDim.x * 256;
   float s, inv_s;
   pow2_scale(__uint_as_float(sp.maxbits[which]), s, inv_s);
   f16x4* hi = reinterpret_cast<f16x4*>(sp.hi[which]);
   f16x4* lo = reinterpret_cast<f16x4*>(sp.lo[which]);
-  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < sp.nquad[which]; q += (int64_t)gridDim.x * 256) {
-    const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
-    const f32x4 v = load_quad(src, pix, ch, C, ld, vec);
-    f16x4 h4, l4;
+  for (int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x; q0 < nq; q0 += 4 * stride) {
+    f32x4 v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const float a = v[j] * s; const _Float16 ah = (_Float16)a; h4[j] = ah; l4[j] = (_Float16)(a - (float)ah); }
-    hi[q] = h4; lo[q] = l4;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = q0 + u * stride < nq ? q0 + u * stride : q0;
+      const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
+      v[u] = load_quad(src, pix, ch, C, ld, vec);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t q = q0 + u * stride;
+      if (q >= nq) break;
+      f16x4 h4, l4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float a = v[u][j] * s; const _Float16 ah = (_Float16)a; h4[j] = ah; l4[j] = (_Float16)(a - (float)ah); }
+      hi[q] = h4; lo[q] = l4;
+    }
   }
 }
 
@@ -657,7 +676,7 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
     pp.nquad[0] = (int64_t)d->N * d->H * d->W * pp.cq[0]; pp.nquad[1] = (int64_t)d->N * d->Ho * d->Wo * pp.cq[1];
     (void)hipMemsetAsync(pp.maxbits, 0, 8, h->stream);
     const int64_t nq = std::max(pp.nquad[0], pp.nquad[1]);
-    const unsigned gx = (unsigned)std::min<int64_t>(pcnn_cdiv64(nq, 256 * 4), 8192);
+    const unsigned gx = (unsigned)std::min<int64_t>(pcnn_cdiv64(nq, 256 * 4), 4096);
     hipLaunchKernelGGL(split_absmax_kernel, dim3(gx, 2), dim3(256), 0, h->stream, pp);
     hipLaunchKernelGGL(split_convert_kernel, dim3(gx, 2), dim3(256), 0, h->stream, pp);
     PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(split planes)");

@@ -40,6 +40,45 @@ __global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_kernel(int64_t npix, in
   }
 }
 
+// float4 variant (C, the channel strides and the base pointers multiples of 4 floats): thread -> (pixel slot r = tid / GQ,
+// channel quad q = tid % GQ), no padding of the channel count to a power of two; same partial layout
+__global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_vec4_kernel(int64_t npix, int C, const float* __restrict__ dy, int lddy,
+                                                                     const float* __restrict__ a, int lda, const float* __restrict__ bn_scale,
+                                                                     int act, float alpha, float* __restrict__ dz, int lddz,
+                                                                     float* __restrict__ partial /*[gridDim][3][C]*/) {
+  __shared__ float red[3][CS_BLOCK * 4];
+  const int GQ = C >> 2, R = CS_BLOCK / GQ;
+  const int tid = threadIdx.x, r = tid / GQ, q = tid - r * GQ, c = q << 2;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < R) {
+    float sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = bn_scale ? bn_scale[c + j] : 1.f;
+    for (int64_t pix = (int64_t)blockIdx.x * R + r; pix < npix; pix += (int64_t)gridDim.x * R) {
+      const float4 g4 = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
+      const float4 a4 = a ? *reinterpret_cast<const float4*>(a + pix * lda + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
+      float z[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        z[j] = g[j] * sc[j] * pcnn_act_grad_from_out(av[j], act, alpha);
+        s0[j] += z[j]; s1[j] += g[j] * av[j]; s2[j] += g[j];
+      }
+      if (dz) *reinterpret_cast<float4*>(dz + pix * lddz + c) = make_float4(z[0], z[1], z[2], z[3]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][tid * 4 + j] = s0[j]; red[1][tid * 4 + j] = s1[j]; red[2][tid * 4 + j] = s2[j]; }
+  __syncthreads();
+  if (tid < C) {                       // channel tid: entries (r * GQ + tid / 4) * 4 + tid % 4 = r * C + tid
+    for (int k = 0; k < 3; ++k) {
+      float s = 0.f;
+      for (int rr = 0; rr < R; ++rr) s += red[k][rr * C + tid];
+      partial[((int64_t)blockIdx.x * 3 + k) * C + tid] = s;
+    }
+  }
+}
+
 // one workgroup per channel: the (<= 1024) block partials of each of the 3 sums are tree-reduced in a fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* o0, float* o1, float* o2) {
   __shared__ float red[3][256];
@@ -321,8 +360,14 @@ extern "C" int pcnn_conv2d_epilogue_bwd(pcnn_handle h, int64_t npix, int C, cons
   const int CP = pow2_ge(C);
   const int nb = colsum_blocks(npix, CP);
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(nb), dim3(CS_BLOCK), 0, h->stream, npix, C, CP, dy, lddy, a, lda, bn_scale, act, act_alpha,
-                     dz, lddz, partial);
+  const bool vec4 = C % 4 == 0 && lddy % 4 == 0 && (!a || lda % 4 == 0) && (!dz || lddz % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0;
+  if (vec4)
+    hipLaunchKernelGGL(epilogue_bwd_vec4_kernel, dim3(nb), dim3(CS_BLOCK), 0, h->stream, npix, C, dy, lddy, a, lda, bn_scale, act, act_alpha,
+                       dz, lddz, partial);
+  else
+    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(nb), dim3(CS_BLOCK), 0, h->stream, npix, C, CP, dy, lddy, a, lda, bn_scale, act, act_alpha,
+                       dz, lddz, partial);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_epilogue_bwd");
   if (dbias || dsum_dy_a || dsum_dy) {
     hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, h->stream, partial, nb, C, dbias, dsum_dy_a, dsum_dy);

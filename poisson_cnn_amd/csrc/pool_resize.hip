@@ -57,17 +57,28 @@ __global__ __launch_bounds__(256) void pool_fwd_large_kernel(int kind, int N, in
   }
 }
 
-__global__ void pool_bwd_avg_kernel(int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx, const float* __restrict__ dy, int lddy,
-                                    float* __restrict__ dx, int lddx, int accumulate) {
-  const int64_t total = (int64_t)N * H * W * C;
+template <int V>   // V channels per thread (4: float4 accesses)
+__global__ __launch_bounds__(256) void pool_bwd_avg_kernel(int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx, const float* __restrict__ dy,
+                                                           int lddy, float* __restrict__ dx, int lddx, int accumulate) {
+  const int CV = C / V;
+  const int64_t total = (int64_t)N * H * W * CV;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = i % C; int64_t r = i / C; const int xx = r % W; r /= W; const int yy = r % H; const int n = r / H;
+    const int c = (int)(i % CV) * V; int64_t r = i / CV; const int xx = r % W; r /= W; const int yy = r % H; const int n = r / H;
     const int oy = (yy + pby) / f, ox = (xx + pbx) / f;
     int y0, y1, x0, x1;
     win(oy, f, pby, H, y0, y1); win(ox, f, pbx, W, x0, x1);
-    const float g = dy[(((int64_t)n * Ho + oy) * Wo + ox) * lddy + c] / (float)((y1 - y0) * (x1 - x0));
-    float* dst = &dx[(((int64_t)n * H + yy) * W + xx) * lddx + c];
-    *dst = accumulate ? *dst + g : g;
+    const float cnt = (float)((y1 - y0) * (x1 - x0));
+    const float* src = dy + (((int64_t)n * Ho + oy) * Wo + ox) * lddy + c;
+    float* dst = dx + (((int64_t)n * H + yy) * W + xx) * lddx + c;
+    if (V == 4) {
+      const float4 g = *reinterpret_cast<const float4*>(src);
+      float4 o = make_float4(g.x / cnt, g.y / cnt, g.z / cnt, g.w / cnt);
+      if (accumulate) { const float4 d = *reinterpret_cast<const float4*>(dst); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+      *reinterpret_cast<float4*>(dst) = o;
+    } else {
+      const float g = *src / cnt;
+      *dst = accumulate ? *dst + g : g;
+    }
   }
 }
 
@@ -256,8 +267,12 @@ extern "C" int pcnn_pool2d_bwd(pcnn_handle h, int kind, int N, int H, int W, int
   (void)y; (void)ldy;
   const int Ho = pcnn_cdiv(H, f), Wo = pcnn_cdiv(W, f), pby = (Ho * f - H) / 2, pbx = (Wo * f - W) / 2;
   if (kind == PCNN_POOL_AVERAGE) {
-    hipLaunchKernelGGL(pool_bwd_avg_kernel, grid1d((int64_t)N * H * W * C), dim3(256), 0, h->stream, N, H, W, C, f, Ho, Wo, pby, pbx, dy, lddy, dx, lddx,
-                       accumulate);
+    if (vec4_ok(C, dy, lddy, dx, lddx))
+      hipLaunchKernelGGL(pool_bwd_avg_kernel<4>, grid1d((int64_t)N * H * W * (C / 4)), dim3(256), 0, h->stream, N, H, W, C, f, Ho, Wo, pby, pbx, dy, lddy, dx,
+                         lddx, accumulate);
+    else
+      hipLaunchKernelGGL(pool_bwd_avg_kernel<1>, grid1d((int64_t)N * H * W * C), dim3(256), 0, h->stream, N, H, W, C, f, Ho, Wo, pby, pbx, dy, lddy, dx, lddx,
+                         accumulate);
   } else {
     PCNN_REQUIRE(h, x, "pcnn_pool2d_bwd: max pooling needs the forward input");
     if (!accumulate) {

@@ -43,6 +43,66 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void probe(const f16x8* __res
   out[blockIdx.x * 256 + tid] = s;
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// same work per iteration as TWO steps of probe<> (K = 32), issued as v_mfma_f32_16x16x32_f16: 2 x 2 blocks of 16 x 16 per M-tile
+template <int LDSR, int GLB, int MT>
+__global__ __launch_bounds__(256, 2) void probe16(const f16x8* __restrict__ w, float* out, int iters, int nsteps_w) {
+  extern __shared__ f16x8 planes[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kg = lane >> 4;
+  for (int i = tid; i < 4096; i += 256) { f16x8 v; for (int j = 0; j < 8; ++j) v[j] = (_Float16)(0.37f * (float)(((i * 8 + j) * 2654435761u >> 20) & 1023) - 180.f); planes[i] = v; }
+  __syncthreads();
+  const f16x8* hi = planes; const f16x8* lo = planes + 2048;
+  f32x4v acc[MT][2][2];
+  for (int m = 0; m < MT; ++m) for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int i = 0; i < 4; ++i) acc[m][a][b][i] = 0.f;
+  f16x8 ah[MT][2], al[MT][2], bh[2], bl[2], nah[MT][2], nal[MT][2], nbh[2], nbl[2];
+  for (int m = 0; m < MT; ++m) for (int a = 0; a < 2; ++a) { ah[m][a] = hi[r16 + 16 * a + m * 46]; al[m][a] = lo[r16 + 16 * a + m * 46]; }
+  const f16x8* wl = w + kg * 16 + r16;
+  for (int b = 0; b < 2; ++b) { bh[b] = wl[b * 64]; bl[b] = wl[64 * nsteps_w + b * 64]; }
+  int tw = 0;
+  for (int t = 0; t < iters / 2; ++t) {
+    if (GLB) { tw = tw + 2 >= nsteps_w ? 0 : tw + 2; for (int b = 0; b < 2; ++b) { nbh[b] = wl[(tw + b) * 64]; nbl[b] = wl[64 * nsteps_w + (tw + b) * 64]; } }
+    else { for (int b = 0; b < 2; ++b) { nbh[b] = bh[b]; nbl[b] = bl[b]; } }
+    const int off = wave * MT * 46 + ((t * 5) & 511) + kg * 3;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (LDSR) { nah[m][a] = hi[r16 + 16 * a + off + m * 46]; nal[m][a] = lo[r16 + 16 * a + off + m * 46]; } else { nah[m][a] = al[m][a]; nal[m][a] = ah[m][a]; }
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          acc[m][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][a], bh[b], acc[m][a][b], 0, 0, 0);
+          acc[m][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][a], bl[b], acc[m][a][b], 0, 0, 0);
+          acc[m][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][a], bh[b], acc[m][a][b], 0, 0, 0);
+        }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) for (int a = 0; a < 2; ++a) { ah[m][a] = nah[m][a]; al[m][a] = nal[m][a]; }
+    for (int b = 0; b < 2; ++b) { bh[b] = nbh[b]; bl[b] = nbl[b]; }
+  }
+  float s = 0.f;
+  for (int m = 0; m < MT; ++m) for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int i = 0; i < 4; ++i) s += acc[m][a][b][i];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int LDSR, int GLB, int MT>
+void run16(const char* name, const f16x8* w, float* out, int nsteps_w) {
+  const int iters = 4000, blocks = 512;
+  hipFuncSetAttribute((const void*)probe16<LDSR, GLB, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    probe16<LDSR, GLB, MT><<<blocks, 256, 65536>>>(w, out, iters, nsteps_w);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)blocks * 4 * iters * (3.0 * MT) * 32 * 32 * 16 * 2;
+    if (rep) printf("%-28s MT=%d: %.3f ms, %.0f TFLOP/s f16 (%.0f fp32-equivalent)  [16x16x32]\n", name, MT, ms, flop / ms / 1e9, flop / ms / 3e9);
+  }
+}
+
 template <int LDSR, int GLB, int MT>
 void run(const char* name, const f16x8* w, float* out, int nsteps_w) {
   const int iters = 4000, blocks = 512;
@@ -78,6 +138,8 @@ int main() {
   run<1, 0, 4>("mfma + lds A", w, out, nsteps_w);
   run<0, 1, 4>("mfma + global B", w, out, nsteps_w);
   run<1, 1, 4>("mfma + lds A + global B", w, out, nsteps_w);
+  run16<0, 0, 4>("mfma only", w, out, nsteps_w);
+  run16<1, 1, 4>("mfma + lds A + global B", w, out, nsteps_w);
   run<0, 0, 8>("mfma only", w, out, nsteps_w);
   run<1, 1, 8>("mfma + lds A + global B", w, out, nsteps_w);
   return 0;
