@@ -130,10 +130,12 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (PMC collection
         # cannot be combined with the timed run); the committed summary is reported for the workload it was measured on.
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_c4_pmc_summary.json')
-        if args.workload == 'c4' and args.math == 'fp32' and os.path.exists(pmc):
+        pmc_name, pmc_key = (('r01_c4_pmc_summary.json', 'conv_fwd<1>') if args.math == 'fp32'
+                             else ('r01_c4_pmc_summary_split.json', 'conv_fwd_split_kernel<1>'))
+        pmc = os.path.join(ROOT, 'profiles', pmc_name)
+        if args.workload == 'c4' and os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f)['kernels']['conv_fwd<1>']['traffic_bytes_per_launch']
+                traffic = json.load(f)['kernels'][pmc_key]['traffic_bytes_per_launch']
         peak = PEAK_FP32_MFMA_TFLOPS if args.math == 'fp32' else PEAK_SPLIT_TFLOPS
         flops, secs, calls = prof.totals('conv_fwd')
         wf, ws_, wc = prof.totals('conv_wgrad')
@@ -148,7 +150,7 @@ def main():
                        'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': args.math, 'final_loss': loss},
             'roofline': {'bound': 'mfma', 'kernel': ('conv_fwd_kernel<1>' if args.math == 'fp32' else 'conv_fwd_split_kernel<1>') + ' (fused pad+conv fwd and data-gradient)', 'achieved': flops / secs / 1e12 if secs else None,
                          'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)', 'frac': flops / secs / 1e12 / peak if secs else None,
-                         'traffic': traffic, 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_c4_pmc_summary.json)', 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,
+                         'traffic': traffic, 'algorithmic_bytes_per_launch': prof.total_bytes('conv_fwd') / calls if calls else None, 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)' % pmc_name, 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,
                          'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / peak if ws_ else None,
                                           'launches': wc, 'avg_launch_ms': 1e3 * ws_ / wc if wc else None}},
         }

@@ -15,6 +15,7 @@
 //   * Epilogue from the accumulators: bias, activation, optional BN affine, optional residual, NHWC store with an
 //     arbitrary channel stride (so a conv can write straight into a channel slice of a concat buffer).
 #include "pcnn_internal.h"
+#include "conv_epilogue.h"
 
 int pcnn_conv2d_fwd_split(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                           const float* bn_shift, const float* residual, float* y, float* act_out);   // conv_fwd_split.hip
@@ -29,7 +30,7 @@ struct ConvParams {
   float* y; float* act_out;
   int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, pt, pl, pad_mode; float pad_value; int act; float alpha;
   int ld_res, ld_act;
-  int tiles_x, tiles_y, CK, PS, vec_ok;
+  int tiles_x, tiles_y, CK, PS, vec_ok, epi_vec;
   const float* wp;   // packed filter, see pack_weights_kernel
 };
 
@@ -38,7 +39,13 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvPara
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int half = lane >> 5, col = lane & 31;
-  int tile = blockIdx.x;
+  // XCD-aware order: workgroup ids go round-robin to the 8 XCDs, so XCD x takes the x-th contiguous eighth of the tiles -
+  // neighbouring tiles (shared halo rows and columns) meet in one L2
+  int tile;
+  {
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+    tile = xcd * per + min(xcd, rem) + (blockIdx.x >> 3);
+  }
   const int tx = tile % p.tiles_x; tile /= p.tiles_x;
   const int ty = tile % p.tiles_y;
   const int n = tile / p.tiles_y;
@@ -166,32 +173,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvPara
     if (s < nsteps) step(b0, b1, false);
   }
 
-  // ---- epilogue
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int co = t * 32 + col;
-    if (co >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[co] : 0.f;
-    const float sc = p.bn_scale ? p.bn_scale[co] : 1.f;
-    const float sh = p.bn_scale ? p.bn_shift[co] : 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oy = y0 + wave * MT + m;
-      if (oy >= p.Ho) continue;
-      const int64_t rowpix = ((int64_t)n * p.Ho + oy) * p.Wo;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ox = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
-        if (ox >= p.Wo) continue;
-        const int64_t pix = rowpix + ox;
-        float v = pcnn_act(tot[m][t][i] + bias, p.act, p.alpha);
-        if (p.act_out) p.act_out[pix * p.ld_act + co] = v;
-        v = v * sc + sh;
-        if (p.res) v += p.res[pix * p.ld_res + co];
-        p.y[pix * p.ldy + co] = v;
-      }
-    }
-  }
+  // ---- epilogue (conv_epilogue.h): staged through the LDS the halo tile no longer needs
+  ConvEpilogue e;
+  e.bias = p.bias; e.bn_scale = p.bn_scale; e.bn_shift = p.bn_shift; e.res = p.res; e.y = p.y; e.act_out = p.act_out;
+  e.Ho = p.Ho; e.Wo = p.Wo; e.Cout = p.Cout; e.ldy = p.ldy; e.ld_res = p.ld_res; e.ld_act = p.ld_act; e.act = p.act; e.alpha = p.alpha;
+  e.vec = p.epi_vec;
+  conv_epilogue_store<MT, NT>(tot, 1.0f, e, n, y0, x0, lds);
 }
 
 // w (kh,kw,Cin,Cout) HWIO -> wp [tap][cin_pad/8][2][NT*32][4], zero padded: wp[...][g][h][co][j] = w[tap][8g + 4h + j][co]
@@ -252,7 +239,8 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
     if ((size_t)TR * TC * ps * 4 <= MAX_LDS_BYTES) { CK = cand; break; }
   }
   p.CK = CK; p.PS = ((CK / 4) % 2 == 0) ? CK + 4 : CK;
-  const size_t lds = (size_t)TR * TC * p.PS * 4;
+  p.epi_vec = conv_epilogue_vec_ok(d->Cout, y, d->ldy, residual, d->ld_res, act_out, d->ld_act_out);
+  const size_t lds = std::max((size_t)TR * TC * p.PS * 4, conv_epilogue_lds_bytes(d->Cout));
   PCNN_REQUIRE(h, lds <= 160 * 1024, "pcnn_conv2d_fwd: halo tile needs %zu B of LDS", lds);
   {
     const int NTh = d->Cout <= 32 ? 1 : 2;

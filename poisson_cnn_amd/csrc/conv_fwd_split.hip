@@ -16,13 +16,15 @@
 //   * one MFMA K-step (16) = 2 filter taps x 8 channels: lanes 0-31 (k = 0..7) read tap 2t, lanes 32-63 tap 2t+1;
 //   * the filter is packed (per call) into matching fp16 hi/lo fragments, scaled by a per-tensor power of two.
 #include "pcnn_internal.h"
+#include "conv_epilogue.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int TH = 16, TW = 32, WAVES = 4, MT = TH / WAVES;
-constexpr int MAXPIX = 6;   // halo pixels per thread per chunk: (16+14)*(32+14)/256 = 5.4 for k = 15
+constexpr int TW = 32, WAVES = 4;   // tile = (WAVES*MT) rows x 32 columns; MT = 4 (16 rows), or 2 for layers with little work per tile
+// halo pixels per thread per chunk: MT = 4: (16+14)*(32+14)/256 = 5.4 for k = 15; MT = 2 (k <= 5): (8+4)*(32+4)/256 = 1.7
+constexpr int max_pix(int MT) { return MT == 2 ? 2 : 6; }
 
 struct SplitParams {
   const float* x; const float* bias; const float* bn_scale; const float* bn_shift; const float* res; float* y; float* act_out;
@@ -30,7 +32,7 @@ struct SplitParams {
   const float* wscale;        // wscale[0] = 1 / s_w
   int64_t wplane;             // f16x8 elements per plane
   int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, pt, pl, pad_mode; float pad_value; int act; float alpha;
-  int ld_res, ld_act, tiles_x, tiles_y, vec_ok;
+  int ld_res, ld_act, tiles_x, tiles_y, vec_ok, epi_vec;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -39,11 +41,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_split_kernel(SplitParams p) {
+// MT = 2 halves the accumulator registers: 4 workgroups per CU instead of 2 hide the load -> convert -> MFMA -> store latency chain
+// of the small layers (3x3 / 5x5, <= 20 channels), whose tiles hold only a few MFMA steps
+template <int NT, int MT>
+__global__ __launch_bounds__(256, NT == 1 ? (MT == 2 ? 4 : 2) : 1) void conv_fwd_split_kernel(SplitParams p) {
+  constexpr int TH = WAVES * MT, MAXPIX = max_pix(MT);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
-  int tile = blockIdx.x;
+  // XCD-aware order: workgroup ids go round-robin to the 8 XCDs, so XCD x takes the x-th contiguous eighth of the tiles -
+  // neighbouring tiles (shared halo rows and columns) meet in one L2
+  int tile;
+  {
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+    tile = xcd * per + min(xcd, rem) + (blockIdx.x >> 3);
+  }
   const int tx = tile % p.tiles_x; tile /= p.tiles_x;
   const int ty = tile % p.tiles_y;
   const int n = tile / p.tiles_y;
@@ -187,32 +198,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_split_kernel(Sp
         for (int i = 0; i < 16; ++i) { tot[m][t][i] = fmaf(acc[m][t][i], inv_s, tot[m][t][i]); acc[m][t][i] = 0.f; }
   }
 
-  // ---- epilogue (same as conv_fwd.hip)
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int co = t * 32 + col;
-    if (co >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[co] : 0.f;
-    const float sc = p.bn_scale ? p.bn_scale[co] : 1.f;
-    const float sh = p.bn_scale ? p.bn_shift[co] : 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oy = y0 + wave * MT + m;
-      if (oy >= p.Ho) continue;
-      const int64_t rowpix = ((int64_t)n * p.Ho + oy) * p.Wo;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ox = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
-        if (ox >= p.Wo) continue;
-        const int64_t pix = rowpix + ox;
-        float v = pcnn_act(tot[m][t][i] * inv_sw + bias, p.act, p.alpha);
-        if (p.act_out) p.act_out[pix * p.ld_act + co] = v;
-        v = v * sc + sh;
-        if (p.res) v += p.res[pix * p.ld_res + co];
-        p.y[pix * p.ldy + co] = v;
-      }
-    }
-  }
+  // ---- epilogue (conv_epilogue.h): staged through the LDS the planes no longer need
+  ConvEpilogue e;
+  e.bias = p.bias; e.bn_scale = p.bn_scale; e.bn_shift = p.bn_shift; e.res = p.res; e.y = p.y; e.act_out = p.act_out;
+  e.Ho = p.Ho; e.Wo = p.Wo; e.Cout = p.Cout; e.ldy = p.ldy; e.ld_res = p.ld_res; e.ld_act = p.ld_act; e.act = p.act; e.alpha = p.alpha;
+  e.vec = p.epi_vec;
+  conv_epilogue_store<MT, NT>(tot, inv_sw, e, n, y0, x0, reinterpret_cast<float*>(smem));
 }
 
 // per-tensor power-of-two scale of the filter: out[0] = 1/s, out[1] = s with max|w|*s in [2^12, 2^13)
@@ -256,10 +247,13 @@ __global__ void pack_split_kernel(const float* __restrict__ w, const float* __re
 int pcnn_conv2d_fwd_split(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                           const float* bn_shift, const float* residual, float* y, float* act_out) {
   if (d->kh > 15 || d->kw > 15 || d->Cout > 64) return -1;
-  const int TR = TH + d->kh - 1, TC = TW + d->kw - 1;
-  if (TR * TC > 256 * MAXPIX) return -1;
   const int NT = d->Cout <= 32 ? 1 : 2;
   const int cin_pad = (d->Cin + 7) & ~7, ng = cin_pad >> 3, T = d->kh * d->kw, nT2 = (T + 1) >> 1;
+  static const int mt2_max_k = getenv("PCNN_SPLIT_MT2_MAXK") ? atoi(getenv("PCNN_SPLIT_MT2_MAXK")) : 640;
+  const int MTsel = (NT == 1 && T * cin_pad <= mt2_max_k && (2 * WAVES + d->kh - 1) * (TW + d->kw - 1) <= 256 * max_pix(2)) ? 2 : 4;       // 8-row tiles for layers with few MFMA steps per tile
+  const int TH = WAVES * MTsel;
+  const int TR = TH + d->kh - 1, TC = TW + d->kw - 1;
+  if (TR * TC > 256 * max_pix(MTsel)) return -1;
   const int64_t plane_halfs = ((int64_t)ng * nT2 + 4) * 2 * NT * 32 * 8;       // + spare steps for the prefetch past the end
   const size_t need = 256 + (size_t)plane_halfs * 2 * sizeof(_Float16);
   if (h->scratch_bytes < need) {
@@ -284,15 +278,19 @@ int pcnn_conv2d_fwd_split(pcnn_handle h, const pcnn_conv_desc* d, const float* x
   p.act = d->act; p.alpha = d->act_alpha; p.ld_res = d->ld_res; p.ld_act = d->ld_act_out;
   p.tiles_x = pcnn_cdiv(d->Wo, TW); p.tiles_y = pcnn_cdiv(d->Ho, TH);
   p.vec_ok = (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  const size_t lds = (size_t)TR * TC * 32 + 64;
+  p.epi_vec = conv_epilogue_vec_ok(d->Cout, y, d->ldy, residual, d->ld_res, act_out, d->ld_act_out);
+  const size_t lds = std::max((size_t)TR * TC * 32 + 64, conv_epilogue_lds_bytes(d->Cout));
   const int64_t nblk = (int64_t)d->N * p.tiles_x * p.tiles_y;
   if (nblk >= (1ll << 31)) return -1;
-  if (NT == 1) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(conv_fwd_split_kernel<1>, dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
+  if (NT == 1 && MTsel == 2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_fwd_split_kernel<1, 2>), dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
+  } else if (NT == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_fwd_split_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(conv_fwd_split_kernel<2>, dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_split_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_fwd_split_kernel<2, 4>), dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
   }
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_fwd(split)");
   return 0;

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 // channels padded to multiples of 4 (Cip, Cop) and in its channel order (channel 4q + j of a pixel at position j*Cp/4 + q).
 // nel counts the partials' elements (kh*kw*Cip*Cop), dw is dense [kh*kw][Cin][Cout].
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t nel, int S, const unsigned* __restrict__ maxbits,
-                                    int Cin, int Cout, int Cip, int Cop) {
+                                    int Cin, int Cout, int Cip, int Cop, int SL) {
   float rs = 1.f;
   if (maxbits) {
     int ex = 0, ez = 0;
@@ -283,7 +283,24 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     rs = (okx ? ldexpf(1.0f, ex - 13) : 1.0f) * (okz ? ldexpf(1.0f, ez - 13) : 1.0f);
   }
   const int GX = Cip >> 2, GZ = Cop >> 2;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nel; e += (int64_t)gridDim.x * blockDim.x) {
+  // SL slices of the split index per element (fixed summation tree): small filters would otherwise leave the chip to a handful
+  // of threads walking hundreds of partials each
+  __shared__ float red[256];
+  const int EL = 256 / SL;                       // elements per workgroup
+  const int le = threadIdx.x % EL, sl = threadIdx.x / EL;
+  for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < nel; e0 += (int64_t)gridDim.x * EL) {
+    const int64_t e = e0 + le;
+    float s = 0.f;
+    if (e < nel)
+      for (int k = sl; k < S; k += SL) s += ws[(int64_t)k * nel + e];
+    if (SL > 1) {
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (sl == 0)
+        for (int q = 1; q < SL; ++q) s += red[q * EL + le];
+      __syncthreads();
+    }
+    if (sl != 0 || e >= nel) continue;
     int64_t o = e;
     if (maxbits) {
       const int pz = (int)(e % Cop); const int64_t t = e / Cop;
@@ -292,8 +309,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
       if (ci >= Cin || co >= Cout) continue;
       o = (tap * Cin + ci) * Cout + co;
     }
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += ws[(int64_t)k * nel + e];
     dw[o] = s * rs;
   }
 }
@@ -336,12 +351,14 @@ __device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
 
 struct SplitPlanes {
   const float* src[2]; _Float16* hi[2]; _Float16* lo[2];
-  int64_t nquad[2]; int cq[2]; int C[2]; int ld[2]; int vec[2];     // quads in total, quads per pixel, channels, source channel stride, float4-loadable
+  int64_t nquad[2]; int cq[2]; int C[2]; int ld[2]; int vec[2];     // quads in total, quads per pixel, channels, source channel stride, 1 = float4-loadable, 2 = and dense
   unsigned* maxbits;
 };
 
 // channels 4q .. 4q+3 of one pixel; channels past C read as zero (the planes are padded to a multiple of 4 channels)
-__device__ __forceinline__ f32x4 load_quad(const float* __restrict__ src, int64_t pix, int ch, int C, int ld, int vec) {
+__device__ __forceinline__ f32x4 load_quad(const float* __restrict__ src, int64_t qi, int cq, int C, int ld, int vec) {
+  if (vec == 2) return reinterpret_cast<const f32x4*>(src)[qi];      // dense tensor: quad qi is the qi-th float4, no index arithmetic
+  const int64_t pix = qi / cq; const int ch = (int)(qi - pix * cq) << 2;
   const float* q = src + pix * ld + ch;
   if (vec) return *reinterpret_cast<const f32x4*>(q);
   f32x4 v;
@@ -363,8 +380,7 @@ __global__ __launch_bounds__(256) void split_absmax_kernel(SplitPlanes sp) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t q = q0 + u * stride < nq ? q0 + u * stride : q0;
-      const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
-      v[u] = load_quad(src, pix, ch, C, ld, vec);
+      v[u] = load_quad(src, q, cq, C, ld, vec);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
@@ -394,8 +410,7 @@ __global__ __launch_bounds__(256) void split_convert_kernel(SplitPlanes sp) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t q = q0 + u * stride < nq ? q0 + u * stride : q0;
-      const int64_t pix = q / cq; const int ch = (int)(q - pix * cq) << 2;
-      v[u] = load_quad(src, pix, ch, C, ld, vec);
+      v[u] = load_quad(src, q, cq, C, ld, vec);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -672,7 +687,7 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
     pp.hi[0] = planes; pp.lo[0] = planes + plane_elems_x(&pd);
     pp.hi[1] = pp.lo[0] + plane_elems_x(&pd); pp.lo[1] = pp.hi[1] + plane_elems_z(&pd);
     pp.cq[0] = pd.Cin >> 2; pp.cq[1] = pd.Cout >> 2; pp.C[0] = d->Cin; pp.C[1] = d->Cout; pp.ld[0] = d->ldx; pp.ld[1] = d->ldy;
-    pp.vec[0] = p.vecx; pp.vec[1] = p.vecdz;
+    pp.vec[0] = p.vecx ? (d->ldx == d->Cin ? 2 : 1) : 0; pp.vec[1] = p.vecdz ? (d->ldy == d->Cout ? 2 : 1) : 0;   // 2 = dense
     pp.nquad[0] = (int64_t)d->N * d->H * d->W * pp.cq[0]; pp.nquad[1] = (int64_t)d->N * d->Ho * d->Wo * pp.cq[1];
     (void)hipMemsetAsync(pp.maxbits, 0, 8, h->stream);
     const int64_t nq = std::max(pp.nquad[0], pp.nquad[1]);
@@ -695,9 +710,10 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
 #undef PCNN_WG
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad");
   const int64_t nel = (int64_t)d->kh * d->kw * ud->Cin * ud->Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(nel, 256), 2048)), dim3(256), 0, h->stream,
+  const int SL = nel >= 65536 ? 1 : (nel >= 8192 ? 4 : 16);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(nel, 256 / SL), 2048)), dim3(256), 0, h->stream,
                      p.ws, dw, nel, pl.S, split_ok ? reinterpret_cast<const unsigned*>(static_cast<char*>(workspace) + partials_bytes(&pd, pl)) : nullptr,
-                     d->Cin, d->Cout, ud->Cin, ud->Cout);
+                     d->Cin, d->Cout, ud->Cin, ud->Cout, SL);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(reduce)");
   return 0;
 }

@@ -110,14 +110,17 @@ class KernelTimer:
     MFMA kernels, with the algorithmic FLOP count of each launch."""
 
     def __init__(self):
-        self.records = []   # (kind, flops, start_event, end_event)
+        self.records = []   # (kind, flops, start_event, end_event, algorithmic bytes)
 
-    def launch(self, kind, flops, fn):
+    def launch(self, kind, flops, fn, nbytes=0.0):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.records.append((kind, flops, s, e))
+        self.records.append((kind, flops, s, e, nbytes))
+
+    def total_bytes(self, kind):
+        return sum(r[4] for r in self.records if r[0] == kind)
 
     def totals(self, kind):
         torch.cuda.synchronize()
@@ -133,11 +136,11 @@ def set_kernel_timer(t):
     _timer = t
 
 
-def _launch(kind, flops, fn):
+def _launch(kind, flops, fn, nbytes=0.0):
     if _timer is None:
         fn()
     else:
-        _timer.launch(kind, flops, fn)
+        _timer.launch(kind, flops, fn, nbytes)
 
 
 # ----------------------------------------------------------------------------- convolution
@@ -160,7 +163,8 @@ def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CON
     d = conv_desc(x.shape, _ld(x), w.shape, (Ho, Wo), _ld(out), pad_top, pad_left, pad_mode, pad_value, act,
                   _ld(residual) if residual is not None else 0, _ld(act_out) if act_out is not None else 0)
     _launch('conv_fwd', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout,
-            lambda: handle().call('pcnn_conv2d_fwd', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out)))
+            lambda: handle().call('pcnn_conv2d_fwd', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out)),
+            4.0 * (N * H * W * Cin + N * Ho * Wo * Cout * (1 + (residual is not None) + (act_out is not None)) + kh * kw * Cin * Cout))
     return out
 
 
