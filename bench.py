@@ -130,12 +130,12 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (PMC collection
         # cannot be combined with the timed run); the committed summary is reported for the workload it was measured on.
         traffic = None
-        pmc_name, pmc_key = (('r01_c4_pmc_summary.json', 'conv_fwd<1>') if args.math == 'fp32'
-                             else ('r01_c4_pmc_summary_split.json', 'conv_fwd_split_kernel<1>'))
+        pmc_name = 'r01_c4_pmc_summary.json' if args.math == 'fp32' else 'r01_c4_pmc_summary_split.json'
         pmc = os.path.join(ROOT, 'profiles', pmc_name)
         if args.workload == 'c4' and os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f)['kernels'][pmc_key]['traffic_bytes_per_launch']
+                ks = [v for k, v in json.load(f)['kernels'].items() if k.startswith('conv_fwd')]   # all tile variants = all 'conv_fwd' launches
+            traffic = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in ks) / max(sum(v['launches'] for v in ks), 1)
         peak = PEAK_FP32_MFMA_TFLOPS if args.math == 'fp32' else PEAK_SPLIT_TFLOPS
         flops, secs, calls = prof.totals('conv_fwd')
         wf, ws_, wc = prof.totals('conv_wgrad')
@@ -148,7 +148,7 @@ def main():
             'config': {'workload': '%s: Homogeneous_Poisson_NN_Legacy(hpnn.json) full train step (fwd+bwd+loss+Adam%s), %d x %dx%d Dirichlet grids per GPU'
                                    % (args.workload, '+RCCL all-reduce' if dp.world_size > 1 else '', per_gpu, H, W),
                        'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': args.math, 'final_loss': loss},
-            'roofline': {'bound': 'mfma', 'kernel': ('conv_fwd_kernel<1>' if args.math == 'fp32' else 'conv_fwd_split_kernel<1>') + ' (fused pad+conv fwd and data-gradient)', 'achieved': flops / secs / 1e12 if secs else None,
+            'roofline': {'bound': 'mfma', 'kernel': ('conv_fwd_kernel' if args.math == 'fp32' else 'conv_fwd_split_kernel') + ' (fused pad+conv fwd and data-gradient; all launches of a step)', 'achieved': flops / secs / 1e12 if secs else None,
                          'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)', 'frac': flops / secs / 1e12 / peak if secs else None,
                          'traffic': traffic, 'algorithmic_bytes_per_launch': prof.total_bytes('conv_fwd') / calls if calls else None, 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)' % pmc_name, 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,
                          'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / peak if ws_ else None,

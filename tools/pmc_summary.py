@@ -15,7 +15,7 @@ def per_kernel(path, counter):
         if r['Counter_Name'] != counter:
             continue
         n = r['Kernel_Name']
-        m = re.search(r'(conv_fwd_split_kernel<\d>|conv_fwd_kernel<\d>|wgrad_split_kernel|wgrad_kernel|split_convert_kernel|split_absmax_kernel|epilogue_bwd\w*)', n)
+        m = re.search(r'(conv_fwd_split_kernel<\d, \d>|conv_fwd_kernel<\d>|wgrad_split_kernel|wgrad_kernel|split_convert_kernel|split_absmax_kernel|epilogue_bwd\w*)', n)
         if m:
             acc[m.group(1)].append(float(r['Counter_Value']) * 1024.0)
     return acc
