@@ -232,6 +232,28 @@ int pcnn_set_max_magnitude(pcnn_handle h, int N, int64_t per, const float* targe
 /* x[n,:] *= s[n] */
 int pcnn_scale_samples(pcnn_handle h, int N, int64_t per, const float* s, float* x);
 
+/* ---- Dirichlet_BC_NN_Legacy_2 / Poisson_CNN_Legacy (kernels in csrc/dbcnn.hip) ------------------------------ */
+/* out[n,y,0:3] = {bc[n,y], 1, cos(pi y/(L-1))}: the boundary input with its positional embeddings
+ * (models/Dirichlet_BC_NN_Legacy.py:113-124,136-139); 1-D tensors are NHWC with H = 1 */
+int pcnn_dbc_assemble_input(pcnn_handle h, int N, int L, const float* bc, float* out, int ldo);
+/* Spatial pyramid AVERAGE pool over channels and spatial bins (layers/SpatialPyramidPool.py:10-11,35-66); bins as pcnn_spp_max_fwd */
+int pcnn_spp_avg_fwd(pcnn_handle h, int N, int H, int W, int C, int ldx, int nb, const int32_t* bins, const float* x, float* out);
+int pcnn_spp_avg_bwd(pcnn_handle h, int N, int H, int W, int C, int lddx, int nb, const int32_t* bins, const float* dout, float* dx);
+/* tf.einsum('bmy,mx,bm->bmxy', f, sinh_table, d) written as NHWC (N,X,L,M+2) with the two positional-embedding channels
+ * cos(pi x/(X-1)), cos(pi y/(L-1)) appended (models/Dirichlet_BC_NN_Legacy.py:150-156).  f: (N,L,M) stride ldf; sinh_table (M,X); d (N,M) */
+int pcnn_dbc_expand_fwd(pcnn_handle h, int N, int X, int L, int M, const float* f, int ldf, const float* sinh_table, const float* d, float* out, int ldo);
+size_t pcnn_dbc_expand_bwd_workspace(int N, int L, int M);
+int pcnn_dbc_expand_bwd(pcnn_handle h, int N, int X, int L, int M, const float* dout, int lddo, const float* f, int ldf, const float* sinh_table,
+                        const float* d, float* df, int lddf, float* dd, void* workspace, size_t workspace_bytes);
+/* adjoint of pcnn_set_max_magnitude (dataset/utils/set_max_magnitude.py:14-25 inside a GradientTape): x = the UNSCALED input */
+int pcnn_set_max_magnitude_bwd(pcnn_handle h, int N, int64_t per, const float* target, const float* x, const float* dy, float* dx);
+/* y[n,0,:] = bc[n,:] (bc == NULL: zeros = the adjoint): tf.concat([expand_dims(bc), out[...,1:,:]], 2) (models/Dirichlet_BC_NN_Legacy.py:164) */
+int pcnn_set_first_row(pcnn_handle h, int N, int X, int L, const float* bc, float* y);
+/* flip_and_rotate_tensor for (N,H,W) fields (dataset/utils/flip_and_rotate_tensor.py:4-47): out = reverse(transpose?(in)) along the flagged
+ * axes, scaled per sample by alpha[n] (NULL = 1) and optionally accumulated into out (the five-term sum of models/Poisson_CNN_Legacy.py:48) */
+int pcnn_flip_rotate(pcnn_handle h, int N, int Ho, int Wo, int transpose, int flip_y, int flip_x, const float* in, const float* alpha,
+                     int accumulate, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -339,3 +339,28 @@ def concat(xs, axis):
 
 def asarray(x):
     return np.asarray(x, dtype=np.float64)
+
+
+# ---- additions for Dirichlet_BC_NN_Legacy_2 / Poisson_CNN_Legacy (oracle/dbcnn.py)
+def einsum(eq, *xs):
+    return np.einsum(eq, *[np.asarray(x, dtype=np.float64) for x in xs])
+
+
+def set_max_magnitude_in_batch(x, target=1.0, return_factors=False):
+    """dataset/utils/set_max_magnitude.py:4-50: per sample, x * target / max|x|."""
+    x = np.asarray(x, dtype=np.float64)
+    f = target / np.abs(x.reshape(x.shape[0], -1)).max(axis=1)
+    y = x * f.reshape((-1,) + (1,) * (x.ndim - 1))
+    return (y, f) if return_factors else y
+
+
+def flip(x, axes):
+    return np.flip(x, axis=tuple(axes)) if len(axes) else x
+
+
+def transpose(x, perm):
+    return np.transpose(x, perm)
+
+
+def zeros_like(x):
+    return np.zeros_like(x)

@@ -173,3 +173,26 @@ def jacobi_iterations(guess, rhs, dx, n_iterations, stencil_sizes=(3, 3), orders
         mask[:, :, py:-py, px:-px] = 1.0
         x = x * (1 - mask) + F.pad(inner, (px, px, py, py))
     return x
+
+
+# ---- additions for Dirichlet_BC_NN_Legacy_2 / Poisson_CNN_Legacy (oracle/dbcnn.py)
+def einsum(eq, *xs):
+    return torch.einsum(eq, *[asarray(x) for x in xs])
+
+
+def set_max_magnitude_in_batch(x, target=1.0, return_factors=False):
+    f = target / x.reshape(x.shape[0], -1).abs().amax(dim=1)      # amax splits its gradient evenly over ties, like tf.reduce_max
+    y = x * f.reshape((-1,) + (1,) * (x.dim() - 1))
+    return (y, f) if return_factors else y
+
+
+def flip(x, axes):
+    return torch.flip(x, dims=tuple(axes)) if len(axes) else x
+
+
+def transpose(x, perm):
+    return x.permute(*perm)
+
+
+def zeros_like(x):
+    return torch.zeros_like(x)

@@ -35,7 +35,8 @@ def load():
     lib.pcnn_last_error.restype = c_char_p
     lib.pcnn_last_error.argtypes = [c_void_p]
     lib.pcnn_create.argtypes = [c_int, c_void_p, POINTER(c_void_p)]
-    for name in ('pcnn_conv2d_wgrad_workspace', 'pcnn_colsum_workspace', 'pcnn_deconv_wgrad_workspace', 'pcnn_channel_scale_workspace'):
+    for name in ('pcnn_conv2d_wgrad_workspace', 'pcnn_colsum_workspace', 'pcnn_deconv_wgrad_workspace', 'pcnn_channel_scale_workspace',
+                 'pcnn_dbc_expand_bwd_workspace'):
         if hasattr(lib, name):
             getattr(lib, name).restype = c_size_t
     _lib = lib

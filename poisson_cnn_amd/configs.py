@@ -84,3 +84,37 @@ def load_config(path):
 def dump_config(cfg, path):
     with open(path, 'w') as f:
         json.dump(copy.deepcopy(cfg), f, indent=2)
+
+
+def dbcnn():
+    """experiments/dbcnn.json (Dirichlet_BC_NN_Legacy_2)."""
+    model = {
+        'data_format': 'channels_first', 'use_batchnorm': True,
+        'boundary_conv_config': {'filters': [2, 4, 6, 8, 12, 16, 24, 27], 'kernel_sizes': [19, 17, 15, 13, 11, 9, 7, 5], 'padding_mode': 'symmetric',
+                                 'activation': 'tf.nn.leaky_relu', 'use_bias': True, 'bias_initializer': 'zeros'},
+        'spp_config': {'levels': [2, 3, 4, 5, 8, 11, 15, 30, 45], 'pooling_type': 'average'},
+        'domain_info_mlp_config': {'units': [512, 256, 27], 'activations': ['tanh', 'tanh', 'tanh']},
+        'final_convolutions_config': {'filters': [23, 19, 15, 11, 7, 5, 3, 1], 'kernel_sizes': [7, 7, 5, 5, 5, 3, 3, 3], 'padding_mode': 'CONSTANT',
+                                      'constant_padding_value': 0.0, 'activation': 'tf.nn.tanh', 'use_bias': True, 'bias_initializer': 'zeros'},
+        'postsmoother_iterations': 0}
+    dataset = {'batch_size': 50, 'batches_per_epoch': 200, 'random_output_shape_range': [[192, 384], [192, 384]], 'random_dx_range': [5e-3, 5e-2],
+               'solver_method': 'multigrid', 'boundary_random_smoothness_range': {'left': [3, 8], 'right': [3, 8], 'top': [3, 8], 'bottom': [3, 8]}}
+    training = {'n_epochs': 200, 'precision': 'float32', 'optimizer': 'adam', 'optimizer_parameters': {'learning_rate': 1e-4, 'amsgrad': False},
+                'min_learning_rate': 1e-7,
+                'loss_parameters': {'ndims': 2, 'data_format': 'channels_first', 'mae_loss_weight': 1.0, 'integral_loss_weight': 0.4,
+                                    'integral_loss_config': {'n_quadpts': 47, 'Lp_norm_power': 2}, 'physics_informed_loss_weight': 0.0,
+                                    'physics_informed_loss_config': {'stencil_sizes': [5, 5], 'orders': 2, 'normalize': False},
+                                    'scale_sample_loss_by_target_peak_magnitude': False}}
+    return {'model': model, 'dataset': dataset, 'training': training}
+
+
+def dbcnn_tiny():
+    """Same structure as dbcnn() with few, narrow stages: unit tests and __graft_entry__.smoke()."""
+    cfg = dbcnn()
+    m = cfg['model']
+    m['boundary_conv_config'].update(filters=[2, 4, 6], kernel_sizes=[7, 5, 3])
+    m['spp_config']['levels'] = [2, 3, 5]
+    m['domain_info_mlp_config'] = {'units': [16, 6], 'activations': ['tanh', 'tanh']}
+    m['final_convolutions_config'].update(filters=[5, 3, 1], kernel_sizes=[3, 3, 3])
+    cfg['training']['loss_parameters']['integral_loss_config']['n_quadpts'] = 11
+    return cfg

@@ -134,16 +134,21 @@ class ConvUnit:
 
     def __init__(self, store, ctx, name, k, cin, cout, *, pad='advanced', padding_mode='CONSTANT', pad_value=0.0, activation='linear',
                  use_bias=True, bn_name=None):
+        """k: int (square kernel) or (kh, kw); a Conv1D of the reference is a (1, k) kernel on an (N, 1, L, C) tensor."""
         self.store, self.ctx, self.name = store, ctx, name
-        self.k, self.cin, self.cout = int(k), int(cin), int(cout)
-        self.pads = advanced_pad_amounts(self.k) if pad == 'advanced' else same_pad_amounts(self.k)
+        self.kh, self.kw = (int(k), int(k)) if np.isscalar(k) else (int(k[0]), int(k[1]))
+        self.k = self.kw
+        self.cin, self.cout = int(cin), int(cout)
+        amounts = advanced_pad_amounts if pad == 'advanced' else same_pad_amounts
+        self.pads_y, self.pads_x = amounts(self.kh), amounts(self.kw)
+        self.pads = self.pads_x
         self.mode = padding_mode.upper() if pad == 'advanced' else 'CONSTANT'
         if self.mode not in ops.PAD_MODES:
             raise ValueError('unknown padding mode ' + padding_mode)
         self.pad_value = float(pad_value) if pad == 'advanced' else 0.0
         self.act = canonical_activation(activation)
         self.use_bias = use_bias
-        store.add(name + '/kernel', (self.k, self.k, self.cin, self.cout), 'glorot')
+        store.add(name + '/kernel', (self.kh, self.kw, self.cin, self.cout), 'glorot')
         if use_bias:
             store.add(name + '/bias', (self.cout,), 'zeros')
         self.bn_name = bn_name
@@ -167,7 +172,7 @@ class ConvUnit:
         if self.bn_name is not None and training and getattr(self.store, 'bn_training', False):
             # training-mode BatchNormalization: batch statistics need the whole activation first (two passes)
             a = ops.empty((N, H, W, self.cout), x.device)
-            ops.conv2d_fwd(x, w, b, pad_top=self.pads[0], pad_left=self.pads[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act, out=a)
+            ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act, out=a)
             sw = self.store.w
             _, stats = ops.bn_train_forward(a, sw[self.bn_name + '/gamma'], sw[self.bn_name + '/beta'], sw[self.bn_name + '/moving_mean'],
                                             sw[self.bn_name + '/moving_variance'], residual=residual, out=out, ws=self.ctx.ws)
@@ -175,7 +180,7 @@ class ConvUnit:
             return out
         need_a = training and (sc is not None or residual is not None)
         a = ops.empty((N, H, W, self.cout), x.device) if need_a else None
-        ops.conv2d_fwd(x, w, b, pad_top=self.pads[0], pad_left=self.pads[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
+        ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
                        bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a)
         if training:
             self.saved = (x, a if a is not None else out, None)   # without BN/residual the output itself is the activation
@@ -203,16 +208,16 @@ class ConvUnit:
             if trivial:
                 dz = dy
         w = s.w[self.name + '/kernel']
-        ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads[0], pad_left=self.pads[0], pad_mode=self.mode, pad_value=self.pad_value,
+        ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
                          out=g[self.name + '/kernel'], ws=self.ctx.ws)
         if not need_dx:
             return None
-        k = self.k
-        wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((k, k, self.cout, self.cin), w.device))
+        kh, kw = self.kh, self.kw
+        wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
         if self.mode == 'CONSTANT':
-            return ops.conv2d_fwd(dz, wf, None, pad_top=k - 1 - self.pads[0], pad_left=k - 1 - self.pads[0])
-        gp = ops.conv2d_fwd(dz, wf, None, pad_top=k - 1, pad_left=k - 1, out_hw=(H + k - 1, W + k - 1))
-        return ops.pad_fold_bwd(gp, (H, W), (self.pads, self.pads), self.mode)
+            return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0])
+        gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1))
+        return ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode)
 
 
 class resnet:

@@ -43,7 +43,96 @@ def _as_device(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
-class Homogeneous_Poisson_NN_Legacy:
+class _ModelBase:
+    """What the three model classes share: the Keras-style weight API over a ParamStore, compile(), fit()."""
+    model_name = 'model'
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def trainable_variables(self):
+        return [self.store.w[n] for n in self.store.trainable_names()]
+
+    @property
+    def weight_names(self):
+        return self.store.names
+
+    def get_weights(self):
+        return [self.store.w[n].detach().cpu().numpy().copy() for n in self.store.names]
+
+    def set_weights(self, weights):
+        if isinstance(weights, dict):
+            missing = set(self.store.names) - set(weights)
+            if missing:
+                raise ValueError('missing weights: %s' % sorted(missing)[:5])
+            weights = [weights[n] for n in self.store.names]
+        if len(weights) != len(self.store.names):
+            raise ValueError('expected %d weight arrays, got %d' % (len(self.store.names), len(weights)))
+        for n, v in zip(self.store.names, weights):
+            v = np.asarray(v, dtype=np.float32)
+            if tuple(v.shape) != tuple(self.store.w[n].shape):
+                raise ValueError('shape mismatch for %s: %s vs %s' % (n, v.shape, tuple(self.store.w[n].shape)))
+            self.store.w[n].copy_(torch.from_numpy(v))
+
+    def save_weights(self, path):
+        np.savez(path, **{n.replace('/', '.'): w for n, w in zip(self.store.names, self.get_weights())})
+
+    def load_weights(self, path):
+        with np.load(path if str(path).endswith('.npz') else str(path) + '.npz') as z:
+            self.set_weights({n: z[n.replace('/', '.')] for n in self.store.names})
+
+    def count_params(self):
+        return self.store.n_trainable
+
+    def summary(self, print_fn=print):
+        print_fn('%s (MI355X / libpcnn)' % self.model_name)
+        for name, shape, _, kind in self.store.specs:
+            print_fn('  %-44s %-20s %s' % (name, shape, 'trainable' if kind in ('w', 'bn_gamma', 'bn_beta') else 'non-trainable'))
+        print_fn('Trainable params: %d' % self.store.n_trainable)
+
+    def __call__(self, inp, training=False):
+        return self.call(inp, training=training)
+
+    def compile(self, loss, optimizer):
+        self.optimizer = optimizer
+        self.loss_fn = loss
+        optimizer.bind(self.store)
+
+    def fit(self, dataset, epochs=1, callbacks=(), verbose=1, steps_per_epoch=None):
+        """Minimal Keras-style loop over a Sequence-like dataset (`__len__`, `__getitem__` -> ([rhs, dx], soln))."""
+        history = {'loss': [], 'mse': [], 'lr': []}
+        self.stop_training = False
+        for cb in callbacks:
+            cb.set_model(self)
+        for epoch in range(epochs):
+            n = steps_per_epoch if steps_per_epoch is not None else len(dataset)
+            agg = {'loss': 0.0, 'mse': 0.0}
+            for step in range(n):
+                inp, tar = dataset[step]
+                logs = self.train_step((tuple(inp), tar))
+                logs = {k: (float(v) if not isinstance(v, float) else v) for k, v in logs.items()}
+                for k in agg:
+                    agg[k] += logs[k]
+                for cb in callbacks:
+                    cb.on_batch_end(step, logs)
+                if self.stop_training:
+                    break
+            logs = {'loss': agg['loss'] / max(step + 1, 1), 'mse': agg['mse'] / max(step + 1, 1), 'lr': self.optimizer.learning_rate}
+            for k in history:
+                history[k].append(logs[k])
+            if verbose:
+                print('Epoch %d/%d - loss: %.6g - mse: %.6g - lr: %.3g' % (epoch + 1, epochs, logs['loss'], logs['mse'], logs['lr']), flush=True)
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+            if hasattr(dataset, 'on_epoch_end'):
+                dataset.on_epoch_end()
+            if self.stop_training:
+                break
+        return history
+
+
+class Homogeneous_Poisson_NN_Legacy(_ModelBase):
+    model_name = 'Homogeneous_Poisson_NN_Legacy'
+
     def __init__(self, data_format='channels_first', final_convolutions_config=None, pre_bottleneck_convolutions_config=None,
                  bottleneck_deconv_config=None, bottleneck_multilinear_config=None, input_normalization=None, output_scaling=None,
                  use_batchnorm=False, postsmoother_iterations=5, use_scaling=False, use_positional_embeddings=True, scaling_config=None,
@@ -144,52 +233,7 @@ class Homogeneous_Poisson_NN_Legacy:
         self.grad_sync = None    # set by parallel.DataParallel: called with the flat gradient bucket before the optimizer step
         self._acc = None
 
-    # ------------------------------------------------------------------ weights
-    @property
-    def trainable_variables(self):
-        return [self.store.w[n] for n in self.store.trainable_names()]
-
-    @property
-    def weight_names(self):
-        return self.store.names
-
-    def get_weights(self):
-        return [self.store.w[n].detach().cpu().numpy().copy() for n in self.store.names]
-
-    def set_weights(self, weights):
-        if isinstance(weights, dict):
-            missing = set(self.store.names) - set(weights)
-            if missing:
-                raise ValueError('missing weights: %s' % sorted(missing)[:5])
-            weights = [weights[n] for n in self.store.names]
-        if len(weights) != len(self.store.names):
-            raise ValueError('expected %d weight arrays, got %d' % (len(self.store.names), len(weights)))
-        for n, v in zip(self.store.names, weights):
-            v = np.asarray(v, dtype=np.float32)
-            if tuple(v.shape) != tuple(self.store.w[n].shape):
-                raise ValueError('shape mismatch for %s: %s vs %s' % (n, v.shape, tuple(self.store.w[n].shape)))
-            self.store.w[n].copy_(torch.from_numpy(v))
-
-    def save_weights(self, path):
-        np.savez(path, **{n.replace('/', '.'): w for n, w in zip(self.store.names, self.get_weights())})
-
-    def load_weights(self, path):
-        with np.load(path if str(path).endswith('.npz') else str(path) + '.npz') as z:
-            self.set_weights({n: z[n.replace('/', '.')] for n in self.store.names})
-
-    def count_params(self):
-        return self.store.n_trainable
-
-    def summary(self, print_fn=print):
-        print_fn('Homogeneous_Poisson_NN_Legacy (MI355X / libpcnn)')
-        for name, shape, _, kind in self.store.specs:
-            print_fn('  %-44s %-20s %s' % (name, shape, 'trainable' if kind in ('w', 'bn_gamma', 'bn_beta') else 'non-trainable'))
-        print_fn('Trainable params: %d' % self.store.n_trainable)
-
     # ------------------------------------------------------------------ forward
-    def __call__(self, inp, training=False):
-        return self.call(inp, training=training)
-
     def call(self, inp, training=False):
         """reference :183-257.  inp = [rhs (N,1,H,W), dx (N,1)]; returns (N,1,H,W) (torch CUDA tensor)."""
         rhs, dx = inp
@@ -268,11 +312,6 @@ class Homogeneous_Poisson_NN_Legacy:
         self.store.finish_bn_grads()
 
     # ------------------------------------------------------------------ training (reference :259-296)
-    def compile(self, loss, optimizer):
-        self.optimizer = optimizer
-        self.loss_fn = loss
-        optimizer.bind(self.store)
-
     def _loss_and_grads(self, rhs, dx, y_true):
         pred = self.call([rhs, dx], training=True)
         loss, dpred = self.loss_fn.value_and_grad(y_true, pred, rhs, torch.cat([dx, dx], 1))
@@ -304,34 +343,178 @@ class Homogeneous_Poisson_NN_Legacy:
         self.optimizer.apply_gradients()
         return {'loss': loss, 'mse': self.loss_fn.mse_metric(gt, pred), 'lr': self.optimizer.learning_rate}
 
-    def fit(self, dataset, epochs=1, callbacks=(), verbose=1, steps_per_epoch=None):
-        """Minimal Keras-style loop over a Sequence-like dataset (`__len__`, `__getitem__` -> ([rhs, dx], soln))."""
-        history = {'loss': [], 'mse': [], 'lr': []}
-        self.stop_training = False
-        for cb in callbacks:
-            cb.set_model(self)
-        for epoch in range(epochs):
-            n = steps_per_epoch if steps_per_epoch is not None else len(dataset)
-            agg = {'loss': 0.0, 'mse': 0.0}
-            for step in range(n):
-                inp, tar = dataset[step]
-                logs = self.train_step(((inp[0], inp[1]), tar))
-                logs = {k: (float(v) if not isinstance(v, float) else v) for k, v in logs.items()}
-                for k in agg:
-                    agg[k] += logs[k]
-                for cb in callbacks:
-                    cb.on_batch_end(step, logs)
-                if self.stop_training:
-                    break
-            logs = {'loss': agg['loss'] / max(step + 1, 1), 'mse': agg['mse'] / max(step + 1, 1), 'lr': self.optimizer.learning_rate}
-            for k in history:
-                history[k].append(logs[k])
-            if verbose:
-                print('Epoch %d/%d - loss: %.6g - mse: %.6g - lr: %.3g' % (epoch + 1, epochs, logs['loss'], logs['mse'], logs['lr']), flush=True)
-            for cb in callbacks:
-                cb.on_epoch_end(epoch, logs)
-            if hasattr(dataset, 'on_epoch_end'):
-                dataset.on_epoch_end()
-            if self.stop_training:
-                break
-        return history
+
+# =====================================================================================================================
+class Dirichlet_BC_NN_Legacy_2(_ModelBase):
+    """Drop-in for poisson_CNN/models/Dirichlet_BC_NN_Legacy.py:14-187: same constructor kwargs (the "model" section of
+    experiments/dbcnn.json loads unchanged), `model([bc (N,1,L), dx (N,1), x_output_resolution]) -> (N,1,X,L)`,
+    `train_step(((bc, dx), y))`.  1-D tensors are NHWC (N,1,L,C) inside; Conv1D kernels are stored as (1,k,Cin,Cout)."""
+    model_name = 'Dirichlet_BC_NN_Legacy_2'
+
+    def __init__(self, data_format='channels_first', boundary_conv_config=None, spp_config=None, domain_info_mlp_config=None,
+                 final_convolutions_config=None, postsmoother_iterations=0, use_batchnorm=False, device=None, seed=0, batchnorm_training=False):
+        if data_format != 'channels_first':
+            raise NotImplementedError('only data_format="channels_first" (all shipped configs) is supported at the API')
+        if boundary_conv_config is None:
+            raise ValueError('Provide a config for the boundary convolutions.')
+        if spp_config is None:
+            raise ValueError('Provide a config for the Spatial Pyramid Pooling.')
+        if final_convolutions_config is None:
+            raise ValueError('Provide a config for the domain convolutions.')
+        if domain_info_mlp_config is None:
+            raise ValueError('Provide a config for the domain info MLP.')
+        if device is None and not torch.cuda.is_available():
+            raise RuntimeError('Dirichlet_BC_NN_Legacy_2 needs an AMD GPU: the HIP kernels are the only compute path '
+                               '(device="cpu" builds the parameter structure only; calling the model will raise)')
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.ndims, self.data_format, self.use_batchnorm = 2, data_format, use_batchnorm
+        assert boundary_conv_config['filters'][-1] == domain_info_mlp_config['units'][-1]       # reference :39
+        self.x_dir_nmodes = M = domain_info_mlp_config['units'][-1]
+        if M > 27:
+            import warnings
+            warnings.warn('%d sinh modes chosen may lead to NaN values with float32 precision. Consider using fewer than 28 when using float32.' % M)
+        self.store = S = L.ParamStore()
+        S.bn_training = bool(batchnorm_training)
+        self.ctx = C = L.Context()
+        # boundary convolutions (:44-63): per stage conv (+BN) then a 1-D resnet
+        bcc = copy.deepcopy(boundary_conv_config)
+        mode, val = bcc.pop('padding_mode', 'CONSTANT'), bcc.pop('constant_padding_value', 0.0)
+        self.boundary = []
+        cin = 3
+        for k in range(len(bcc['filters'])):
+            a = get_init_arguments_from_config(bcc, k, ['filters', 'kernel_sizes'], ['filters', 'kernel_size'])
+            act, ub = a.get('activation', 'linear'), a.get('use_bias', True)
+            self.boundary.append(L.ConvUnit(S, C, 'bc/stage%d/conv' % k, (1, a['kernel_size']), cin, a['filters'], padding_mode=mode, pad_value=val,
+                                            activation=act, use_bias=ub, bn_name=('bc/stage%d/bn' % k) if use_batchnorm else None))
+            self.boundary.append(L.resnet(S, C, 'bc/stage%d/res' % k, a['filters'], (1, a['kernel_size']), use_batchnorm=use_batchnorm,
+                                          padding_mode=mode, constant_padding_value=val, activation=act, use_bias=ub))
+            cin = a['filters']
+        # SPP (:68) + domain-info MLP (:69-74)
+        self.spp_levels = [lv if isinstance(lv, int) else lv[0] for lv in spp_config['levels']]
+        kind = spp_config.get('pooling_type', 'average').lower()
+        if kind not in ('average', 'avg'):
+            raise NotImplementedError('Dirichlet_BC_NN_Legacy_2: only average spatial pyramid pooling (the shipped config) is implemented')
+        din = 3 + sum(self.spp_levels)
+        self.mlp = []
+        for k, (u, a) in enumerate(zip(domain_info_mlp_config['units'], domain_info_mlp_config['activations'])):
+            self.mlp.append(L.Dense(S, 'mlp/dense%d' % k, din, u, a))
+            din = u
+        # final convolutions (:76-97)
+        fc = copy.deepcopy(final_convolutions_config)
+        nst = len(fc['filters'])
+        fmode, fval = fc.pop('padding_mode', 'CONSTANT'), fc.pop('constant_padding_value', 0.0)
+        nreg = fc.pop('final_regular_conv_stages', 2)
+        self.final = []
+        cin = M + 2
+        for k in range(nst - nreg):
+            a = get_init_arguments_from_config(fc, k, ['filters', 'kernel_sizes'], ['filters', 'kernel_size'])
+            act, ub = a.get('activation', 'linear'), a.get('use_bias', True)
+            self.final.append(L.ConvUnit(S, C, 'final/stage%d/conv' % k, a['kernel_size'], cin, a['filters'], padding_mode=fmode, pad_value=fval,
+                                         activation=act, use_bias=ub))
+            self.final.append(L.resnet(S, C, 'final/stage%d/res' % k, a['filters'], a['kernel_size'], padding_mode='constant', activation=act, use_bias=ub))
+            cin = a['filters']
+        for j, k in enumerate(range(nst - nreg, nst)):
+            self.final.append(L.ConvUnit(S, C, 'final/out%d' % j, fc['kernel_sizes'][k], cin, fc['filters'][k], pad='same', activation='tanh',
+                                         use_bias=fc.get('use_bias', True)))
+            cin = fc['filters'][k]
+        if cin != 1:
+            raise ValueError('the last final convolution must have 1 filter')
+        self.postsmoother = L.JacobiIterationLayer(postsmoother_iterations) if postsmoother_iterations > 0 else None
+        S.finalize(self.device)
+        S.initialize(seed)
+        self.optimizer = self.loss_fn = self.grad_sync = None
+        self._bins, self._sinh = {}, {}
+
+    def _bin_table(self, Lh):
+        if Lh not in self._bins:
+            from .utils import split_indices
+            bins = []
+            for lv in self.spp_levels:
+                ix = split_indices(Lh, lv)
+                if (np.diff(ix) <= 0).any():
+                    raise ValueError('boundary too short for the spatial pyramid: %d bins over %d points' % (lv, Lh))
+                bins += [[0, 1, ix[b], ix[b + 1]] for b in range(lv)]
+            self._bins[Lh] = torch.tensor(np.array(bins, dtype=np.int32), device=self.device)
+        return self._bins[Lh]
+
+    def _sinh_table(self, X):
+        """build_series_x_dir_components (:106-111): input-independent, so tabulated on the host (fp64, rounded once)."""
+        if X not in self._sinh:
+            xbar = np.linspace(0.0, 1.0, X)
+            v = np.sinh(np.outer(np.arange(1, self.x_dir_nmodes + 1, dtype=np.float64), np.pi * (xbar - 1.0)))
+            v = v / np.abs(v).max(axis=1, keepdims=True)
+            self._sinh[X] = torch.from_numpy(v.astype(np.float32)).to(self.device).contiguous()
+        return self._sinh[X]
+
+    def call(self, inp, training=False):
+        """reference :126-170."""
+        bc, dx, X = inp
+        X = int(X)
+        bc, dx = _as_device(bc, self.device), _as_device(dx, self.device)
+        if bc.dim() != 3 or bc.shape[1] != 1:
+            raise ValueError('bc must have shape (N,1,L)')
+        dx = dx.reshape(dx.shape[0], -1)[:, :1].contiguous()
+        N, _, Lh = bc.shape
+        S = self.store
+        S.refresh_bn()
+        bc2 = bc.reshape(N, Lh)
+        o = ops.dbc_assemble_input(bc2)
+        for lyr in self.boundary:
+            o = lyr.forward(o, training=training)
+        bc_conv = o                                                            # (N,1,L,M)
+        bins = self._bin_table(Lh)
+        feats = ops.spp_avg_fwd(bc_conv, bins)
+        ds = torch.cat([dx * float(X - 1), dx * float(Lh - 1)], 1)           # compute_domain_sizes (:131); tiny (N,2) host-side assembly
+        d = torch.cat([dx, ds / ds.amax(dim=1, keepdim=True), feats], 1).contiguous()
+        for lyr in self.mlp:
+            d = lyr.forward(d, training=training)
+        sh = self._sinh_table(X)
+        x = ops.dbc_expand_fwd(bc_conv, sh, d)                                # (N,X,L,M+2)
+        for lyr in self.final:
+            x = lyr.forward(x, training=training)
+        pre = x.view(N, X, Lh)
+        out, _ = ops.set_max_magnitude_fwd(pre, 1.0)                          # (:163)
+        ops.set_first_row(out, bc2)                                           # (:165-166)
+        if training:
+            self._saved = {'bc_conv': bc_conv, 'mlp_out': d, 'sinh': sh, 'pre': pre, 'bins': bins, 'shape': (N, X, Lh)}
+        if self.postsmoother is not None:
+            dx2 = torch.cat([dx, dx], 1).contiguous()
+            out = self.postsmoother.forward(out.view(N, X, Lh, 1), torch.zeros_like(out).view(N, X, Lh, 1), dx2, training=training).view(N, X, Lh)
+        return out.view(N, 1, X, Lh)
+
+    def backward(self, dpred):
+        sv = self._saved
+        self._saved = None
+        N, X, Lh = sv['shape']
+        d = dpred.contiguous().view(N, X, Lh)
+        if self.postsmoother is not None:
+            d = self.postsmoother.backward(d.view(N, X, Lh, 1)).view(N, X, Lh)
+        else:
+            d = d.clone()
+        ops.set_first_row(d, None)                                            # the first row is the (constant) boundary input
+        d = ops.set_max_magnitude_bwd(sv['pre'], d, 1.0).view(N, X, Lh, 1)
+        for lyr in reversed(self.final):
+            d = lyr.backward(d, inplace=True)
+        dbc_conv, dd = ops.dbc_expand_bwd(d, sv['bc_conv'], sv['sinh'], sv['mlp_out'], ws=self.ctx.ws)
+        for lyr in reversed(self.mlp):
+            dd = lyr.backward(dd, need_dx=True)
+        dfeats = dd[:, 3:].contiguous()                                       # [dx, domain sizes] carry no parameters upstream
+        dbc_conv = ops.axpby(1.0, ops.spp_avg_bwd(sv['bins'], dfeats, tuple(sv['bc_conv'].shape)), 1.0, dbc_conv)
+        d = dbc_conv
+        for i, lyr in enumerate(reversed(self.boundary)):
+            last = i == len(self.boundary) - 1
+            d = lyr.backward(d, need_dx=not last, inplace=True) if isinstance(lyr, L.ConvUnit) else lyr.backward(d, inplace=True)
+        self.store.finish_bn_grads()
+
+    def train_step(self, data):
+        """reference :172-187: the loss sees rhs = 0 and dx repeated for both axes."""
+        (bc, dx), y_true = data
+        bc, dx, y_true = _as_device(bc, self.device), _as_device(dx, self.device), _as_device(y_true, self.device)
+        dx = dx.reshape(dx.shape[0], -1)[:, :1].contiguous()
+        pred = self.call([bc, dx, y_true.shape[2]], training=True)
+        loss, dpred = self.loss_fn.value_and_grad(y_true, pred, torch.zeros_like(y_true), torch.cat([dx, dx], 1))
+        self.backward(dpred)
+        if self.grad_sync is not None:
+            self.grad_sync(self.store.flat_g)
+        self.optimizer.apply_gradients()
+        return {'loss': loss, 'mse': self.loss_fn.mse_metric(y_true, pred), 'lr': self.optimizer.learning_rate}

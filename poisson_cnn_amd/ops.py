@@ -499,3 +499,86 @@ def adam_step(w, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
 
 def sgd_step(w, g, lr, grad_scale=1.0):
     handle().call('pcnn_sgd_step', c_int64(w.numel()), _p(w), _p(g), c_float(lr), c_float(grad_scale))
+
+
+# ----------------------------------------------------------------------------- Dirichlet_BC_NN_Legacy_2 / Poisson_CNN_Legacy
+def dbc_assemble_input(bc_nl):
+    """(N, L) boundary values -> (N, 1, L, 3) NHWC [bc, 1, cos(pi y/(L-1))] (models/Dirichlet_BC_NN_Legacy.py:136-139)."""
+    N, Lh = bc_nl.shape
+    out = empty((N, 1, Lh, 3), bc_nl.device)
+    handle().call('pcnn_dbc_assemble_input', c_int(N), c_int(Lh), _p(bc_nl), _p(out), c_int(3))
+    return out
+
+
+def spp_avg_fwd(x, bins):
+    N, H, W, C = x.shape
+    nb = bins.shape[0]
+    out = empty((N, nb), x.device)
+    handle().call('pcnn_spp_avg_fwd', c_int(N), c_int(H), c_int(W), c_int(C), c_int(_ld(x)), c_int(nb), _p(bins), _p(x), _p(out))
+    return out
+
+
+def spp_avg_bwd(bins, dout, x_shape):
+    N, H, W, C = x_shape
+    dx = empty((N, H, W, C), dout.device)
+    handle().call('pcnn_spp_avg_bwd', c_int(N), c_int(H), c_int(W), c_int(C), c_int(C), c_int(bins.shape[0]), _p(bins), _p(dout), _p(dx))
+    return dx
+
+
+def dbc_expand_fwd(f, sinh_table, d):
+    """f (N,1,L,M) boundary features, sinh_table (M,X), d (N,M) -> (N,X,L,M+2) (einsum + positional embeddings)."""
+    N, _, Lh, M = f.shape
+    X = sinh_table.shape[1]
+    out = empty((N, X, Lh, M + 2), f.device)
+    handle().call('pcnn_dbc_expand_fwd', c_int(N), c_int(X), c_int(Lh), c_int(M), _p(f), c_int(_ld(f)), _p(sinh_table), _p(d), _p(out), c_int(M + 2))
+    return out
+
+
+def dbc_expand_bwd(dout, f, sinh_table, d, ws=None):
+    N, _, Lh, M = f.shape
+    X = sinh_table.shape[1]
+    lib = _lib.load()
+    wsb = (ws or _default_ws).get(lib.pcnn_dbc_expand_bwd_workspace(c_int(N), c_int(Lh), c_int(M)), f.device)
+    df = empty((N, 1, Lh, M), f.device)
+    dd = empty((N, M), f.device)
+    handle().call('pcnn_dbc_expand_bwd', c_int(N), c_int(X), c_int(Lh), c_int(M), _p(dout), c_int(_ld(dout)), _p(f), c_int(_ld(f)), _p(sinh_table),
+                  _p(d), _p(df), c_int(M), _p(dd), _p(wsb), c_size_t(wsb.numel() * 4))
+    return df, dd
+
+
+def set_max_magnitude_fwd(x, target=1.0):
+    """Returns (x * target / max|x| per sample, factors); x (N, ...) contiguous, not modified."""
+    N = x.shape[0]
+    y = x.clone()
+    t = torch.full((N,), float(target), dtype=torch.float32, device=x.device)
+    fac = empty((N,), x.device)
+    handle().call('pcnn_set_max_magnitude', c_int(N), c_int64(x.numel() // N), _p(t), _p(y), _p(fac))
+    return y, fac
+
+
+def set_max_magnitude_bwd(x, dy, target=1.0):
+    N = x.shape[0]
+    t = torch.full((N,), float(target), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    handle().call('pcnn_set_max_magnitude_bwd', c_int(N), c_int64(x.numel() // N), _p(t), _p(x), _p(dy), _p(dx))
+    return dx
+
+
+def set_first_row(y_nxl, bc_nl=None):
+    """In place: y[n, 0, :] = bc[n, :] (or zeros)."""
+    N, X, Lh = y_nxl.shape
+    handle().call('pcnn_set_first_row', c_int(N), c_int(X), c_int(Lh), _p(bc_nl), _p(y_nxl))
+    return y_nxl
+
+
+def flip_rotate(x_nhw, transpose=False, flip_y=False, flip_x=False, alpha=None, out=None, accumulate=False):
+    """out = reverse(transpose?(x)) per sample (dataset/utils/flip_and_rotate_tensor.py), optionally * alpha[n] and accumulated."""
+    N, H, W = x_nhw.shape
+    Ho, Wo = (W, H) if transpose else (H, W)
+    if out is None:
+        out = empty((N, Ho, Wo), x_nhw.device)
+        accumulate = False
+    assert tuple(out.shape) == (N, Ho, Wo) and out.is_contiguous() and x_nhw.is_contiguous()
+    handle().call('pcnn_flip_rotate', c_int(N), c_int(Ho), c_int(Wo), c_int(int(transpose)), c_int(int(flip_y)), c_int(int(flip_x)), _p(x_nhw),
+                  _p(alpha), c_int(int(accumulate)), _p(out))
+    return out
