@@ -92,10 +92,14 @@ class _ModelBase:
     def __call__(self, inp, training=False):
         return self.call(inp, training=training)
 
+    @property
+    def stores(self):
+        return [self.store]
+
     def compile(self, loss, optimizer):
         self.optimizer = optimizer
         self.loss_fn = loss
-        optimizer.bind(self.store)
+        optimizer.bind(self.stores)
 
     def fit(self, dataset, epochs=1, callbacks=(), verbose=1, steps_per_epoch=None):
         """Minimal Keras-style loop over a Sequence-like dataset (`__len__`, `__getitem__` -> ([rhs, dx], soln))."""
@@ -516,5 +520,148 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         self.backward(dpred)
         if self.grad_sync is not None:
             self.grad_sync(self.store.flat_g)
+        self.optimizer.apply_gradients()
+        return {'loss': loss, 'mse': self.loss_fn.mse_metric(y_true, pred), 'lr': self.optimizer.learning_rate}
+
+
+    # ------------------------------------------------------------------ used by Poisson_CNN_Legacy: several calls per step share the weights
+    def _stateful(self):
+        objs = [self]
+        for lyr in self.boundary + self.final:
+            objs += [lyr.c0, lyr.c1, lyr.c2] if isinstance(lyr, L.resnet) else [lyr]
+        return objs + self.mlp + ([self.postsmoother] if self.postsmoother is not None else [])
+
+    def snapshot(self):
+        """What backward() needs from the last call(training=True)."""
+        return [(o, {k: getattr(o, k) for k in ('saved', '_saved', 'dx2') if hasattr(o, k)}) for o in self._stateful()]
+
+    @staticmethod
+    def restore(snap):
+        for o, attrs in snap:
+            for k, v in attrs.items():
+                setattr(o, k, v)
+
+
+# =====================================================================================================================
+class Poisson_CNN_Legacy(_ModelBase):
+    """Drop-in for poisson_CNN/models/Poisson_CNN_Legacy.py:5-71: `Poisson_CNN_Legacy(hpnn, dbcnn)`,
+    `model([rhs (N,1,H,W), left (N,1,W), top (N,1,H), right (N,1,W), bottom (N,1,H), dx (N,1)]) -> (N,1,H,W)`: the homogeneous
+    solution plus one Dirichlet_BC_NN_Legacy_2 pass per edge (left/right and top/bottom are batched: same weights, same shapes),
+    rotated/flipped into place by flip_and_rotate_tensor and un-normalised by the per-sample scaling factors."""
+    model_name = 'Poisson_CNN_Legacy'
+
+    def __init__(self, hpnn, dbcnn, jacobi_iterations=0):
+        if jacobi_iterations > 0:
+            # the reference constructor dereferences an unimported module name here (Poisson_CNN_Legacy.py:11) and raises NameError
+            raise NotImplementedError('Poisson_CNN_Legacy: jacobi_iterations > 0 is unreachable in the reference (NameError at construction)')
+        self.hpnn, self.dbcnn = hpnn, dbcnn
+        self.device = hpnn.device
+        self.optimizer = self.loss_fn = self.grad_sync = None
+
+    # weights: the two sub-models' lists, hpnn first (Keras tracks attributes in assignment order)
+    @property
+    def stores(self):
+        return [self.hpnn.store, self.dbcnn.store]
+
+    @property
+    def weight_names(self):
+        return ['hpnn/' + n for n in self.hpnn.weight_names] + ['dbcnn/' + n for n in self.dbcnn.weight_names]
+
+    @property
+    def trainable_variables(self):
+        return self.hpnn.trainable_variables + self.dbcnn.trainable_variables
+
+    def get_weights(self):
+        return self.hpnn.get_weights() + self.dbcnn.get_weights()
+
+    def set_weights(self, weights):
+        if isinstance(weights, dict):
+            self.hpnn.set_weights({n[5:]: v for n, v in weights.items() if n.startswith('hpnn/')})
+            self.dbcnn.set_weights({n[6:]: v for n, v in weights.items() if n.startswith('dbcnn/')})
+        else:
+            k = len(self.hpnn.weight_names)
+            self.hpnn.set_weights(list(weights[:k]))
+            self.dbcnn.set_weights(list(weights[k:]))
+
+    def save_weights(self, path):
+        np.savez(path, **{n.replace('/', '.'): w for n, w in zip(self.weight_names, self.get_weights())})
+
+    def load_weights(self, path):
+        with np.load(path if str(path).endswith('.npz') else str(path) + '.npz') as z:
+            self.set_weights({n: z[n.replace('/', '.')] for n in self.weight_names})
+
+    def count_params(self):
+        return self.hpnn.count_params() + self.dbcnn.count_params()
+
+    def summary(self, print_fn=print):
+        self.hpnn.summary(print_fn)
+        self.dbcnn.summary(print_fn)
+
+    # (transpose, flip rows, flip columns) that flip_and_rotate_tensor applies to each edge's result (:36-46) ...
+    _PLACE = {'left': (False, False, False), 'top': (True, False, True), 'right': (False, True, False), 'bottom': (True, False, False)}
+    # ... and their adjoints (a transpose swaps the roles of the two flips)
+    _ADJ = {'left': (False, False, False), 'top': (True, True, False), 'right': (False, True, False), 'bottom': (True, False, False)}
+
+    def call(self, inp, training=False):
+        rhs, left, top, right, bottom, dx = [_as_device(v, self.device) for v in inp]
+        dx = dx.reshape(dx.shape[0], -1)[:, :1].contiguous()
+        N, _, H, W = rhs.shape
+        rhs_n, rhs_f = ops.set_max_magnitude_fwd(rhs.reshape(N, H * W), 1.0)                 # :24
+        edges = {}
+        for name, v in (('left', left), ('top', top), ('right', right), ('bottom', bottom)):
+            edges[name] = ops.set_max_magnitude_fwd(v.reshape(N, -1), 1.0)                   # :25-28
+        h = self.hpnn.call([rhs_n.view(N, 1, H, W), dx], training=training)
+        dmax = torch.cat([dx * float(H - 1), dx * float(W - 1)], 1).amax(dim=1)
+        scale_h = (dmax * dmax / rhs_f).contiguous()                                          # :30
+        pred = ops.flip_rotate(h.view(N, H, W), alpha=scale_h)
+        dx2 = torch.cat([dx, dx], 0).contiguous()
+        snaps, scales = {}, {}
+        for pair, X in ((('left', 'right'), H), (('top', 'bottom'), W)):
+            bc = torch.cat([edges[pair[0]][0], edges[pair[1]][0]], 0)
+            out = self.dbcnn.call([bc.view(2 * N, 1, -1), dx2, X], training=training)        # (2N,1,X,L)
+            out = out.view(2 * N, X, -1)
+            for j, name in enumerate(pair):
+                scales[name] = (1.0 / edges[name][1]).contiguous()                            # :33-46
+                t, fy, fx = self._PLACE[name]
+                ops.flip_rotate(out[j * N:(j + 1) * N], transpose=t, flip_y=fy, flip_x=fx, alpha=scales[name], out=pred, accumulate=True)
+            if training:
+                snaps[pair] = self.dbcnn.snapshot()
+        if training:
+            self._saved = {'snaps': snaps, 'scales': scales, 'scale_h': scale_h, 'shape': (N, H, W)}
+        return pred.view(N, 1, H, W)
+
+    def backward(self, dpred):
+        sv = self._saved
+        self._saved = None
+        N, H, W = sv['shape']
+        d = dpred.contiguous().view(N, H, W)
+        self.hpnn.backward(ops.flip_rotate(d, alpha=sv['scale_h']).view(N, 1, H, W))
+        acc = None
+        for pair, X in ((('top', 'bottom'), W), (('left', 'right'), H)):
+            Lh = H if X == W else W
+            dout = ops.empty((2 * N, X, Lh), self.device)
+            for j, name in enumerate(pair):
+                t, fy, fx = self._ADJ[name]
+                ops.flip_rotate(d, transpose=t, flip_y=fy, flip_x=fx, alpha=sv['scales'][name], out=dout[j * N:(j + 1) * N])
+            self.dbcnn.restore(sv['snaps'][pair])
+            self.dbcnn.backward(dout.view(2 * N, 1, X, Lh))
+            g = self.dbcnn.store.flat_g
+            if acc is None:
+                acc = g.clone()
+            else:
+                ops.axpby_flat(1.0, acc, 1.0, g)                                              # the two passes share the weights
+
+    def train_step(self, data):
+        """reference :56-66."""
+        inputs, y_true = data
+        inputs = [_as_device(v, self.device) for v in inputs]
+        y_true = _as_device(y_true, self.device)
+        dx = inputs[5].reshape(inputs[5].shape[0], -1)[:, :1].contiguous()
+        pred = self.call(inputs, training=True)
+        loss, dpred = self.loss_fn.value_and_grad(y_true, pred, inputs[0], torch.cat([dx, dx], 1))
+        self.backward(dpred)
+        if self.grad_sync is not None:
+            for s in self.stores:
+                self.grad_sync(s.flat_g)
         self.optimizer.apply_gradients()
         return {'loss': loss, 'mse': self.loss_fn.mse_metric(y_true, pred), 'lr': self.optimizer.learning_rate}

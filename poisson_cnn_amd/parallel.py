@@ -53,8 +53,9 @@ class DataParallel:
 
     def attach(self, model):
         """Replicate rank 0's weights and hook the gradient all-reduce in front of the optimizer step."""
-        self.broadcast(model.store.flat_w)
-        self.broadcast(model.store.flat_stats)
+        for store in getattr(model, 'stores', [model.store]):
+            self.broadcast(store.flat_w)
+            self.broadcast(store.flat_stats)
         model.grad_sync = self.all_reduce_sum
         return model
 

@@ -17,7 +17,9 @@ from . import ops
 
 class _Optimizer:
     def bind(self, store):
-        self.store = store
+        """store: one ParamStore or a list of them (a composite model such as Poisson_CNN_Legacy trains several buckets)."""
+        self.stores = list(store) if isinstance(store, (list, tuple)) else [store]
+        self.store = self.stores[0]
         self._init_state()
 
     def _init_state(self):
@@ -35,13 +37,14 @@ class Adam(_Optimizer):
 
     def _init_state(self):
         import torch
-        self.m = torch.zeros_like(self.store.flat_w)
-        self.v = torch.zeros_like(self.store.flat_w)
+        self.ms = [torch.zeros_like(s.flat_w) for s in self.stores]
+        self.vs = [torch.zeros_like(s.flat_w) for s in self.stores]
+        self.m, self.v = self.ms[0], self.vs[0]
 
     def apply_gradients(self, grad_scale=1.0):
         self.iterations += 1
-        s = self.store
-        ops.adam_step(s.flat_w, s.flat_g, self.m, self.v, self.learning_rate, self.beta_1, self.beta_2, self.epsilon, self.iterations, grad_scale)
+        for s, m, v in zip(self.stores, self.ms, self.vs):
+            ops.adam_step(s.flat_w, s.flat_g, m, v, self.learning_rate, self.beta_1, self.beta_2, self.epsilon, self.iterations, grad_scale)
 
 
 class SGD(_Optimizer):
@@ -51,7 +54,8 @@ class SGD(_Optimizer):
 
     def apply_gradients(self, grad_scale=1.0):
         self.iterations += 1
-        ops.sgd_step(self.store.flat_w, self.store.flat_g, self.learning_rate, grad_scale)
+        for s in self.stores:
+            ops.sgd_step(s.flat_w, s.flat_g, self.learning_rate, grad_scale)
 
 
 def choose_optimizer(name):

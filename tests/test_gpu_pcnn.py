@@ -1,0 +1,87 @@
+"""GPU parity of Poisson_CNN_Legacy (homogeneous network + four Dirichlet_BC_NN_Legacy_2 passes) and
+of the flip_and_rotate_tensor kernel against the fp64 oracle / its autograd twin."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dbcnn as odb, hpnn as ohpnn, np_ops, torch_twin, loss as oloss
+from poisson_cnn_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def f32(a):
+    return np.asarray(a).astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize('rc,flips', [(0, ()), (0, (2,)), (1, (2,)), (3, ()), (1, ()), (2, (3,))])
+def test_flip_rotate_kernel(rc, flips):
+    from poisson_cnn_amd import ops
+    x = f32(np.random.default_rng(rc).standard_normal((2, 1, 7, 5)))
+    ref = odb.flip_and_rotate(np_ops, x, rotation_count=rc, flip_axes=flips)
+    t = rc % 2 == 1
+    fy = ((2 in flips) + (rc != 0 and [[0, 0], [1, 0], [1, 1], [0, 1]][rc % 4][0])) % 2 == 1
+    fx = ((3 in flips) + (rc != 0 and [[0, 0], [1, 0], [1, 1], [0, 1]][rc % 4][1])) % 2 == 1
+    xd = torch.tensor(x[:, 0], dtype=torch.float32).cuda().contiguous()
+    y = ops.flip_rotate(xd, transpose=t, flip_y=fy, flip_x=fx).cpu().numpy()
+    assert np.array_equal(y, ref[:, 0].astype(np.float32))
+    # adjoint: <P x, g> = <x, P^T g> with P^T = (transpose, flip_y', flip_x') = (t, fx, fy) if t else (t, fy, fx)
+    g = torch.randn(*y.shape, device='cuda')
+    gt = ops.flip_rotate(g.contiguous(), transpose=t, flip_y=fx if t else fy, flip_x=fy if t else fx)
+    assert abs(float((torch.tensor(y).cuda() * g).sum()) - float((xd * gt).sum())) < 1e-4
+
+
+def _build():
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy, Dirichlet_BC_NN_Legacy_2, Poisson_CNN_Legacy
+    hcfg, dcfg = configs.hpnn_tiny()['model'], configs.dbcnn_tiny()['model']
+    hp, dp = ohpnn.init_params(hcfg, seed=3, gain=1.5, randomize_all=True), odb.init_params(dcfg, seed=4, gain=1.5, randomize_all=True)
+    h, d = Homogeneous_Poisson_NN_Legacy(**hcfg), Dirichlet_BC_NN_Legacy_2(**dcfg)
+    h.set_weights(hp)
+    d.set_weights(dp)
+    return Poisson_CNN_Legacy(h, d), hcfg, hp, dcfg, dp
+
+
+def _inputs(N, H, W, seed):
+    rng = np.random.default_rng(seed)
+    rhs = f32(rng.uniform(-2, 2, (N, 1, H, W)))
+    edge = lambda n: f32(np.cumsum(rng.standard_normal((N, 1, n)), axis=2) * 0.2)
+    return rhs, edge(W), edge(H), edge(W), edge(H), f32(rng.uniform(5e-3, 5e-2, (N, 1)))
+
+
+def test_pcnn_forward():
+    model, hcfg, hp, dcfg, dp = _build()
+    inp = _inputs(2, 44, 38, 1)
+    ref = odb.pcnn_forward(np_ops, hcfg, hp, dcfg, dp, *inp)
+    y = model(list(inp)).cpu().numpy()
+    assert y.shape == ref.shape
+    assert rel(y, ref) < 1e-5
+
+
+def test_pcnn_train_step_gradients():
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import Adam
+    model, hcfg, hp, dcfg, dp = _build()
+    inp = _inputs(2, 40, 46, 2)
+    target = f32(np.random.default_rng(9).standard_normal((2, 1, 40, 46)))
+    lossp = dict(configs.dbcnn_tiny()['training']['loss_parameters'])
+    ht = {k: torch.tensor(v, dtype=torch.float64, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in hp.items()}
+    dt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in dp.items()}
+    pred = odb.pcnn_forward(torch_twin, hcfg, ht, dcfg, dt, *[torch.tensor(v) for v in inp])
+    loss = oloss.loss_wrapper(global_batch_size=2, **lossp)(target, pred, torch.tensor(inp[0]), np.concatenate([inp[5], inp[5]], 1))
+    loss.backward()
+    model.compile(loss=loss_wrapper(global_batch_size=2, **lossp), optimizer=Adam(learning_rate=1e-4))
+    w0 = model.get_weights()
+    logs = model.train_step((list(inp), target))
+    assert abs(float(logs['loss']) - float(loss.detach())) < 2e-5 * abs(float(loss.detach()))
+    for sub, ref in ((model.hpnn, ht), (model.dbcnn, dt)):
+        g = {n: sub.store.g[n].cpu().numpy() for n in sub.store.trainable_names()}
+        flat = np.concatenate([g[n].ravel() for n in g]); flat_ref = np.concatenate([ref[n].grad.numpy().ravel() for n in g])
+        assert rel(flat, flat_ref) < 5e-4, sub.model_name
+    w1 = model.get_weights()
+    assert any(not np.array_equal(a, b) for a, b in zip(w0, w1))
+    assert len(model.weight_names) == len(w0) == len(model.hpnn.weight_names) + len(model.dbcnn.weight_names)
