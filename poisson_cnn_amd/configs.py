@@ -118,3 +118,22 @@ def dbcnn_tiny():
     m['final_convolutions_config'].update(filters=[5, 3, 1], kernel_sizes=[3, 3, 3])
     cfg['training']['loss_parameters']['integral_loss_config']['n_quadpts'] = 11
     return cfg
+
+
+def pcnn_end_to_end():
+    """experiments/pcnn_end_to_end.json: Poisson_CNN_Legacy(hpnn, dbcnn) trained jointly on four-edge numerical samples."""
+    dataset = {'batch_size': 5, 'batches_per_epoch': 200, 'random_output_shape_range': [[192, 384], [192, 384]], 'random_dx_range': [0.005, 0.05],
+               'solver_method': 'multigrid', 'rhs_random_smoothness_range': [3, 8], 'randomize_rhs_smoothness': True,
+               'boundary_random_smoothness_range': {'left': [3, 8], 'right': [3, 8], 'top': [3, 8], 'bottom': [3, 8]}}
+    training = copy.deepcopy(dbcnn()['training'])
+    training['optimizer_parameters']['learning_rate'] = 1e-5
+    training['loss_parameters']['scale_sample_loss_by_target_peak_magnitude'] = True
+    return {'hpnn_model': hpnn()['model'], 'dbcnn_model': dbcnn()['model'], 'dataset': dataset, 'training': training}
+
+
+def pcnn_end_to_end_tiny():
+    cfg = pcnn_end_to_end()
+    cfg['hpnn_model'], cfg['dbcnn_model'] = hpnn_tiny()['model'], dbcnn_tiny()['model']
+    cfg['dataset'].update(batch_size=2, batches_per_epoch=2, random_output_shape_range=[[40, 56], [40, 56]])
+    cfg['training']['loss_parameters']['integral_loss_config']['n_quadpts'] = 11
+    return cfg

@@ -129,7 +129,7 @@ def load_model_checkpoint(model, checkpoint_path, **unused):
 def main(argv=None):
     from . import configs
     from .utils import convert_tf_object_names
-    from .models import Homogeneous_Poisson_NN_Legacy
+    from .models import Homogeneous_Poisson_NN_Legacy, Dirichlet_BC_NN_Legacy_2, Poisson_CNN_Legacy
     from .losses import loss_wrapper
     from .dataset import numerical_dataset_generator, reverse_poisson_dataset_generator, reverse_poisson_dataset_generator_homogeneous_neumann
     from . import parallel
@@ -140,6 +140,8 @@ def main(argv=None):
     p.add_argument('--dataset_type', type=lambda x: str(x).lower(), default='analytical')
     p.add_argument('--learning_rate', type=str, default=None)
     p.add_argument('--epochs', type=int, default=None)
+    p.add_argument('--model', type=lambda x: str(x).lower(), default='hpnn', choices=['hpnn', 'dbcnn', 'pcnn'],
+                   help='hpnn: train/hpnn_legacy_train.py; dbcnn: train/dbcnn_legacy_train.py; pcnn: train/pcnn_end_to_end.py')
     args = p.parse_args(argv)
     if args.dataset_type not in ('numerical', 'analytical'):
         raise ValueError('Invalid dataset type. Received: ' + args.dataset_type)
@@ -151,14 +153,23 @@ def main(argv=None):
     dcfg = dict(config['dataset'])
     dcfg['batch_size'] = dp.local_batch(gbs)
     dcfg['seed'] = dcfg.get('seed', 0) + dp.rank
-    neumann = config['model'].get('bc_type', 'dirichlet').lower() == 'neumann'
-    if args.dataset_type == 'numerical':
-        dataset = numerical_dataset_generator(**dcfg)
-    elif neumann:
-        dataset = reverse_poisson_dataset_generator_homogeneous_neumann(**dcfg)
+    if args.model == 'dbcnn':      # train/dbcnn_legacy_train.py:26-31: one non-zero edge, zero right-hand side
+        dataset = numerical_dataset_generator(randomize_boundary_smoothness=True, exclude_zero_boundaries=True, nonzero_boundaries=['left'], rhses='zero',
+                                              return_boundaries=True, return_dx=True, return_rhs=False, **dcfg)
+        model = Dirichlet_BC_NN_Legacy_2(**config['model'])
+    elif args.model == 'pcnn':     # train/pcnn_end_to_end.py:28-34: all four edges + a random right-hand side, both sub-models trained jointly
+        dataset = numerical_dataset_generator(randomize_boundary_smoothness=True, exclude_zero_boundaries=False, nonzero_boundaries=['left', 'right', 'top', 'bottom'],
+                                              rhses='random', return_boundaries=True, return_dx=True, return_rhs=True, **dcfg)
+        model = Poisson_CNN_Legacy(Homogeneous_Poisson_NN_Legacy(**config['hpnn_model']), Dirichlet_BC_NN_Legacy_2(**config['dbcnn_model']))
     else:
-        dataset = reverse_poisson_dataset_generator(**dcfg)
-    model = Homogeneous_Poisson_NN_Legacy(**config['model'])
+        neumann = config['model'].get('bc_type', 'dirichlet').lower() == 'neumann'
+        if args.dataset_type == 'numerical':
+            dataset = numerical_dataset_generator(**dcfg)
+        elif neumann:
+            dataset = reverse_poisson_dataset_generator_homogeneous_neumann(**dcfg)
+        else:
+            dataset = reverse_poisson_dataset_generator(**dcfg)
+        model = Homogeneous_Poisson_NN_Legacy(**config['model'])
     optimizer = choose_optimizer(config['training']['optimizer'])(**config['training']['optimizer_parameters'])
     loss = loss_wrapper(global_batch_size=gbs, **config['training']['loss_parameters'])
     model.compile(loss=loss, optimizer=optimizer)

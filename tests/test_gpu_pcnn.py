@@ -85,3 +85,18 @@ def test_pcnn_train_step_gradients():
     w1 = model.get_weights()
     assert any(not np.array_equal(a, b) for a, b in zip(w0, w1))
     assert len(model.weight_names) == len(w0) == len(model.hpnn.weight_names) + len(model.dbcnn.weight_names)
+
+
+@pytest.mark.parametrize('which', ['dbcnn', 'pcnn'])
+def test_training_cli_runs(which, tmp_path):
+    """python -m poisson_cnn_amd.train <json> --model dbcnn|pcnn: the counterparts of train/dbcnn_legacy_train.py and
+    train/pcnn_end_to_end.py - dataset generated on the device, two optimizer steps, a checkpoint that loads back."""
+    import json, os
+    from poisson_cnn_amd import train
+    cfg = configs.pcnn_end_to_end_tiny() if which == 'pcnn' else configs.dbcnn_tiny()
+    if which == 'dbcnn':
+        cfg['dataset'].update(batch_size=3, batches_per_epoch=2, random_output_shape_range=[[40, 56], [40, 56]])
+    path = tmp_path / 'cfg.json'
+    path.write_text(json.dumps(cfg))
+    train.main([str(path), '--model', which, '--checkpoint_dir', str(tmp_path), '--epochs', '1'])
+    assert any(f.startswith('chkpt') for f in os.listdir(tmp_path))
