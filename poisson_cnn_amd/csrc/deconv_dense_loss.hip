@@ -105,25 +105,26 @@ __global__ void dense_fwd_kernel(int N, int In, int Out, const float* __restrict
   y[i] = pcnn_act(acc, act, alpha);
 }
 
-// single workgroup; dz computed on the fly
+// grid-stride over output elements (every dx / dw / db element is independent); dz computed on the fly
 __global__ __launch_bounds__(256) void dense_bwd_kernel(int N, int In, int Out, const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ y, const float* __restrict__ dy, int act, float alpha,
                                                         float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db) {
   auto dz = [&](int n, int o) { return dy[n * Out + o] * pcnn_act_grad_from_out(y[n * Out + o], act, alpha); };
+  const int t0 = blockIdx.x * blockDim.x + threadIdx.x, ts = gridDim.x * blockDim.x;
   if (dx)
-    for (int i = threadIdx.x; i < N * In; i += blockDim.x) {
+    for (int i = t0; i < N * In; i += ts) {
       const int n = i / In, k = i % In;
       float acc = 0.f;
       for (int o = 0; o < Out; ++o) acc = fmaf(dz(n, o), w[k * Out + o], acc);
       dx[i] = acc;
     }
-  for (int i = threadIdx.x; i < In * Out; i += blockDim.x) {
+  for (int i = t0; i < In * Out; i += ts) {
     const int k = i / Out, o = i % Out;
     float acc = 0.f;
     for (int n = 0; n < N; ++n) acc = fmaf(x[n * In + k], dz(n, o), acc);
     dw[i] += acc;
   }
-  for (int o = threadIdx.x; o < Out; o += blockDim.x) {
+  for (int o = t0; o < Out; o += ts) {
     float acc = 0.f;
     for (int n = 0; n < N; ++n) acc += dz(n, o);
     db[o] += acc;
@@ -345,7 +346,8 @@ extern "C" int pcnn_dense_fwd(pcnn_handle h, int N, int In, int Out, const float
 extern "C" int pcnn_dense_bwd(pcnn_handle h, int N, int In, int Out, const float* x, const float* w, const float* y, const float* dy, int act,
                               float alpha, float* dx, float* dw, float* db) {
   PCNN_REQUIRE(h, h && x && w && y && dy && dw && db, "pcnn_dense_bwd: null argument");
-  hipLaunchKernelGGL(dense_bwd_kernel, dim3(1), dim3(256), 0, h->stream, N, In, Out, x, w, y, dy, act, alpha, dx, dw, db);
+  const int work = std::max(N * In, In * Out);
+  hipLaunchKernelGGL(dense_bwd_kernel, dim3(std::min(pcnn_cdiv(work, 256), 1024)), dim3(256), 0, h->stream, N, In, Out, x, w, y, dy, act, alpha, dx, dw, db);
   PCNN_CHECK_LAUNCH(h, "pcnn_dense_bwd");
   return 0;
 }

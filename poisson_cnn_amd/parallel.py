@@ -53,7 +53,7 @@ class DataParallel:
 
     def attach(self, model):
         """Replicate rank 0's weights and hook the gradient all-reduce in front of the optimizer step."""
-        for store in model.stores:
+        for store in (model.stores if hasattr(model, 'stores') else [model.store]):
             self.broadcast(store.flat_w)
             self.broadcast(store.flat_stats)
         model.grad_sync = self.all_reduce_sum
