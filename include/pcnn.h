@@ -80,6 +80,10 @@ int pcnn_conv2d_flip_transpose_weights(pcnn_handle h, const float* w, float* wt,
 size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d);
 int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
                       void* workspace, size_t workspace_bytes);
+/* Same with optional hints: x_absmax / dz_absmax point to device floats holding max|x| / max|dz| (exact, or any finite upper bound
+ * within a factor 2^10: the scale only has to keep the fp16 halves in range), NULL = compute here.  Ignored in the fp32 math mode. */
+int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
+                           void* workspace, size_t workspace_bytes, const float* x_absmax, const float* dz_absmax);
 
 /* Backward of the fused epilogue: given dy (gradient at y) and the saved activation a = act(z),
  *   dz = dy * bn_scale[c] * act'(z)      (act' recovered from a: leaky -> a>0 ? 1 : alpha, tanh -> 1-a^2)
@@ -90,6 +94,11 @@ size_t pcnn_colsum_workspace(int C);
 int pcnn_conv2d_epilogue_bwd(pcnn_handle h, int64_t npix, int C, const float* dy, int lddy, const float* a, int lda,
                              const float* bn_scale, int act, float act_alpha, float* dz, int lddz,
                              float* dbias, float* dsum_dy_a, float* dsum_dy, void* workspace, size_t workspace_bytes);
+/* Same, and additionally dz_absmax[0] = max|dz| over the tensor (device float, NULL = skip): the weight-gradient kernels of the
+ * split math mode scale dz by this maximum - computing it here saves them a pass over dz (pcnn_conv2d_wgrad_hint) */
+int pcnn_conv2d_epilogue_bwd_absmax(pcnn_handle h, int64_t npix, int C, const float* dy, int lddy, const float* a, int lda,
+                                    const float* bn_scale, int act, float act_alpha, float* dz, int lddz, float* dbias,
+                                    float* dsum_dy_a, float* dsum_dy, float* dz_absmax, void* workspace, size_t workspace_bytes);
 
 /* Adjoint of tf.pad SYMMETRIC / REFLECT / CONSTANT: folds the gradient on the padded domain
  * gp (N, H+pt+pb, W+pl+pr, C) back onto the un-padded image: gx[n,y,x,c] = sum of gp over all padded positions

@@ -353,6 +353,7 @@ struct SplitPlanes {
   const float* src[2]; _Float16* hi[2]; _Float16* lo[2];
   int64_t nquad[2]; int cq[2]; int C[2]; int ld[2]; int vec[2];     // quads in total, quads per pixel, channels, source channel stride, 1 = float4-loadable, 2 = and dense
   unsigned* maxbits;
+  const float* hint[2];                                              // device max|.| supplied by the caller (NULL: computed by split_absmax_kernel)
 };
 
 // channels 4q .. 4q+3 of one pixel; channels past C read as zero (the planes are padded to a multiple of 4 channels)
@@ -371,6 +372,13 @@ __device__ __forceinline__ f32x4 load_quad(const float* __restrict__ src, int64_
 // are pure streaming: 4 independent 16-byte loads in flight per thread.
 __global__ __launch_bounds__(256) void split_absmax_kernel(SplitPlanes sp) {
   const int which = blockIdx.y;
+  if (sp.hint[which]) {                // the producer already knows the maximum
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const float v = fabsf(sp.hint[which][0]);
+      sp.maxbits[which] = __float_as_uint(v <= 3.0e38f ? v : 3.0e38f);
+    }
+    return;
+  }
   const float* src = sp.src[which];
   const int cq = sp.cq[which], ld = sp.ld[which], C = sp.C[which], vec = sp.vec[which];
   const int64_t nq = sp.nquad[which], stride = (int64_t)gridDim.x * 256;
@@ -660,6 +668,11 @@ extern "C" size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d) {
 
 extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
                                  void* workspace, size_t workspace_bytes) {
+  return pcnn_conv2d_wgrad_hint(h, d, x, dz, dw, workspace, workspace_bytes, nullptr, nullptr);
+}
+
+extern "C" int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
+                                      void* workspace, size_t workspace_bytes, const float* x_absmax, const float* dz_absmax) {
   PCNN_REQUIRE(h, h && d && x && dz && dw && workspace, "pcnn_conv2d_wgrad: null argument");
   PCNN_REQUIRE(h, d->Cin >= 1 && d->Cin <= 128 && d->Cout >= 1 && d->Cout <= 64, "pcnn_conv2d_wgrad: channels %d->%d unsupported (<=64)", d->Cin, d->Cout);
   PCNN_REQUIRE(h, d->ldx >= d->Cin && d->ldy >= d->Cout, "pcnn_conv2d_wgrad: channel stride smaller than channel count");
@@ -683,7 +696,7 @@ extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const f
     SplitPlanes pp;
     pp.maxbits = reinterpret_cast<unsigned*>(base);
     _Float16* planes = reinterpret_cast<_Float16*>(base + 256);
-    pp.src[0] = x; pp.src[1] = dz;
+    pp.src[0] = x; pp.src[1] = dz; pp.hint[0] = x_absmax; pp.hint[1] = dz_absmax;
     pp.hi[0] = planes; pp.lo[0] = planes + plane_elems_x(&pd);
     pp.hi[1] = pp.lo[0] + plane_elems_x(&pd); pp.lo[1] = pp.hi[1] + plane_elems_z(&pd);
     pp.cq[0] = pd.Cin >> 2; pp.cq[1] = pd.Cout >> 2; pp.C[0] = d->Cin; pp.C[1] = d->Cout; pp.ld[0] = d->ldx; pp.ld[1] = d->ldy;

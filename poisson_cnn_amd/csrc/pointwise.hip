@@ -15,10 +15,10 @@ static int pow2_ge(int c) { int p = 1; while (p < c) p <<= 1; return p; }
 __global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_kernel(int64_t npix, int C, int CP, const float* __restrict__ dy, int lddy,
                                                                 const float* __restrict__ a, int lda, const float* __restrict__ bn_scale,
                                                                 int act, float alpha, float* __restrict__ dz, int lddz,
-                                                                float* __restrict__ partial /*[gridDim][3][C]*/) {
+                                                                float* __restrict__ partial /*[gridDim][3][C]*/, unsigned* __restrict__ absmax) {
   __shared__ float red[3][CS_BLOCK];
   const int tid = threadIdx.x, c = tid % CP, r = tid / CP, R = CS_BLOCK / CP;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, zmax = 0.f;
   if (c < C) {
     const float sc = bn_scale ? bn_scale[c] : 1.f;
     for (int64_t pix = (int64_t)blockIdx.x * R + r; pix < npix; pix += (int64_t)gridDim.x * R) {
@@ -26,8 +26,13 @@ __global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_kernel(int64_t npix, in
       const float av = a ? a[pix * lda + c] : 0.f;
       const float z = g * sc * pcnn_act_grad_from_out(av, act, alpha);
       if (dz) dz[pix * lddz + c] = z;
-      s0 += z; s1 += g * av; s2 += g;
+      s0 += z; s1 += g * av; s2 += g; zmax = fmaxf(zmax, fabsf(z));
     }
+  }
+  if (absmax) {                        // max |dz| of the tensor: one atomic per wave (float bits of non-negative values order like integers)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
+    if ((tid & 63) == 0) atomicMax(absmax, __float_as_uint(zmax <= 3.0e38f ? zmax : 3.0e38f));
   }
   red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
   __syncthreads();
@@ -45,8 +50,9 @@ __global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_kernel(int64_t npix, in
 __global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_vec4_kernel(int64_t npix, int C, const float* __restrict__ dy, int lddy,
                                                                      const float* __restrict__ a, int lda, const float* __restrict__ bn_scale,
                                                                      int act, float alpha, float* __restrict__ dz, int lddz,
-                                                                     float* __restrict__ partial /*[gridDim][3][C]*/) {
+                                                                     float* __restrict__ partial /*[gridDim][3][C]*/, unsigned* __restrict__ absmax) {
   __shared__ float red[3][CS_BLOCK * 4];
+  float zmax = 0.f;
   const int GQ = C >> 2, R = CS_BLOCK / GQ;
   const int tid = threadIdx.x, r = tid / GQ, q = tid - r * GQ, c = q << 2;
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -62,10 +68,15 @@ __global__ __launch_bounds__(CS_BLOCK) void epilogue_bwd_vec4_kernel(int64_t npi
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         z[j] = g[j] * sc[j] * pcnn_act_grad_from_out(av[j], act, alpha);
-        s0[j] += z[j]; s1[j] += g[j] * av[j]; s2[j] += g[j];
+        s0[j] += z[j]; s1[j] += g[j] * av[j]; s2[j] += g[j]; zmax = fmaxf(zmax, fabsf(z[j]));
       }
       if (dz) *reinterpret_cast<float4*>(dz + pix * lddz + c) = make_float4(z[0], z[1], z[2], z[3]);
     }
+  }
+  if (absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o));
+    if ((tid & 63) == 0) atomicMax(absmax, __float_as_uint(zmax <= 3.0e38f ? zmax : 3.0e38f));
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { red[0][tid * 4 + j] = s0[j]; red[1][tid * 4 + j] = s1[j]; red[2][tid * 4 + j] = s2[j]; }
@@ -353,6 +364,13 @@ extern "C" size_t pcnn_colsum_workspace(int C) { return (size_t)CS_MAXBLK * 3 * 
 extern "C" int pcnn_conv2d_epilogue_bwd(pcnn_handle h, int64_t npix, int C, const float* dy, int lddy, const float* a, int lda,
                                         const float* bn_scale, int act, float act_alpha, float* dz, int lddz, float* dbias,
                                         float* dsum_dy_a, float* dsum_dy, void* workspace, size_t workspace_bytes) {
+  return pcnn_conv2d_epilogue_bwd_absmax(h, npix, C, dy, lddy, a, lda, bn_scale, act, act_alpha, dz, lddz, dbias, dsum_dy_a, dsum_dy, nullptr, workspace,
+                                         workspace_bytes);
+}
+
+extern "C" int pcnn_conv2d_epilogue_bwd_absmax(pcnn_handle h, int64_t npix, int C, const float* dy, int lddy, const float* a, int lda,
+                                               const float* bn_scale, int act, float act_alpha, float* dz, int lddz, float* dbias,
+                                               float* dsum_dy_a, float* dsum_dy, float* dz_absmax, void* workspace, size_t workspace_bytes) {
   PCNN_REQUIRE(h, h && dy && workspace, "pcnn_conv2d_epilogue_bwd: null argument");
   PCNN_REQUIRE(h, C >= 1 && C <= CS_BLOCK, "pcnn_conv2d_epilogue_bwd: C=%d unsupported", C);
   PCNN_REQUIRE(h, a || act == PCNN_ACT_LINEAR, "pcnn_conv2d_epilogue_bwd: activation output required for a non-linear activation");
@@ -362,12 +380,14 @@ extern "C" int pcnn_conv2d_epilogue_bwd(pcnn_handle h, int64_t npix, int C, cons
   float* partial = static_cast<float*>(workspace);
   const bool vec4 = C % 4 == 0 && lddy % 4 == 0 && (!a || lda % 4 == 0) && (!dz || lddz % 4 == 0) &&
                     ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0;
+  unsigned* amax = reinterpret_cast<unsigned*>(dz_absmax);
+  if (amax) (void)hipMemsetAsync(amax, 0, sizeof(unsigned), h->stream);
   if (vec4)
     hipLaunchKernelGGL(epilogue_bwd_vec4_kernel, dim3(nb), dim3(CS_BLOCK), 0, h->stream, npix, C, dy, lddy, a, lda, bn_scale, act, act_alpha,
-                       dz, lddz, partial);
+                       dz, lddz, partial, amax);
   else
     hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(nb), dim3(CS_BLOCK), 0, h->stream, npix, C, CP, dy, lddy, a, lda, bn_scale, act, act_alpha,
-                       dz, lddz, partial);
+                       dz, lddz, partial, amax);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_epilogue_bwd");
   if (dbias || dsum_dy_a || dsum_dy) {
     hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, h->stream, partial, nb, C, dbias, dsum_dy_a, dsum_dy);

@@ -200,16 +200,21 @@ class ConvUnit:
         s1 = s.bn_s1[self.bn_off:self.bn_off + self.cout] if sc is not None else None
         s2 = s.bn_s2[self.bn_off:self.bn_off + self.cout] if sc is not None else None
         trivial = self.act == 'linear' and sc is None
+        amax = None                    # max|dz|: a by-product of the epilogue pass that the split-mode weight gradient would otherwise recompute
         if trivial and not self.use_bias:
             dz = dy
         else:
+            if not trivial:
+                if getattr(self, '_amax', None) is None:
+                    self._amax = torch.zeros(1, dtype=torch.float32, device=dy.device)
+                amax = self._amax
             ops.epilogue_bwd(dy, a if (self.act != 'linear' or sc is not None) else None, act=self.act, bn_scale=sc, dz=None if trivial else dz,
-                             dbias=g[self.name + '/bias'] if self.use_bias else None, s_dy_a=s1, s_dy=s2, ws=self.ctx.ws)
+                             dbias=g[self.name + '/bias'] if self.use_bias else None, s_dy_a=s1, s_dy=s2, ws=self.ctx.ws, dz_absmax=amax)
             if trivial:
                 dz = dy
         w = s.w[self.name + '/kernel']
         ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
-                         out=g[self.name + '/kernel'], ws=self.ctx.ws)
+                         out=g[self.name + '/kernel'], ws=self.ctx.ws, dz_absmax=amax)
         if not need_dx:
             return None
         kh, kw = self.kh, self.kw

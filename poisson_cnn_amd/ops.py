@@ -175,7 +175,7 @@ def flip_transpose_weights(w, out=None):
     return wt
 
 
-def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, out=None, ws=None):
+def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, out=None, ws=None, x_absmax=None, dz_absmax=None):
     """dw (kh,kw,Cin,Cout) of the forward conv that maps x -> dz's shape."""
     N, Ho, Wo, Cout = dz.shape
     d = conv_desc(x.shape, _ld(x), w_shape, (Ho, Wo), _ld(dz), pad_top, pad_left, pad_mode, pad_value)
@@ -185,17 +185,18 @@ def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_
     dw = out if out is not None else empty(tuple(w_shape), x.device)
     assert dw.is_contiguous()
     _launch('conv_wgrad', 2.0 * N * Ho * Wo * w_shape[0] * w_shape[1] * w_shape[2] * w_shape[3],
-            lambda: handle().call('pcnn_conv2d_wgrad', byref(d), _p(x), _p(dz), _p(dw), _p(wsb), c_size_t(wsb.numel() * 4)))
+            lambda: handle().call('pcnn_conv2d_wgrad_hint', byref(d), _p(x), _p(dz), _p(dw), _p(wsb), c_size_t(wsb.numel() * 4), _p(x_absmax), _p(dz_absmax)))
     return dw
 
 
-def epilogue_bwd(dy, a, *, act='linear', bn_scale=None, dz=None, dbias=None, s_dy_a=None, s_dy=None, ws=None):
+def epilogue_bwd(dy, a, *, act='linear', bn_scale=None, dz=None, dbias=None, s_dy_a=None, s_dy=None, ws=None, dz_absmax=None):
+    """dz_absmax: optional 1-element device tensor that receives max|dz| (a free by-product; conv2d_wgrad takes it as a hint)."""
     N, H, W, C = dy.shape
     lib = _lib.load()
     wsb = (ws or _default_ws).get(lib.pcnn_colsum_workspace(c_int(C)), dy.device)
-    handle().call('pcnn_conv2d_epilogue_bwd', c_int64(N * H * W), c_int(C), _p(dy), c_int(_ld(dy)), _p(a), c_int(_ld(a) if a is not None else 0),
+    handle().call('pcnn_conv2d_epilogue_bwd_absmax', c_int64(N * H * W), c_int(C), _p(dy), c_int(_ld(dy)), _p(a), c_int(_ld(a) if a is not None else 0),
                   _p(bn_scale), c_int(ACTS[act]), c_float(LEAKY_ALPHA), _p(dz), c_int(_ld(dz) if dz is not None else 0),
-                  _p(dbias), _p(s_dy_a), _p(s_dy), _p(wsb), c_size_t(wsb.numel() * 4))
+                  _p(dbias), _p(s_dy_a), _p(s_dy), _p(dz_absmax), _p(wsb), c_size_t(wsb.numel() * 4))
     return dz
 
 
