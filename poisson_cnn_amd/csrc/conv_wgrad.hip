@@ -354,6 +354,7 @@ struct SplitPlanes {
   int64_t nquad[2]; int cq[2]; int C[2]; int ld[2]; int vec[2];     // quads in total, quads per pixel, channels, source channel stride, 1 = float4-loadable, 2 = and dense
   unsigned* maxbits;
   const float* hint[2];                                              // device max|.| supplied by the caller (NULL: computed by split_absmax_kernel)
+  int zN, zHo, zWo, zTY, zWp, zC, zCp;                                // dz unit planes: [N][TY = ceil(Ho/8)][Wp = 32*ceil(Wo/32)][Cp] units of 8 rows
 };
 
 // channels 4q .. 4q+3 of one pixel; channels past C read as zero (the planes are padded to a multiple of 4 channels)
@@ -432,16 +433,49 @@ __global__ __launch_bounds__(256) void split_convert_kernel(SplitPlanes sp) {
   }
 }
 
+// dz is consumed as the B operand straight from global memory, so its planes are written in the MFMA unit layout: one 16-byte
+// unit = the 8 rows of a tile row-block for one (column, channel), units ordered [n][row block][column][channel position], channel
+// 4q + j at position j*Cp/4 + q (the same order the x tile uses in LDS).  Rows past Ho, columns past Wo and channels past C are zero.
+__global__ __launch_bounds__(256) void split_convert_dz_units_kernel(SplitPlanes sp) {
+  const float* src = sp.src[1];
+  const int GZ = sp.zCp >> 2, ld = sp.ld[1], C = sp.zC, vec = sp.vec[1];
+  float s, inv_s;
+  pow2_scale(__uint_as_float(sp.maxbits[1]), s, inv_s);
+  f16x8* hi = reinterpret_cast<f16x8*>(sp.hi[1]);
+  f16x8* lo = reinterpret_cast<f16x8*>(sp.lo[1]);
+  const int64_t total = (int64_t)sp.zN * sp.zTY * sp.zWp * GZ;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i % GZ); int64_t r = i / GZ; const int x = (int)(r % sp.zWp); r /= sp.zWp; const int ty = (int)(r % sp.zTY); const int n = (int)(r / sp.zTY);
+    f32x4 v[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int y = ty * 8 + rr;
+      if (y < sp.zHo && x < sp.zWo) v[rr] = load_quad(src, ((int64_t)n * sp.zHo + y) * sp.zWo * (int64_t)GZ + (int64_t)x * GZ + q, GZ, C, ld, vec);
+      else v[rr] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t ubase = (((int64_t)n * sp.zTY + ty) * sp.zWp + x) * sp.zCp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x8 h8, l8;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) { const float a = v[rr][j] * s; const _Float16 ah = (_Float16)a; h8[rr] = ah; l8[rr] = (_Float16)(a - (float)ah); }
+      hi[ubase + j * GZ + q] = h8; lo[ubase + j * GZ + q] = l8;
+    }
+  }
+}
+
 struct WgradSplitParams {
   WgradParams b;
-  const _Float16* xh; const _Float16* xl; const _Float16* zh; const _Float16* zl;
+  const _Float16* xh; const _Float16* xl; const _Float16* zh; const _Float16* zl;   // x: dense NHWC planes; dz: unit planes (see the dz convert kernel)
   const unsigned* maxbits;
+  int zTY, zWp;
 };
 
 // Software pipeline: the two co-resident workgroups of a CU run in lock-step (same work, same start), so their load and MFMA
 // phases do NOT overlap by themselves.  Each workgroup therefore prefetches its NEXT tile from the planes into registers
-// (XR task rounds for x, one for dz; 8-byte loads, in flight during the MFMA loop) and only the register transpose + LDS
-// writes sit between two MFMA loops.  Accumulators: one fp32 set per wave, folded into the workgroup's partial-sum slot in
+// (XR task rounds of 8-byte loads, in flight during the MFMA loop) and only the register transpose + LDS writes sit between two
+// MFMA loops.  The dz (B) fragments are not staged at all: the pre-pass wrote them in fragment order, each wave loads its pair
+// (hi, lo) of the next K step from global/L2 while the MFMAs of the current step run - like the filter in the forward kernel.  Accumulators: one fp32 set per wave, folded into the workgroup's partial-sum slot in
 // global memory every FOLD tiles (blocked summation without a second register set - the registers hold the prefetch).
 template <int TAPS, int XR>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp) {
@@ -457,11 +491,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp
   const int TCx = WTW + p.KWG - 1;
   // units per plane; fragment over-reads (< 32 units past a plane, garbage rows/columns that are discarded) land in the next
   // plane, only the last plane needs 512 B of slack - every byte counts: k = 15, 32 channels must fit twice into 160 KiB
-  const int nux = TCx * p.Cin, nudz = WTW * p.Cout;
+  const int nux = TCx * p.Cin;
   f16x8* xh = reinterpret_cast<f16x8*>(lds);
   f16x8* xl = xh + nux;
-  f16x8* zh = xl + nux;
-  f16x8* zl = zh + nudz;
 
   float sx_, isx, sz_, isz;
   pow2_scale(__uint_as_float(sp.maxbits[0]), sx_, isx);
@@ -471,7 +503,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp
     const float a = p.pad_value * sx_; const _Float16 ah = (_Float16)a, al = (_Float16)(a - (float)ah);
     padh = (f16x4){ah, ah, ah, ah}; padl = (f16x4){al, al, al, al};
   }
-  const f16x4 zero4 = (f16x4){0, 0, 0, 0};
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -482,29 +513,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int ntile = (kwg * p.Cin + 31) >> 5;
   const int ntw = ntile > wv ? (ntile - wv + WAVES - 1) / WAVES : 0;
-  const int GX = p.Cin >> 2, GZ = p.Cout >> 2;                        // channel quads
-  const int ntask_x = TCx * GX, ntask_z = WTW * GZ;
+  const int GX = p.Cin >> 2;                                          // channel quads
+  const int ntask_x = TCx * GX;
 
-  // this thread's tasks (fixed for all tiles): x task k -> column xc[k], first channel xch[k]; dz task -> column zc, channel zch
+  // this thread's tasks (fixed for all tiles): x task k -> column xc[k], first channel xch[k]
   int xc[XR], xch[XR];
 #pragma unroll
   for (int k = 0; k < XR; ++k) { const int task = min(tid + 256 * k, ntask_x - 1); xc[k] = task / GX; xch[k] = (task - xc[k] * GX) << 2; }
-  const int ztask = min(tid, ntask_z - 1);
-  const int zc = ztask / GZ, zch = (ztask - zc * GZ) << 2;
 
-  f16x4 pxh[XR][WTH], pxl[XR][WTH], pzh[WTH], pzl[WTH];               // the prefetched tile
-  unsigned xin_mask[XR], zin_mask = 0;                                // bit r: row r of the task is inside the image
+  f16x4 pxh[XR][WTH], pxl[XR][WTH];                                   // the prefetched x tile
+  unsigned xin_mask[XR];                                              // bit r: row r of the task is inside the image
 
   // all plane addresses are (uniform base pointer) + (32-bit byte offset): hi and lo share the offset register
   const char* const bxh = reinterpret_cast<const char*>(sp.xh); const char* const bxl = reinterpret_cast<const char*>(sp.xl);
-  const char* const bzh = reinterpret_cast<const char*>(sp.zh); const char* const bzl = reinterpret_cast<const char*>(sp.zl);
   auto issue = [&](int tile) {                                        // global loads only: nothing here waits for them
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
     const int n = tt / p.tiles_y;
     const int y0 = ty * WTH, x0 = tx * WTW;
-    const unsigned xbase = (unsigned)n * p.H * p.W, zbase = (unsigned)n * p.Ho * p.Wo;   // pixels; planes are < 4 GiB (host check)
+    const unsigned xbase = (unsigned)n * p.H * p.W;                  // pixels; planes are < 4 GiB (host check)
+    // interior tiles (the x window lies inside the image: all but the border ring of tiles) need no boundary-condition index maps:
+    // the generic path below costs ~2 000 scalar instructions per tile, which is what bounds the small layers
+    const int sy0 = y0 + ki - p.pt, sx0 = x0 + kj0 - p.pl;
+    if (sy0 >= 0 && sy0 + WTH <= p.H && sx0 >= 0 && sx0 + TCx <= p.W) {
+      const unsigned row0 = xbase + (unsigned)sy0 * p.W + (unsigned)sx0, rstride = (unsigned)p.W * p.Cin * 2u;
+#pragma unroll
+      for (int k = 0; k < XR; ++k) {
+        xin_mask[k] = 0xffu;
+        unsigned e = ((row0 + (unsigned)xc[k]) * p.Cin + xch[k]) * 2u;
+#pragma unroll
+        for (int r = 0; r < WTH; ++r) {
+          pxh[k][r] = *reinterpret_cast<const f16x4*>(bxh + e);
+          pxl[k][r] = *reinterpret_cast<const f16x4*>(bxl + e);
+          e += rstride;
+        }
+      }
+      return;
+    }
     unsigned xrow[WTH]; unsigned rowmask = 0;                         // wave-uniform: x rows shifted by the filter row, BC applied
 #pragma unroll
     for (int r = 0; r < WTH; ++r) {
@@ -523,16 +569,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp
         pxl[k][r] = *reinterpret_cast<const f16x4*>(bxl + e);
       }
     }
-    const int ox = x0 + zc;
-    zin_mask = 0;
-#pragma unroll
-    for (int r = 0; r < WTH; ++r) {
-      const bool in = y0 + r < p.Ho && ox < p.Wo;
-      if (in) zin_mask |= 1u << r;
-      const unsigned e = ((zbase + (unsigned)(in ? y0 + r : 0) * p.Wo + (unsigned)(in ? ox : 0)) * p.Cout + zch) * 2u;
-      pzh[r] = *reinterpret_cast<const f16x4*>(bzh + e);
-      pzl[r] = *reinterpret_cast<const f16x4*>(bzl + e);
-    }
   };
 
   auto stage = [&]() {                                                // register transpose (8 rows x 4 channels -> 4 units) + LDS writes
@@ -550,19 +586,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp
           const int u = xc[k] * p.Cin + (xch[k] >> 2) + j * GX;      // channel 4q + j sits at position j*GX + q of its column
           xh[u] = h8; xl[u] = l8;
         }
-      }
-    }
-    if (tid < ntask_z) {
-#pragma unroll
-      for (int r = 0; r < WTH; ++r)
-        if (!((zin_mask >> r) & 1u)) { pzh[r] = zero4; pzl[r] = zero4; }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f16x8 h8, l8;
-#pragma unroll
-        for (int r = 0; r < WTH; ++r) { h8[r] = pzh[r][j]; l8[r] = pzl[r][j]; }
-        const int u = zc * p.Cout + (zch >> 2) + j * GZ;
-        zh[u] = h8; zl[u] = l8;
       }
     }
   };
@@ -604,20 +627,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp
       stage();
       __syncthreads();
       if (g + 1 < FOLD && tile + p.S < p.ntiles) issue(tile + p.S);   // in flight during the MFMA loop
-      // ---- accumulate: 16 K steps of 2 columns x 8 rows
+      // ---- accumulate: 16 K steps of 2 columns x 8 rows; B (dz) fragments from the unit planes, one step ahead
+      {
+        int tt = tile;
+        const int tx = tt % p.tiles_x; tt /= p.tiles_x;
+        const int ty = tt % p.tiles_y;
+        const int n = tt / p.tiles_y;
+        const int64_t zu = (((int64_t)n * sp.zTY + ty) * sp.zWp + tx * WTW + half) * p.Cout + col;     // unit of step 0
+        const f16x8* zh_t = reinterpret_cast<const f16x8*>(sp.zh) + zu;
+        const f16x8* zl_t = reinterpret_cast<const f16x8*>(sp.zl) + zu;
+        const int zstep = 2 * p.Cout;                                 // units per K step (2 columns)
+        f16x8 bh = zh_t[0], bl = zl_t[0];
 #pragma unroll 2
-      for (int xp = 0; xp < WTW / 2; ++xp) {
-        const int cx = 2 * xp + half;
-        const f16x8 bh = zh[cx * p.Cout + col], bl = zl[cx * p.Cout + col];
+        for (int xp = 0; xp < WTW / 2; ++xp) {
+          const int cx = 2 * xp + half;
+          const f16x8 nbh = zh_t[(xp + 1) * zstep], nbl = zl_t[(xp + 1) * zstep];   // past the last step: the next tile's units (unused)
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          if (t < ntw) {
-            const int u = cx * p.Cin + (wv + WAVES * t) * 32 + col;
-            const f16x8 ah = xh[u], al = xl[u];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+          for (int t = 0; t < TAPS; ++t) {
+            if (t < ntw) {
+              const int u = cx * p.Cin + (wv + WAVES * t) * 32 + col;
+              const f16x8 ah = xh[u], al = xl[u];
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+            }
           }
+          bh = nbh; bl = nbl;
         }
       }
     }
@@ -644,13 +679,20 @@ pcnn_conv_desc padded_desc(const pcnn_conv_desc* d) {
   return pd;
 }
 size_t plane_elems_x(const pcnn_conv_desc* pd) { return (((size_t)pd->N * pd->H * pd->W * pd->Cin) + 127) & ~(size_t)127; }
-size_t plane_elems_z(const pcnn_conv_desc* pd) { return (((size_t)pd->N * pd->Ho * pd->Wo * pd->Cout) + 127) & ~(size_t)127; }
+int z_ty(const pcnn_conv_desc* pd) { return pcnn_cdiv(pd->Ho, WTH); }
+int z_wp(const pcnn_conv_desc* pd) { return pcnn_cdiv(pd->Wo, WTW) * WTW; }
+// dz unit planes: 8 * [N][TY][Wp][Cout] halfs + one K step of slack for the fragment prefetch past the last tile
+size_t plane_elems_z(const pcnn_conv_desc* pd) { return (size_t)pd->N * z_ty(pd) * z_wp(pd) * pd->Cout * 8 + (size_t)2 * 64 * pd->Cout * 8; }
 size_t plane_bytes(const pcnn_conv_desc* pd) { return 2 * sizeof(_Float16) * (plane_elems_x(pd) + plane_elems_z(pd)); }
 int split_xr(const pcnn_conv_desc* pd, const WgradPlan& pls) { return pcnn_cdiv((WTW + pls.KWG - 1) * (pd->Cin >> 2), 256); }
-size_t split_lds(const pcnn_conv_desc* pd, const WgradPlan& pls) { return ((size_t)(WTW + pls.KWG - 1) * pd->Cin + (size_t)WTW * pd->Cout) * 32 + 512; }
+size_t split_lds(const pcnn_conv_desc* pd, const WgradPlan& pls) { return (size_t)(WTW + pls.KWG - 1) * pd->Cin * 32 + 512; }
+// Grid of the split kernel: sized like the fp32 kernel's (2 workgroups per CU).  Sizing it to the split kernel's own, higher
+// occupancy limit (up to 5 per CU for the small variants) was measured: no gain - the small layers are bound by the kh-fold
+// re-read of the planes, not by latency.
+WgradPlan make_split_plan(const pcnn_conv_desc* pd) { return make_plan(pd); }
 bool split_eligible(const pcnn_conv_desc* pd, const WgradPlan& pls) {      // pd, pls: the padded layer and its plan
   const int xr = split_xr(pd, pls);
-  return pls.NTC == 1 && xr >= 1 && xr <= 3 && pls.TAPS <= 4 && WTW * (pd->Cout >> 2) <= 256 && split_lds(pd, pls) <= 160 * 1024 &&
+  return pls.NTC == 1 && xr >= 1 && xr <= 3 && pls.TAPS <= 4 && split_lds(pd, pls) <= 160 * 1024 &&
          plane_elems_x(pd) * 2 < ((size_t)1 << 32) && plane_elems_z(pd) * 2 < ((size_t)1 << 32);
 }
 
@@ -660,7 +702,7 @@ extern "C" size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d) {
   if (!d) return 0;
   const WgradPlan pl = make_plan(d);
   const pcnn_conv_desc pd = padded_desc(d);
-  const WgradPlan pls = make_plan(&pd);
+  const WgradPlan pls = make_split_plan(&pd);
   const size_t plain = partials_bytes(d, pl);
   const size_t split = split_eligible(&pd, pls) ? partials_bytes(&pd, pls) + 256 + plane_bytes(&pd) : 0;
   return plain > split ? plain : split;
@@ -678,7 +720,7 @@ extern "C" int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, co
   PCNN_REQUIRE(h, d->ldx >= d->Cin && d->ldy >= d->Cout, "pcnn_conv2d_wgrad: channel stride smaller than channel count");
   PCNN_REQUIRE(h, workspace_bytes >= pcnn_conv2d_wgrad_workspace(d), "pcnn_conv2d_wgrad: workspace too small");
   const pcnn_conv_desc pd = padded_desc(d);
-  const WgradPlan pls = make_plan(&pd);
+  const WgradPlan pls = make_split_plan(&pd);
   const bool split_ok = h->math_mode == PCNN_MATH_SPLIT_F16 && split_eligible(&pd, pls);
   const pcnn_conv_desc* ud = split_ok ? &pd : d;                       // the layer as the chosen kernel sees it
   const WgradPlan pl = split_ok ? pls : make_plan(d);
@@ -701,15 +743,20 @@ extern "C" int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, co
     pp.hi[1] = pp.lo[0] + plane_elems_x(&pd); pp.lo[1] = pp.hi[1] + plane_elems_z(&pd);
     pp.cq[0] = pd.Cin >> 2; pp.cq[1] = pd.Cout >> 2; pp.C[0] = d->Cin; pp.C[1] = d->Cout; pp.ld[0] = d->ldx; pp.ld[1] = d->ldy;
     pp.vec[0] = p.vecx ? (d->ldx == d->Cin ? 2 : 1) : 0; pp.vec[1] = p.vecdz ? (d->ldy == d->Cout ? 2 : 1) : 0;   // 2 = dense
+    pp.zN = d->N; pp.zHo = d->Ho; pp.zWo = d->Wo; pp.zTY = z_ty(&pd); pp.zWp = z_wp(&pd); pp.zC = d->Cout; pp.zCp = pd.Cout;
     pp.nquad[0] = (int64_t)d->N * d->H * d->W * pp.cq[0]; pp.nquad[1] = (int64_t)d->N * d->Ho * d->Wo * pp.cq[1];
     (void)hipMemsetAsync(pp.maxbits, 0, 8, h->stream);
     const int64_t nq = std::max(pp.nquad[0], pp.nquad[1]);
     const unsigned gx = (unsigned)std::min<int64_t>(pcnn_cdiv64(nq, 256 * 4), 4096);
     hipLaunchKernelGGL(split_absmax_kernel, dim3(gx, 2), dim3(256), 0, h->stream, pp);
-    hipLaunchKernelGGL(split_convert_kernel, dim3(gx, 2), dim3(256), 0, h->stream, pp);
+    hipLaunchKernelGGL(split_convert_kernel, dim3(gx, 1), dim3(256), 0, h->stream, pp);          // x -> dense NHWC planes
+    {
+      const int64_t zt = (int64_t)pp.zN * pp.zTY * pp.zWp * (pp.zCp >> 2);
+      hipLaunchKernelGGL(split_convert_dz_units_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(zt, 256), 8192)), dim3(256), 0, h->stream, pp);
+    }
     PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(split planes)");
     WgradSplitParams sp;
-    sp.b = p; sp.xh = pp.hi[0]; sp.xl = pp.lo[0]; sp.zh = pp.hi[1]; sp.zl = pp.lo[1]; sp.maxbits = pp.maxbits;
+    sp.b = p; sp.xh = pp.hi[0]; sp.xl = pp.lo[0]; sp.zh = pp.hi[1]; sp.zl = pp.lo[1]; sp.maxbits = pp.maxbits; sp.zTY = pp.zTY; sp.zWp = pp.zWp;
     const size_t lds = split_lds(&pd, pl);
 #define PCNN_WGS(T, R) if (pl.TAPS == T && xr == R) launch_wgrad_split<T, R>(h, sp, pl, lds); else
     PCNN_WGS(1, 1) PCNN_WGS(1, 2) PCNN_WGS(1, 3) PCNN_WGS(2, 1) PCNN_WGS(2, 2) PCNN_WGS(2, 3)
