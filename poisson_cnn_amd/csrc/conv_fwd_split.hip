@@ -77,19 +77,27 @@ __global__ __launch_bounds__(256, NT == 1 ? (MT == 2 ? 4 : 2) : 1) void conv_fwd
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc[m][t][i] = 0.f; tot[m][t][i] = 0.f; }
 
+  // source pixel of every halo slot of this thread (boundary-condition index maps applied), computed once: the same for all chunks.
+  // -1: outside the image under CONSTANT padding; -2: slot beyond the tile
+  int soff[MAXPIX];
+#pragma unroll
+  for (int q = 0; q < MAXPIX; ++q) {
+    const int u = tid + 256 * q;
+    const int uu = u < npix ? u : 0;
+    const int r = uu / TC, c = uu - r * TC;
+    const int sy = pcnn_pad_index(y0 + r - p.pt, p.H, p.pad_mode);
+    const int sx = pcnn_pad_index(x0 + c - p.pl, p.W, p.pad_mode);
+    soff[q] = u >= npix ? -2 : ((sy >= 0 && sx >= 0) ? sy * p.W + sx : -1);
+  }
+
   for (int c0 = 0; c0 < cin_pad; c0 += 8) {
     // ---- load this chunk's halo pixels (8 channels each) into registers, padding applied
     f32x4 va[MAXPIX], vb[MAXPIX];
     float mx = 0.f;
 #pragma unroll
     for (int q = 0; q < MAXPIX; ++q) {
-      const int u = tid + 256 * q;
-      const int uu = u < npix ? u : 0;
-      const int r = uu / TC, c = uu - r * TC;
-      const int sy = pcnn_pad_index(y0 + r - p.pt, p.H, p.pad_mode);
-      const int sx = pcnn_pad_index(x0 + c - p.pl, p.W, p.pad_mode);
-      const bool inimg = sy >= 0 && sx >= 0;
-      const float* src = xin + ((int64_t)(inimg ? sy : 0) * p.W + (inimg ? sx : 0)) * p.ldx;
+      const bool inimg = soff[q] >= 0;
+      const float* src = xin + (int64_t)(inimg ? soff[q] : 0) * p.ldx;
       f32x4 a, b;
       if (p.vec_ok && c0 + 7 < p.Cin) {
         a = *reinterpret_cast<const f32x4*>(src + c0);
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256, NT == 1 ? (MT == 2 ? 4 : 2) : 1) void conv_fwd
         if (c0 + j >= p.Cin) a[j] = 0.f;
         if (c0 + 4 + j >= p.Cin) b[j] = 0.f;
       }
-      if (u >= npix) { a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a; }
+      if (soff[q] == -2) { a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a; }
       va[q] = a; vb[q] = b;
 #pragma unroll
       for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(fabsf(a[j]), fabsf(b[j])));
