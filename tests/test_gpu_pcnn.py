@@ -100,3 +100,18 @@ def test_training_cli_runs(which, tmp_path):
     path.write_text(json.dumps(cfg))
     train.main([str(path), '--model', which, '--checkpoint_dir', str(tmp_path), '--epochs', '1'])
     assert any(f.startswith('chkpt') for f in os.listdir(tmp_path))
+
+
+def test_forward_matches_committed_golden_vectors():
+    """HIP forward vs the committed oracle fixtures (tests/golden/make_dbcnn_golden.py)."""
+    import os
+    from poisson_cnn_amd.models import Dirichlet_BC_NN_Legacy_2
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dbcnn_forward_golden.npz'))
+    cfg = configs.dbcnn()['model']
+    model = Dirichlet_BC_NN_Legacy_2(**cfg)
+    model.set_weights(odb.init_params(cfg, seed=7, gain=1.3, randomize_all=True))
+    y = model([g['dbcnn_bc'], g['dbcnn_dx'], 96]).cpu().numpy()
+    assert rel(y, g['dbcnn_out']) < 1e-5
+    pm, *_ = _build()
+    y = pm([g['pcnn_' + k] for k in ('rhs', 'left', 'top', 'right', 'bottom', 'dx')]).cpu().numpy()
+    assert rel(y, g['pcnn_out']) < 1e-5

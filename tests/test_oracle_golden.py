@@ -80,3 +80,15 @@ def test_dbcnn_oracle_structure_and_invariants():
     y = odb.forward(np_ops, tiny, p, bc, dx, 25)
     assert y.shape == (2, 1, 25, 30) and np.array_equal(y[:, :, 0, :], bc)
     assert np.all(np.abs(y[:, :, 1:, :]) <= 1.0 + 1e-12)                                   # set_max_magnitude_in_batch(out, 1.0)
+
+
+def test_dbcnn_golden_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/dbcnn_forward_golden.npz (make_dbcnn_golden.py): the composite-model vectors are cheap enough to recompute on the CPU."""
+    from oracle import dbcnn as odb, hpnn as ohpnn
+    from poisson_cnn_amd import configs
+    g = np.load(os.path.join(GOLD, 'dbcnn_forward_golden.npz'))
+    hcfg, dcfg = configs.hpnn_tiny()['model'], configs.dbcnn_tiny()['model']
+    hp, dp = ohpnn.init_params(hcfg, seed=3, gain=1.5, randomize_all=True), odb.init_params(dcfg, seed=4, gain=1.5, randomize_all=True)
+    inp = [g['pcnn_' + k].astype(np.float64) for k in ('rhs', 'left', 'top', 'right', 'bottom', 'dx')]
+    y = odb.pcnn_forward(np_ops, hcfg, hp, dcfg, dp, *inp)
+    assert np.linalg.norm(y - g['pcnn_out']) / np.linalg.norm(g['pcnn_out']) < 1e-6
