@@ -69,3 +69,35 @@ def test_model_forward_and_train_step():
     t.test_forward_matches_committed_golden_vectors()
     t.test_tiny_model_train_step('neumann', 6e-4)
     t.test_hpnn_train_step_gradients('tf.nn.tanh', 3e-4)
+
+
+def test_training_trajectory_matches_fp32_mode():
+    """30 Adam steps on a fixed batch in both math modes: the split mode must follow the fp32 mode's loss trajectory (it is the more
+    accurate of the two, so any drift would be a bug, not rounding) and the loss must go down."""
+    import numpy as np
+    import torch
+    from poisson_cnn_amd import configs, ops
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    from poisson_cnn_amd.train import Adam
+    full = configs.hpnn_tiny()
+    rng = np.random.default_rng(0)
+    rhs = rng.uniform(-1, 1, (4, 1, 48, 40)).astype(np.float32)
+    dx = rng.uniform(5e-3, 5e-2, (4, 1)).astype(np.float32)
+    tgt = (rng.standard_normal((4, 1, 48, 40)) * 0.05).astype(np.float32)
+    prev = ops.get_math_mode()
+    curves = {}
+    try:
+        for mode in ('fp32', 'split_f16'):
+            ops.set_math_mode(mode)
+            model = Homogeneous_Poisson_NN_Legacy(**full['model'], seed=3)
+            model.compile(loss=loss_wrapper(global_batch_size=4, **full['training']['loss_parameters']), optimizer=Adam(learning_rate=2e-4))
+            curves[mode] = [float(model.train_step(((rhs, dx), tgt))['loss']) for _ in range(30)]
+    finally:
+        ops.set_math_mode(prev)
+    a, b = np.array(curves['fp32']), np.array(curves['split_f16'])
+    assert b[-1] < 0.97 * b[0]
+    # Adam's first steps move every weight by lr * sign(g): rounding-level gradient differences flip signs of near-zero entries, so the
+    # two trajectories separate slowly (2.7e-3 after 30 steps); they must stay close and agree at the start
+    assert np.max(np.abs(a - b)[:4] / np.abs(a)[:4]) < 1e-5
+    assert np.max(np.abs(a - b) / np.abs(a)) < 1e-2
