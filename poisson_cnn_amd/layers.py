@@ -186,7 +186,9 @@ class ConvUnit:
             self.saved = (x, a if a is not None else out, None)   # without BN/residual the output itself is the activation
         return out
 
-    def backward(self, dy, need_dx=True, inplace=False):
+    def backward(self, dy, need_dx=True, inplace=False, add_to=None):
+        """add_to: optional tensor added to the returned input gradient inside the data-gradient kernel's epilogue (a skip connection's
+        gradient); it may be overwritten."""
         x, a, bn_stats = self.saved
         self.saved = None
         s, g = self.store, self.store.g
@@ -220,9 +222,12 @@ class ConvUnit:
         kh, kw = self.kh, self.kw
         wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
         if self.mode == 'CONSTANT':
-            return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0])
+            return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to)
         gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1))
-        return ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode)
+        if add_to is not None and add_to.is_contiguous():
+            return ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode, out=add_to, accumulate=True)
+        dx = ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode)
+        return dx if add_to is None else ops.axpby(1.0, add_to, 1.0, dx)
 
 
 class resnet:
@@ -248,8 +253,7 @@ class resnet:
     def backward(self, dy, inplace=False):
         d1 = self.c2.backward(dy, inplace=inplace)           # gradient at (x + BN1(a1))
         d0 = self.c1.backward(d1, inplace=False)              # d1 is still needed for the skip connection
-        dx = self.c0.backward(d0, inplace=True)
-        return ops.axpby(1.0, d1, 1.0, dx)
+        return self.c0.backward(d0, inplace=True, add_to=d1)      # + the skip connection's gradient, fused into the epilogue
 
 
 # ----------------------------------------------------------------------------- bottleneck blocks
