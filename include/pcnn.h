@@ -69,6 +69,10 @@ typedef struct {
 
 int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias,
                     const float* bn_scale, const float* bn_shift, const float* residual, float* y, float* act_out);
+/* Same, and y_absmax[0] = max|y| over the tensor (device float, NULL = skip): when y is the input of the next convolution, that
+ * layer's weight gradient takes it as its x_absmax hint (pcnn_conv2d_wgrad_hint) */
+int pcnn_conv2d_fwd_absmax(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias,
+                           const float* bn_scale, const float* bn_shift, const float* residual, float* y, float* act_out, float* y_absmax);
 
 /* w (kh,kw,Cin,Cout) -> wt (kh,kw,Cout,Cin) with both taps reversed: the filter of the data-gradient convolution. */
 int pcnn_conv2d_flip_transpose_weights(pcnn_handle h, const float* w, float* wt, int kh, int kw, int Cin, int Cout);

@@ -10,6 +10,7 @@ struct ConvEpilogue {
   const float* bias; const float* bn_scale; const float* bn_shift; const float* res; float* y; float* act_out;
   int Ho, Wo, Cout, ldy, ld_res, ld_act, act; float alpha;
   int vec;                    // Cout, ldy, ld_res, ld_act multiples of 4 and y / res / act_out 16-byte aligned
+  unsigned* absmax;           // optional: receives max|y| (float bits) - the weight gradient of the NEXT layer scales its x by it
 };
 
 static inline int conv_epilogue_vec_ok(int Cout, const float* y, int ldy, const float* res, int ld_res, const float* act_out, int ld_act) {
@@ -20,6 +21,18 @@ static inline int conv_epilogue_vec_ok(int Cout, const float* y, int ldy, const 
 }
 static inline size_t conv_epilogue_lds_bytes(int Cout) { return (size_t)4 * 32 * ((Cout + 3) & ~3) * sizeof(float); }
 
+__device__ __forceinline__ void conv_epilogue_absmax(unsigned* absmax, float v) {
+  if (!absmax) return;                 // uniform
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  // tens of thousands of waves would otherwise serialise on one address: the running maximum only grows, so a wave whose value does not
+  // exceed what it reads (possibly stale, i.e. lower) can skip the atomic; after the first few workgroups nearly all do
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned bits = __float_as_uint(v <= 3.0e38f ? v : 3.0e38f);
+    if (bits > __atomic_load_n(absmax, __ATOMIC_RELAXED)) atomicMax(absmax, bits);
+  }
+}
+
 // tot[m][t][i]: wave w owns output rows y0 + w*MT + m; lane (col = lane & 31, half = lane >> 5): channel t*32 + col, pixel
 // x0 + 8*(i>>2) + 4*half + (i&3).  `mul` scales the accumulator (1 for the fp32 kernel).  `stage`: >= conv_epilogue_lds_bytes()
 // of LDS that no wave still reads (the function starts with a barrier).  All 256 threads must call it.
@@ -27,6 +40,7 @@ template <int MT, int NT, typename Acc>
 __device__ __forceinline__ void conv_epilogue_store(const Acc (&tot)[MT][NT], float mul, const ConvEpilogue& e, int n, int y0, int x0,
                                                     float* __restrict__ stage) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  float ymax = 0.f;
   if (!e.vec) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -50,9 +64,11 @@ __device__ __forceinline__ void conv_epilogue_store(const Acc (&tot)[MT][NT], fl
           v = v * sc + sh;
           if (e.res) v += e.res[pix * e.ld_res + co];
           e.y[pix * e.ldy + co] = v;
+          ymax = fmaxf(ymax, fabsf(v));
         }
       }
     }
+    conv_epilogue_absmax(e.absmax, ymax);
     return;
   }
   const int CP = e.Cout, Q = CP >> 2, nvec = 4 * 32 * Q;
@@ -90,6 +106,8 @@ __device__ __forceinline__ void conv_epilogue_store(const Acc (&tot)[MT][NT], fl
         a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
       }
       *reinterpret_cast<float4*>(e.y + pix * e.ldy + q4) = a;
+      ymax = fmaxf(ymax, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
     }
   }
+  conv_epilogue_absmax(e.absmax, ymax);
 }

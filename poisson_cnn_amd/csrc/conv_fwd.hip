@@ -31,6 +31,7 @@ struct ConvParams {
   int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, pt, pl, pad_mode; float pad_value; int act; float alpha;
   int ld_res, ld_act;
   int tiles_x, tiles_y, CK, PS, vec_ok, epi_vec;
+  unsigned* y_absmax;
   const float* wp;   // packed filter, see pack_weights_kernel
 };
 
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv_fwd_kernel(ConvPara
   ConvEpilogue e;
   e.bias = p.bias; e.bn_scale = p.bn_scale; e.bn_shift = p.bn_shift; e.res = p.res; e.y = p.y; e.act_out = p.act_out;
   e.Ho = p.Ho; e.Wo = p.Wo; e.Cout = p.Cout; e.ldy = p.ldy; e.ld_res = p.ld_res; e.ld_act = p.ld_act; e.act = p.act; e.alpha = p.alpha;
-  e.vec = p.epi_vec;
+  e.vec = p.epi_vec; e.absmax = p.y_absmax;
   conv_epilogue_store<MT, NT>(tot, 1.0f, e, n, y0, x0, lds);
 }
 
@@ -202,6 +203,16 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
 }
 
 }  // namespace
+
+extern "C" int pcnn_conv2d_fwd_absmax(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias,
+                                      const float* bn_scale, const float* bn_shift, const float* residual, float* y, float* act_out, float* y_absmax) {
+  PCNN_REQUIRE(h, h != nullptr, "pcnn_conv2d_fwd_absmax: null handle");
+  if (y_absmax) (void)hipMemsetAsync(y_absmax, 0, sizeof(float), h->stream);
+  h->y_absmax = y_absmax;
+  const int rc = pcnn_conv2d_fwd(h, d, x, w, bias, bn_scale, bn_shift, residual, y, act_out);
+  h->y_absmax = nullptr;
+  return rc;
+}
 
 extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias,
                                const float* bn_scale, const float* bn_shift, const float* residual, float* y, float* act_out) {
@@ -240,6 +251,7 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
   }
   p.CK = CK; p.PS = ((CK / 4) % 2 == 0) ? CK + 4 : CK;
   p.epi_vec = conv_epilogue_vec_ok(d->Cout, y, d->ldy, residual, d->ld_res, act_out, d->ld_act_out);
+  p.y_absmax = reinterpret_cast<unsigned*>(h->y_absmax);
   const size_t lds = std::max((size_t)TR * TC * p.PS * 4, conv_epilogue_lds_bytes(d->Cout));
   PCNN_REQUIRE(h, lds <= 160 * 1024, "pcnn_conv2d_fwd: halo tile needs %zu B of LDS", lds);
   {

@@ -33,6 +33,7 @@ struct SplitParams {
   int64_t wplane;             // f16x8 elements per plane
   int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, kh, kw, pt, pl, pad_mode; float pad_value; int act; float alpha;
   int ld_res, ld_act, tiles_x, tiles_y, vec_ok, epi_vec;
+  unsigned* y_absmax;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256, NT == 1 ? (MT == 2 ? 4 : 2) : 1) void conv_fwd
   ConvEpilogue e;
   e.bias = p.bias; e.bn_scale = p.bn_scale; e.bn_shift = p.bn_shift; e.res = p.res; e.y = p.y; e.act_out = p.act_out;
   e.Ho = p.Ho; e.Wo = p.Wo; e.Cout = p.Cout; e.ldy = p.ldy; e.ld_res = p.ld_res; e.ld_act = p.ld_act; e.act = p.act; e.alpha = p.alpha;
-  e.vec = p.epi_vec;
+  e.vec = p.epi_vec; e.absmax = p.y_absmax;
   conv_epilogue_store<MT, NT>(tot, inv_sw, e, n, y0, x0, reinterpret_cast<float*>(smem));
 }
 
@@ -287,6 +288,7 @@ int pcnn_conv2d_fwd_split(pcnn_handle h, const pcnn_conv_desc* d, const float* x
   p.tiles_x = pcnn_cdiv(d->Wo, TW); p.tiles_y = pcnn_cdiv(d->Ho, TH);
   p.vec_ok = (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   p.epi_vec = conv_epilogue_vec_ok(d->Cout, y, d->ldy, residual, d->ld_res, act_out, d->ld_act_out);
+  p.y_absmax = reinterpret_cast<unsigned*>(h->y_absmax);
   const size_t lds = std::max((size_t)TR * TC * 32 + 64, conv_epilogue_lds_bytes(d->Cout));
   const int64_t nblk = (int64_t)d->N * p.tiles_x * p.tiles_y;
   if (nblk >= (1ll << 31)) return -1;

@@ -13,6 +13,7 @@ struct pcnn_handle_s {
   void* scratch = nullptr;        // packed-filter scratch of the conv kernels (grown on demand, owned by the handle)
   size_t scratch_bytes = 0;
   int math_mode = 0;              // PCNN_MATH_FP32 (exact fp32 MFMA) or PCNN_MATH_SPLIT_F16 (3 x fp16 split, fp32 accumulate)
+  float* y_absmax = nullptr;      // set by pcnn_conv2d_fwd_absmax for the duration of one forward launch: receives max|y|
 };
 
 #define PCNN_FAIL(h, ...)                                   \

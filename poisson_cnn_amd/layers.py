@@ -162,7 +162,10 @@ class ConvUnit:
         s = self.store
         return s.bn_scale[self.bn_off:self.bn_off + self.cout], s.bn_shift[self.bn_off:self.bn_off + self.cout]
 
-    def forward(self, x, residual=None, out=None, training=True):
+    def forward(self, x, residual=None, out=None, training=True, x_absmax=None):
+        """x_absmax: optional 1-element device tensor holding max|x| (the producing layer's `out_absmax`): saved for the weight gradient,
+        which would otherwise spend a pass over x on it (split math mode).  After the call `self.out_absmax` holds this layer's."""
+        self.out_absmax = None
         w = self.store.w[self.name + '/kernel']
         b = self.store.w[self.name + '/bias'] if self.use_bias else None
         sc, sh = self._bn()
@@ -176,20 +179,22 @@ class ConvUnit:
             sw = self.store.w
             _, stats = ops.bn_train_forward(a, sw[self.bn_name + '/gamma'], sw[self.bn_name + '/beta'], sw[self.bn_name + '/moving_mean'],
                                             sw[self.bn_name + '/moving_variance'], residual=residual, out=out, ws=self.ctx.ws)
-            self.saved = (x, a, stats)
+            self.saved = (x, a, stats, x_absmax)
             return out
         need_a = training and (sc is not None or residual is not None)
         a = ops.empty((N, H, W, self.cout), x.device) if need_a else None
-        ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
-                       bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a)
         if training:
-            self.saved = (x, a if a is not None else out, None)   # without BN/residual the output itself is the activation
+            self.out_absmax = ops.empty((1,), x.device)          # a fresh buffer per call: a layer may run several times per step
+        ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
+                       bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a, y_absmax=self.out_absmax)
+        if training:
+            self.saved = (x, a if a is not None else out, None, x_absmax)   # without BN/residual the output itself is the activation
         return out
 
     def backward(self, dy, need_dx=True, inplace=False, add_to=None):
         """add_to: optional tensor added to the returned input gradient inside the data-gradient kernel's epilogue (a skip connection's
         gradient); it may be overwritten."""
-        x, a, bn_stats = self.saved
+        x, a, bn_stats, x_absmax = self.saved
         self.saved = None
         s, g = self.store, self.store.g
         N, H, W, _ = x.shape
@@ -216,7 +221,7 @@ class ConvUnit:
                 dz = dy
         w = s.w[self.name + '/kernel']
         ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
-                         out=g[self.name + '/kernel'], ws=self.ctx.ws, dz_absmax=amax)
+                         out=g[self.name + '/kernel'], ws=self.ctx.ws, x_absmax=x_absmax, dz_absmax=amax)
         if not need_dx:
             return None
         kh, kw = self.kh, self.kw
@@ -245,10 +250,12 @@ class resnet:
                 c.bn_name = '%s/bn%d' % (name, i)
                 c.bn_off = store.add_bn(c.bn_name, filters)
 
-    def forward(self, x, out=None, training=True):
-        o = self.c0.forward(x, training=training)
-        o = self.c1.forward(o, residual=x, training=training)
-        return self.c2.forward(o, out=out, training=training)
+    def forward(self, x, out=None, training=True, x_absmax=None):
+        o = self.c0.forward(x, training=training, x_absmax=x_absmax)
+        o = self.c1.forward(o, residual=x, training=training, x_absmax=self.c0.out_absmax)
+        o = self.c2.forward(o, out=out, training=training, x_absmax=self.c1.out_absmax)
+        self.out_absmax = self.c2.out_absmax
+        return o
 
     def backward(self, dy, inplace=False):
         d1 = self.c2.backward(dy, inplace=inplace)           # gradient at (x + BN1(a1))
@@ -280,8 +287,10 @@ class _bottleneck_base:
         self.x = x if training else None
         o = ops.pool2d_fwd(x, self.f, self.pool)
         o = self.conv0.forward(o, training=training)
+        hint = self.conv0.out_absmax
         for r in self.res:
-            o = r.forward(o, training=training)
+            o = r.forward(o, training=training, x_absmax=hint)
+            hint = r.out_absmax
         return o
 
     def _backward_convs_and_down(self, dcoarse, d_in):

@@ -253,8 +253,10 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         x = ops.assemble_input(rhs_hw, self.use_positional_embeddings)
         # dense input [dx, Lx, Ly] (:193,:202): tiny (N,3) host-side assembly
         dense_inp = torch.cat([dx, dx * float(H - 1), dx * float(W - 1)], 1).contiguous()
+        hint = None                                               # max|x| travels with the tensor from layer to layer (weight-gradient scaling)
         for c in self.pre:
-            x = c.forward(x, training=training)
+            x = c.forward(x, training=training, x_absmax=hint)
+            hint = c.out_absmax
         initial = x
         F = self.filters
         cat = ops.empty((N, H, W, 2 * F), self.device)       # [non_bottleneck_conv | merged] (tf.concat axis=1, :224)
@@ -265,7 +267,7 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
             b.forward_into(initial, merged, alpha, 0.0 if i == 0 else 1.0, training=training)
         self.non_bottleneck_conv.forward(initial, out=cat[..., :F], training=training)
         x = self.post_merge_conv.forward(cat, training=training)
-        x = self.post_merge_resnet.forward(x, training=training)
+        x = self.post_merge_resnet.forward(x, training=training, x_absmax=self.post_merge_conv.out_absmax)
         d = dense_inp
         for lyr in self.dx_dense_layers:
             d = lyr.forward(d, training=training)
@@ -273,8 +275,10 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         if training:
             self._saved = {'initial': initial, 'scale_in': x, 'dx_info': d, 'shape': (N, H, W)}
         x = xs
+        hint = None
         for lyr in self.final:
-            x = lyr.forward(x, training=training)
+            x = lyr.forward(x, training=training, x_absmax=hint)
+            hint = lyr.out_absmax
         if self.scaling is not None:
             x = self.scaling.forward(x, rhs_hw.view(N, H, W, 1), training=training)
         x = ops.bc_ring_fwd(x, self.neumann)                      # :251
@@ -463,8 +467,10 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         S.refresh_bn()
         bc2 = bc.reshape(N, Lh)
         o = ops.dbc_assemble_input(bc2)
+        hint = None
         for lyr in self.boundary:
-            o = lyr.forward(o, training=training)
+            o = lyr.forward(o, training=training, x_absmax=hint)
+            hint = lyr.out_absmax
         bc_conv = o                                                            # (N,1,L,M)
         bins = self._bin_table(Lh)
         feats = ops.spp_avg_fwd(bc_conv, bins)
@@ -474,8 +480,10 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
             d = lyr.forward(d, training=training)
         sh = self._sinh_table(X)
         x = ops.dbc_expand_fwd(bc_conv, sh, d)                                # (N,X,L,M+2)
+        hint = None
         for lyr in self.final:
-            x = lyr.forward(x, training=training)
+            x = lyr.forward(x, training=training, x_absmax=hint)
+            hint = lyr.out_absmax
         pre = x.view(N, X, Lh)
         out, _ = ops.set_max_magnitude_fwd(pre, 1.0)                          # (:163)
         ops.set_first_row(out, bc2)                                           # (:165-166)

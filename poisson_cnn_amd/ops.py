@@ -153,7 +153,7 @@ def conv_desc(x_shape, ldx, w_shape, out_hw, ldy, pad_top, pad_left, pad_mode='C
 
 
 def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CONSTANT', pad_value=0.0, act='linear',
-               bn_scale=None, bn_shift=None, residual=None, out=None, act_out=None):
+               bn_scale=None, bn_shift=None, residual=None, out=None, act_out=None, y_absmax=None):
     N, H, W, Cin = x.shape
     kh, kw, ci, Cout = w.shape
     assert w.is_contiguous()
@@ -163,7 +163,8 @@ def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CON
     d = conv_desc(x.shape, _ld(x), w.shape, (Ho, Wo), _ld(out), pad_top, pad_left, pad_mode, pad_value, act,
                   _ld(residual) if residual is not None else 0, _ld(act_out) if act_out is not None else 0)
     _launch('conv_fwd', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout,
-            lambda: handle().call('pcnn_conv2d_fwd', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out)),
+            lambda: handle().call('pcnn_conv2d_fwd_absmax', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out),
+                                  _p(y_absmax)),
             4.0 * (N * H * W * Cin + N * Ho * Wo * Cout * (1 + (residual is not None) + (act_out is not None)) + kh * kw * Cin * Cout))
     return out
 
