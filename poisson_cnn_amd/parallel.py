@@ -24,7 +24,7 @@ class DataParallel:
         if torch.cuda.is_available():
             torch.cuda.set_device(lr % max(torch.cuda.device_count(), 1))
         if ws > 1 and not dist.is_initialized():
-            backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+            backend = backend or os.environ.get('PCNN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             dist.init_process_group(backend=backend, rank=rank, world_size=ws)
