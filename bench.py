@@ -76,7 +76,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--math', default='split_f16', choices=['split_f16', 'fp32'],
                     help='convolution GEMM arithmetic: 3 x fp16 split MFMA with fp32 accumulate (fp32-accurate, default) or plain fp32 MFMA')
+    ap.add_argument('--overlap-wgrad', type=int, default=0, choices=[0, 1],
+                    help='1: run the weight gradients on a second HIP stream, overlapping them with the data-gradient convolutions (the library '
+                         'default; ~3 %% faster end to end).  Default 0 here: with two kernels sharing the chip a launch\'s duration is no '
+                         'longer attributable to it, so the roofline block would stop describing the kernel')
     args = ap.parse_args()
+    os.environ['PCNN_WGRAD_STREAM'] = str(args.overlap_wgrad)
 
     from poisson_cnn_amd import configs, ops, parallel
     from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
@@ -147,7 +152,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': '%s: Homogeneous_Poisson_NN_Legacy(hpnn.json) full train step (fwd+bwd+loss+Adam%s), %d x %dx%d Dirichlet grids per GPU'
                                    % (args.workload, '+RCCL all-reduce' if dp.world_size > 1 else '', per_gpu, H, W),
-                       'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': args.math, 'final_loss': loss},
+                       'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': args.math, 'overlap_wgrad': bool(args.overlap_wgrad), 'final_loss': loss},
             'roofline': {'bound': 'mfma', 'kernel': ('conv_fwd_kernel' if args.math == 'fp32' else 'conv_fwd_split_kernel') + ' (fused pad+conv fwd and data-gradient; all launches of a step)', 'achieved': flops / secs / 1e12 if secs else None,
                          'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)', 'frac': flops / secs / 1e12 / peak if secs else None,
                          'traffic': traffic, 'algorithmic_bytes_per_launch': prof.total_bytes('conv_fwd') / calls if calls else None, 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)' % pmc_name, 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,

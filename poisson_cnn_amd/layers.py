@@ -120,6 +120,28 @@ class Context:
     def __init__(self):
         self.ws = ops.Workspace()
         self._wflip = None
+        # Weight gradients run on a second HIP stream: their HBM-bound pre-pass (abs-max, fp16 plane conversion) and the kernel itself
+        # overlap with the clock-bound data-gradient convolution of the same layer on the main stream (PCNN_WGRAD_STREAM=0 disables).
+        import os
+        self.use_side = False                                  # the model classes switch it on (they join() at the end of backward())
+        self.side_allowed = os.environ.get('PCNN_WGRAD_STREAM', '1') != '0'
+        self.side = None
+        self.ws_side = ops.Workspace()
+
+    def enable_side_stream(self):
+        self.use_side = self.side_allowed
+
+    def side_stream(self):
+        if not self.use_side:
+            return None
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        return self.side
+
+    def join(self):
+        """Main stream waits for the weight gradients enqueued on the side stream (call before the gradients are consumed)."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def wflip(self, shape, device):
         n = int(np.prod(shape))
@@ -212,16 +234,26 @@ class ConvUnit:
             dz = dy
         else:
             if not trivial:
-                if getattr(self, '_amax', None) is None:
-                    self._amax = torch.zeros(1, dtype=torch.float32, device=dy.device)
-                amax = self._amax
+                amax = ops.empty((1,), dy.device)             # fresh per call: read later by the side-stream weight gradient
             ops.epilogue_bwd(dy, a if (self.act != 'linear' or sc is not None) else None, act=self.act, bn_scale=sc, dz=None if trivial else dz,
                              dbias=g[self.name + '/bias'] if self.use_bias else None, s_dy_a=s1, s_dy=s2, ws=self.ctx.ws, dz_absmax=amax)
             if trivial:
                 dz = dy
         w = s.w[self.name + '/kernel']
-        ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
-                         out=g[self.name + '/kernel'], ws=self.ctx.ws, x_absmax=x_absmax, dz_absmax=amax)
+        side = self.ctx.side_stream()
+        if side is None:
+            ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
+                             out=g[self.name + '/kernel'], ws=self.ctx.ws, x_absmax=x_absmax, dz_absmax=amax)
+        else:
+            ev = torch.cuda.Event()
+            ev.record()                                        # dz (and max|dz|) are complete on the main stream here
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                for t in (x, dz, x_absmax, amax):              # keep the allocator from recycling them while the side stream reads
+                    if t is not None:
+                        t.record_stream(side)
+                ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
+                                 out=g[self.name + '/kernel'], ws=self.ctx.ws_side, x_absmax=x_absmax, dz_absmax=amax)
         if not need_dx:
             return None
         kh, kw = self.kh, self.kw

@@ -168,6 +168,7 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         # SURVEY.md row H4), True = batch statistics + moving-average update (Keras training=True semantics, per replica)
         S.bn_training = bool(batchnorm_training)
         self.ctx = C = L.Context()
+        C.enable_side_stream()
 
         # pre-bottleneck convolutions (reference :41-57)
         pre = copy.deepcopy(pre_bottleneck_convolutions_config)
@@ -317,6 +318,7 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         d = d_initial
         for i, c in enumerate(reversed(self.pre)):
             d = c.backward(d, need_dx=(i < len(self.pre) - 1), inplace=True)
+        self.ctx.join()                                            # weight gradients of the side stream
         self.store.finish_bn_grads()
 
     # ------------------------------------------------------------------ training (reference :259-296)
@@ -384,6 +386,7 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         self.store = S = L.ParamStore()
         S.bn_training = bool(batchnorm_training)
         self.ctx = C = L.Context()
+        C.enable_side_stream()
         # boundary convolutions (:44-63): per stage conv (+BN) then a 1-D resnet
         bcc = copy.deepcopy(boundary_conv_config)
         mode, val = bcc.pop('padding_mode', 'CONSTANT'), bcc.pop('constant_padding_value', 0.0)
@@ -516,6 +519,7 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         for i, lyr in enumerate(reversed(self.boundary)):
             last = i == len(self.boundary) - 1
             d = lyr.backward(d, need_dx=not last, inplace=True) if isinstance(lyr, L.ConvUnit) else lyr.backward(d, inplace=True)
+        self.ctx.join()                                            # weight gradients of the side stream
         self.store.finish_bn_grads()
 
     def train_step(self, data):
