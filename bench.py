@@ -135,11 +135,16 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (PMC collection
         # cannot be combined with the timed run); the committed summary is reported for the workload it was measured on.
         traffic = None
+        wgrad_traffic = None
         pmc_name = 'r01_c4_pmc_summary.json' if args.math == 'fp32' else 'r01_c4_pmc_summary_split.json'
         pmc = os.path.join(ROOT, 'profiles', pmc_name)
         if args.workload == 'c4' and os.path.exists(pmc):
             with open(pmc) as f:
-                ks = [v for k, v in json.load(f)['kernels'].items() if k.startswith('conv_fwd')]   # all tile variants = all 'conv_fwd' launches
+                allk = json.load(f)['kernels']
+                ks = [v for k, v in allk.items() if k.startswith('conv_fwd')]   # all tile variants = all 'conv_fwd' launches
+            wk = [v for k, v in allk.items() if k.startswith('wgrad')]
+            if wk:
+                wgrad_traffic = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in wk) / max(sum(v['launches'] for v in wk), 1)
             traffic = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in ks) / max(sum(v['launches'] for v in ks), 1)
         peak = PEAK_FP32_MFMA_TFLOPS if args.math == 'fp32' else PEAK_SPLIT_TFLOPS
         flops, secs, calls = prof.totals('conv_fwd')
@@ -157,7 +162,7 @@ def main():
                          'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)', 'frac': flops / secs / 1e12 / peak if secs else None,
                          'traffic': traffic, 'algorithmic_bytes_per_launch': prof.total_bytes('conv_fwd') / calls if calls else None, 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)' % pmc_name, 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,
                          'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / peak if ws_ else None,
-                                          'launches': wc, 'avg_launch_ms': 1e3 * ws_ / wc if wc else None}},
+                                          'launches': wc, 'avg_launch_ms': 1e3 * ws_ / wc if wc else None, 'traffic': wgrad_traffic}},
         }
         if dp.world_size == 1 and not args.no_cpu_baseline:
             note('cpu baseline (bounded sample) ...')
