@@ -478,7 +478,7 @@ struct WgradSplitParams {
 // (hi, lo) of the next K step from global/L2 while the MFMAs of the current step run - like the filter in the forward kernel.  Accumulators: one fp32 set per wave, folded into the workgroup's partial-sum slot in
 // global memory every FOLD tiles (blocked summation without a second register set - the registers hold the prefetch).
 template <int TAPS, int XR>
-__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitParams sp) {
+__global__ __launch_bounds__(256, (TAPS >= 3 && XR == 2) ? 3 : 2) void wgrad_split_kernel(WgradSplitParams sp) {
   const WgradParams& p = sp.b;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -689,7 +689,19 @@ size_t split_lds(const pcnn_conv_desc* pd, const WgradPlan& pls) { return (size_
 // Grid of the split kernel: sized like the fp32 kernel's (2 workgroups per CU).  Sizing it to the split kernel's own, higher
 // occupancy limit (up to 5 per CU for the small variants) was measured: no gain - the small layers are bound by the kh-fold
 // re-read of the planes, not by latency.
-WgradPlan make_split_plan(const pcnn_conv_desc* pd) { return make_plan(pd); }
+WgradPlan make_split_plan(const pcnn_conv_desc* pd) {
+  WgradPlan pl = make_plan(pd);
+  static const int occ3 = getenv("PCNN_WG_OCC3") ? atoi(getenv("PCNN_WG_OCC3")) : 1;
+  if (occ3 && pl.TAPS >= 3 && split_xr(pd, pl) == 2 && split_lds(pd, pl) * 3 <= 160 * 1024) {
+    // these variants are compiled for 3 workgroups per CU (168 VGPRs): size the grid for 768 slots
+    int S = 8 * ((768 / 8 * 4) / (pd->kh * pl.gz));
+    if (S < 8) S = (768 * 4) / (pd->kh * pl.gz);
+    if (S > pl.ntiles) S = pl.ntiles;
+    if (S < 1) S = 1;
+    pl.S = S;
+  }
+  return pl;
+}
 bool split_eligible(const pcnn_conv_desc* pd, const WgradPlan& pls) {      // pd, pls: the padded layer and its plan
   const int xr = split_xr(pd, pls);
   return pls.NTC == 1 && xr >= 1 && xr <= 3 && pls.TAPS <= 4 && split_lds(pd, pls) <= 160 * 1024 &&
