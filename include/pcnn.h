@@ -218,6 +218,9 @@ int pcnn_pi_loss_bwd(pcnn_handle h, int N, int H, int W, int s, const float* pre
 /* ---- optimizer: tf.keras.optimizers.Adam (train/utils.py:3-8), flat parameter bucket ---------------------------- */
 int pcnn_adam_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale);
+/* Adam(amsgrad=True): vhat = max(vhat, v) is the denominator's second moment (vhat == NULL: plain Adam) */
+int pcnn_adam_amsgrad_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m, float* v, float* vhat, float lr, float beta1,
+                           float beta2, float eps, int step, float grad_scale);
 int pcnn_sgd_step(pcnn_handle h, int64_t n, float* w, const float* g, float lr, float grad_scale);
 
 /* ---- dataset: reference-solution generators (poisson_CNN/dataset) ------------------------------------------- */

@@ -321,13 +321,15 @@ __global__ void jacobi_bwd_kernel(int N, int H, int W, const float* __restrict__
   }
 }
 
+// vhat != nullptr: the AMSGrad variant (tf.keras Adam(amsgrad=True)): the denominator uses the running maximum of v
 __global__ void adam_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            float lr_t, float beta1, float beta2, float eps, float gscale) {
+                            float* __restrict__ vhat, float lr_t, float beta1, float beta2, float eps, float gscale) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
+    if (vhat) { vi = fmaxf(vhat[i], vi); vhat[i] = vi; }
     w[i] -= lr_t * mi / (sqrtf(vi) + eps);
   }
 }
@@ -496,10 +498,15 @@ extern "C" int pcnn_jacobi_sweep_bwd(pcnn_handle h, int N, int H, int W, const f
 
 extern "C" int pcnn_adam_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                               float eps, int step, float grad_scale) {
+  return pcnn_adam_amsgrad_step(h, n, w, g, m, v, nullptr, lr, beta1, beta2, eps, step, grad_scale);
+}
+
+extern "C" int pcnn_adam_amsgrad_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m, float* v, float* vhat, float lr, float beta1,
+                                      float beta2, float eps, int step, float grad_scale) {
   PCNN_REQUIRE(h, h && w && g && m && v && step >= 1, "pcnn_adam_step: bad argument");
   // tf.keras Adam: lr_t = lr * sqrt(1-b2^t)/(1-b1^t); w -= lr_t * m / (sqrt(v) + eps)
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
-  hipLaunchKernelGGL(adam_kernel, grid1d(n), dim3(256), 0, h->stream, n, w, g, m, v, (float)lr_t, beta1, beta2, eps, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, grid1d(n), dim3(256), 0, h->stream, n, w, g, m, v, vhat, (float)lr_t, beta1, beta2, eps, grad_scale);
   PCNN_CHECK_LAUNCH(h, "pcnn_adam_step");
   return 0;
 }

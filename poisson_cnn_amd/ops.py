@@ -494,9 +494,9 @@ def pi_loss_bwd(pred, rhs, kern, coef, dpred):
     return dpred
 
 
-def adam_step(w, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    handle().call('pcnn_adam_step', c_int64(w.numel()), _p(w), _p(g), _p(m), _p(v), c_float(lr), c_float(beta1), c_float(beta2), c_float(eps),
-                  c_int(step), c_float(grad_scale))
+def adam_step(w, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, vhat=None):
+    handle().call('pcnn_adam_amsgrad_step', c_int64(w.numel()), _p(w), _p(g), _p(m), _p(v), _p(vhat), c_float(lr), c_float(beta1), c_float(beta2),
+                  c_float(eps), c_int(step), c_float(grad_scale))
 
 
 def sgd_step(w, g, lr, grad_scale=1.0):

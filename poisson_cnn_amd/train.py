@@ -30,8 +30,7 @@ class Adam(_Optimizer):
     """tf.keras.optimizers.Adam defaults (train/utils.py:3-8; experiments/hpnn.json optimizer_parameters)."""
 
     def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, **unused):
-        if amsgrad:
-            raise NotImplementedError('amsgrad=True is not used by any shipped config')
+        self.amsgrad = bool(amsgrad)
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
 
@@ -39,12 +38,13 @@ class Adam(_Optimizer):
         import torch
         self.ms = [torch.zeros_like(s.flat_w) for s in self.stores]
         self.vs = [torch.zeros_like(s.flat_w) for s in self.stores]
+        self.vhats = [torch.zeros_like(s.flat_w) if self.amsgrad else None for s in self.stores]
         self.m, self.v = self.ms[0], self.vs[0]
 
     def apply_gradients(self, grad_scale=1.0):
         self.iterations += 1
-        for s, m, v in zip(self.stores, self.ms, self.vs):
-            ops.adam_step(s.flat_w, s.flat_g, m, v, self.learning_rate, self.beta_1, self.beta_2, self.epsilon, self.iterations, grad_scale)
+        for s, m, v, vh in zip(self.stores, self.ms, self.vs, self.vhats):
+            ops.adam_step(s.flat_w, s.flat_g, m, v, self.learning_rate, self.beta_1, self.beta_2, self.epsilon, self.iterations, grad_scale, vhat=vh)
 
 
 class SGD(_Optimizer):

@@ -217,6 +217,15 @@ def test_assemble_axpby_adam():
         m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
         wr = wr - 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-7)
     assert rel(wd.cpu().numpy(), wr) < TOL
+    # AMSGrad (tf.keras Adam(amsgrad=True)): the denominator keeps the running maximum of v; gradients shrink so that it matters
+    wd, md, vd, vh = dev(w), ops.zeros((n,)), ops.zeros((n,)), ops.zeros((n,))
+    m = np.zeros(n); v = np.zeros(n); vhat = np.zeros(n); wr = w.copy()
+    for t in range(1, 5):
+        gt = g / t ** 2
+        ops.adam_step(wd, dev(gt), md, vd, 1e-3, 0.9, 0.999, 1e-7, t, vhat=vh)
+        m = 0.9 * m + 0.1 * gt; v = 0.999 * v + 0.001 * gt * gt; vhat = np.maximum(vhat, v)
+        wr = wr - 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(vhat) + 1e-7)
+    assert rel(wd.cpu().numpy(), wr) < TOL and rel(vh.cpu().numpy(), vhat) < 1e-4      # (1 - beta_2) is formed in fp32, as in Keras
 
 
 def test_loss_partials_and_bwd():
