@@ -99,3 +99,24 @@ def test_flip_transpose_and_data_gradient():
     y = np_ops.padded_conv2d(x.astype(np.float64), w.astype(np.float64), None, 'CONSTANT', 0.0, 'linear')
     lhs = float((y * dz).sum()); rhs = float((nchw(dx).astype(np.float64) * x).sum())
     assert abs(lhs - rhs) < 1e-5 * abs(lhs)
+
+
+def test_error_behaviour_of_the_c_abi():
+    """Bad arguments fail loudly through pcnn_last_error (RuntimeError in the shim), never silently: unsupported channel counts, padding
+    beyond what tf.pad allows, an undersized workspace, a null pointer."""
+    import ctypes
+    from poisson_cnn_amd import ops
+    x = torch.randn(1, 20, 20, 4, device='cuda')
+    with pytest.raises(RuntimeError, match='Cout'):
+        ops.conv2d_fwd(x, torch.randn(3, 3, 4, 80, device='cuda'), None, pad_top=1, pad_left=1)
+    with pytest.raises(RuntimeError, match='padding exceeds'):
+        ops.conv2d_fwd(torch.randn(1, 4, 4, 4, device='cuda'), torch.randn(15, 15, 4, 4, device='cuda'), None, pad_top=7, pad_left=7, pad_mode='REFLECT')
+    d = ops.conv_desc(x.shape, 4, (3, 3, 4, 4), (20, 20), 4, 1, 1)
+    dz, dw, ws = torch.randn(1, 20, 20, 4, device='cuda'), torch.empty(3, 3, 4, 4, device='cuda'), torch.empty(16, device='cuda')
+    with pytest.raises(RuntimeError, match='workspace too small'):
+        ops.handle().call('pcnn_conv2d_wgrad', ctypes.byref(d), ops._p(x), ops._p(dz), ops._p(dw), ops._p(ws), ctypes.c_size_t(64))
+    with pytest.raises(RuntimeError, match='null'):
+        ops.handle().call('pcnn_conv2d_wgrad', ctypes.byref(d), ops._p(None), ops._p(dz), ops._p(dw), ops._p(ws), ctypes.c_size_t(64))
+    # the handle stays usable after an error
+    y = ops.conv2d_fwd(x, torch.randn(3, 3, 4, 4, device='cuda'), None, pad_top=1, pad_left=1)
+    assert torch.isfinite(y).all()
