@@ -232,3 +232,23 @@ def test_fit_on_device_generated_data_reduces_loss():
     hist = model.fit(gen, epochs=5, callbacks=[TerminateOnNaN()], verbose=0)
     assert np.isfinite(hist['loss']).all()
     assert np.mean(hist['loss'][-2:]) < 0.8 * hist['loss'][0], hist['loss']   # fresh random batches every step: compare epoch means
+
+
+def test_two_stream_backward_is_bitwise_identical_to_one_stream():
+    """The weight gradients run on a second HIP stream (layers.Context): same kernels, same order per buffer, so the gradient bucket must be
+    bit-identical to the single-stream run - any difference would be a race."""
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import SGD
+    full = configs.hpnn_tiny()
+    cfg = full['model']
+    rhs, dx = make_inputs(3, 52, 44, 17)
+    target = np.random.default_rng(4).standard_normal(rhs.shape) * 0.1
+    grads = []
+    for side in (True, False, True):
+        model, _ = build(cfg, 41)
+        model.ctx.use_side = side
+        model.compile(loss=loss_wrapper(global_batch_size=3, **full['training']['loss_parameters']), optimizer=SGD(learning_rate=0.0))
+        for _ in range(2):
+            model.train_step(((rhs, dx), target))
+        grads.append(model.store.flat_g.cpu().numpy().copy())
+    assert np.array_equal(grads[0], grads[1]) and np.array_equal(grads[0], grads[2])
