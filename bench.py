@@ -1,34 +1,93 @@
 #!/usr/bin/env python3
-"""Headline benchmark: grids/s of one full training step (forward + backward + loss + Adam [+ RCCL gradient all-reduce])
-of Homogeneous_Poisson_NN_Legacy(hpnn.json) on synthetic data resident in HBM.
+"""Headline benchmark: grids/s of one full training step (forward + loss + backward + Adam [+ RCCL gradient all-reduce]) of
+Homogeneous_Poisson_NN_Legacy(hpnn.json) on synthetic data resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c4|c3]
+  python bench.py --gpus N --steps K --warmup W [--workload c4|c3|small]
     c4 (default): 8 x 1024^2 Dirichlet grids per GPU, data-parallel weak scaling (BASELINE.json configs[3])
     c3          : 32 x 512^2 grids per GPU (BASELINE.json configs[2])
-For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
-RCCL).  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fp32-MFMA conv kernel used for the
-forward and the data-gradient convolutions): algorithmic FLOP of all its launches in the timed region / their summed
-duration measured with HIP events on the launch stream.  `cpu_baseline` times the oracle's torch-CPU twin of the same
-graph (fp32, all host cores) on a bounded sample - a stand-in for the reference's TF-CPU path, which cannot run here.
+
+Launching.  N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE
+in the environment: this process IS one rank), or bare (`python bench.py --gpus N`): the parent then starts N fresh child processes - one
+rank per GPU, rendezvous on 127.0.0.1 - BEFORE anything touches the GPU (no exec of a GPU-initialised process), relays rank 0's JSON line
+and exits with the worst child status.
+
+What is timed.  BOTH convolution math modes, W warm-up + K timed steps each, every timed region bracketed by barrier + synchronize, MAX
+over ranks:
+  * `value` / `ms_per_step` / `dtype` / `roofline`: math mode "fp32" - v_mfma_f32_32x32x2_f32, exact fp32 products, the library default
+    and the reference's precision (experiments/hpnn.json:78);
+  * `split_f16` block: the opt-in 3 x fp16 split mode, timed the same way in the same run, with
+    `accuracy_vs_fp32`: forward output and flat gradient of THIS benchmark batch in split mode against fp32 mode (rel-L2 and
+    max componentwise error), measured before the timed regions.
+`roofline` describes the dominant kernel (fused pad+conv forward / data-gradient): algorithmic FLOP of all its launches in the timed
+region / their summed duration from HIP events on the launch stream.  `roofline.hbm_bound` is the north star's "conv forward vs HBM
+roofline" figure: the conv launches whose arithmetic intensity is below the fp32 ridge (3x3 tail, <= 8 channels), algorithmic bytes / time.
+`roofline.traffic` comes from separate `rocprofv3 --pmc` passes (committed summary, tools/pmc_summary.py) and is reported only when the
+summary's source stamp matches the kernel sources of this tree; otherwise null with the reason in `traffic_source`.
+`cpu_baseline` times the oracle's torch-CPU twin of the same graph (fp32, host cores) on one 512^2 grid - a stand-in for the reference's
+TF-CPU path, which cannot run here.  `dataset` is the on-device 512^2 FD reference-solution generator next to its scipy stand-in.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_SPLIT_TFLOPS = 2500.0 / 3  # 3 fp16 MFMA FLOP per algorithmic fp32 FLOP at the ~2.5 PFLOP/s dense fp16 peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s is what a float4 copy achieves)
+WORKLOADS = {'c4': (8, 1024), 'c3': (32, 512), 'small': (2, 256), 'launch-check': (0, 0)}
 
 
-def cpu_baseline(sample_hw=128, seed=0):
-    """fwd+bwd of the identical layer graph on the host cores (oracle twin, fp32) for ONE sample_hw^2 grid."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS),
+                    help="launch-check: no model - rendezvous, barrier, all-reduce of the 22.2 MB gradient bucket and the JSON line only "
+                         "(runs on CPU/gloo; exercises the N > 1 launch path without a GPU)")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dataset', action='store_true')
+    ap.add_argument('--modes', default='split_f16,fp32', help='math modes to time, in order; the LAST one is the headline (default: split_f16,fp32)')
+    ap.add_argument('--math', default=None, choices=['split_f16', 'fp32'], help='time only this mode (profiling runs)')
+    ap.add_argument('--cpu-baseline-hw', type=int, default=512)
+    ap.add_argument('--overlap-wgrad', type=int, default=0, choices=[0, 1],
+                    help='1: run the weight gradients on a second HIP stream, overlapping them with the data-gradient convolutions (the library '
+                         'default; ~3 %% faster end to end).  Default 0 here: with two kernels sharing the chip a launch\'s duration is no '
+                         'longer attributable to it, so the roofline block would stop describing the kernel')
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------- self-launch
+def self_launch(args):
+    """Bare `python bench.py --gpus N`: one child process per rank, started before this process has imported torch or touched a GPU."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline(sample_hw=512, seed=0):
+    """fwd+bwd of the identical layer graph on the host cores (oracle twin, fp32) for ONE sample_hw^2 grid: 1 warm-up + >= 2 timed reps."""
+    import numpy as np
+    import torch
     from oracle import hpnn as ohpnn, torch_twin, loss as oloss
     from poisson_cnn_amd import configs
     full = configs.hpnn()
@@ -56,43 +115,106 @@ def cpu_baseline(sample_hw=128, seed=0):
         step()                      # warm-up (oneDNN primitive creation)
         t0 = time.perf_counter()
         reps = 0
-        while reps < 1 or (time.perf_counter() - t0 < 12.0 and reps < 20):
+        while reps < 2 or (time.perf_counter() - t0 < 20.0 and reps < 5):
             step()
             reps += 1
         dt = (time.perf_counter() - t0) / reps
     finally:
         torch_twin.set_dtype(torch.float64)
-    px_per_s = H * W / dt
-    return {'value': px_per_s / (1024.0 * 1024.0), 'unit': 'grids/s (1024^2-grid equivalents, fwd+bwd)', 'cores': cores, 'kind': 'port',
-            'sample': '%d reps of fwd+bwd on one %dx%d grid (%.2f s each), oracle torch-CPU twin in fp32 - stand-in for TF-CPU' % (reps, H, W, dt)}
+    return {'value': 1.0 / dt, 'unit': 'grids/s (%dx%d grids, fwd+bwd)' % (H, W), 'cores': cores, 'kind': 'port',
+            'grids_per_s_1024_equivalent': H * W / dt / (1024.0 * 1024.0),
+            'sample': '1 warm-up + %d timed reps of fwd+bwd on one %dx%d grid (%.2f s each), oracle torch-CPU twin in fp32 on %d threads - stand-in for TF-CPU'
+                      % (reps, H, W, dt, cores)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='c4', choices=['c4', 'c3', 'small'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--math', default='split_f16', choices=['split_f16', 'fp32'],
-                    help='convolution GEMM arithmetic: 3 x fp16 split MFMA with fp32 accumulate (fp32-accurate, default) or plain fp32 MFMA')
-    ap.add_argument('--overlap-wgrad', type=int, default=0, choices=[0, 1],
-                    help='1: run the weight gradients on a second HIP stream, overlapping them with the data-gradient convolutions (the library '
-                         'default; ~3 %% faster end to end).  Default 0 here: with two kernels sharing the chip a launch\'s duration is no '
-                         'longer attributable to it, so the roofline block would stop describing the kernel')
-    args = ap.parse_args()
-    os.environ['PCNN_WGRAD_STREAM'] = str(args.overlap_wgrad)
+def dataset_block():
+    """On-device FD reference-solution generator at 512^2 (BASELINE configs[4]) next to the scipy sparse-direct stand-in for pyamg."""
+    import numpy as np
+    import torch
+    from oracle import dataset as ods
+    from poisson_cnn_amd.dataset import numerical_dataset_generator
+    N, H = 32, 512
+    gen = numerical_dataset_generator(batch_size=N, batches_per_epoch=1, randomize_rhs_smoothness=True, rhs_random_smoothness_range=[3, 8], seed=0,
+                                      output_shape=[H, H], return_rhs=True, return_boundaries=True, return_dx=True, boundary_smoothness=5)
+    gen[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        inp, soln = gen[0]
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 5
+    rhs, left, top, right, bottom, dx = [x.cpu().numpy().astype(np.float64) for x in inp]
+    t0 = time.perf_counter()
+    ref = ods.multigrid_poisson_solve(rhs[:2, 0], {'left': left[:2, 0], 'right': right[:2, 0], 'top': top[:2, 0], 'bottom': bottom[:2, 0]}, dx[:2, 0])
+    tc = (time.perf_counter() - t0) / 2
+    err = float(np.linalg.norm(soln[:2, 0].cpu().numpy() - ref) / np.linalg.norm(ref))
+    n = H - 2
+    return {'metric': 'reference-solution samples/s at 512^2 (control points -> legacy bicubic -> fp64 DST-I solve, on device)', 'value': N / t,
+            'fp64_mfma_tflops': 8.0 * n ** 3 * N / t / 1e12, 'algorithm': 'GEMM DST-I on v_mfma_f64_16x16x4_f64, 8 n^3 FLOP per sample',
+            'cpu_baseline': {'value': 1.0 / tc, 'unit': 'samples/s', 'kind': 'port',
+                             'sample': '2 samples, scipy.sparse.linalg.splu of the same 5-point system (stand-in for pyamg), 1 thread'},
+            'rel_l2_gpu_vs_cpu': err}
 
+
+# ----------------------------------------------------------------------------------------------------------------- the benchmark
+def launch_check(args, dp):
+    """No model: times K all-reduces of a 22.2 MB fp32 bucket (the per-step gradient exchange) through the same rendezvous / barrier /
+    max-over-ranks path as the real benchmark.  Runs on CPU (gloo); `dry_run` marks the line as not a benchmark result."""
+    import torch
+    dev = 'cuda' if dp.backend == 'nccl' else 'cpu'
+    bucket = torch.full((5556956,), float(dp.rank + 1), dtype=torch.float32, device=dev)
+    for _ in range(args.warmup):
+        dp.all_reduce_sum(bucket)
+    dp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dp.all_reduce_sum(bucket)
+    if dev == 'cuda':
+        torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    if dp.rank == 0:
+        print(json.dumps({'metric': 'launch-check (no model)', 'dry_run': True, 'value': args.steps / elapsed, 'unit': 'all-reduces/s (22.2 MB fp32 bucket)',
+                          'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'launch-check', 'collective': dp.collective_name(), 'parallelism': 'dp%d' % dp.world_size}}), flush=True)
+
+
+def traffic_from_profiles(math, workload, kernel_prefix):
+    """(bytes per launch, provenance) from the committed PMC summary of this mode - only if it was measured on these kernel sources."""
+    from poisson_cnn_amd import _lib
+    name = 'r02_c4_pmc_summary_%s.json' % math
+    path = os.path.join(ROOT, 'profiles', name)
+    if workload != 'c4':
+        return None, 'PMC passes are collected for workload c4 only'
+    if not os.path.exists(path):
+        return None, 'profiles/%s not found' % name
+    with open(path) as f:
+        summ = json.load(f)
+    if summ.get('source_hash') != _lib.source_hash():
+        return None, 'profiles/%s was measured on other kernel sources (stamp %s, this tree %s): re-run tools/collect_pmc.sh' % (name, summ.get('source_hash'), _lib.source_hash())
+    ks = [v for k, v in summ['kernels'].items() if k.startswith(kernel_prefix)]
+    if not ks:
+        return None, 'no %s* rows in profiles/%s' % (kernel_prefix, name)
+    return (sum(v['traffic_bytes_per_launch'] * v['launches'] for v in ks) / max(sum(v['launches'] for v in ks), 1),
+            'profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes; source stamp %s matches)' % (name, summ['source_hash']))
+
+
+def run(args):
+    import numpy as np
+    import torch
     from poisson_cnn_amd import configs, ops, parallel
+    os.environ['PCNN_WGRAD_STREAM'] = str(args.overlap_wgrad)
+    dp = parallel.DataParallel.from_env()
+    if dp.world_size != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, dp.world_size))
+    if args.workload == 'launch-check':
+        return launch_check(args, dp)
     from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
     from poisson_cnn_amd.losses import loss_wrapper
     from poisson_cnn_amd.train import Adam
 
-    dp = parallel.DataParallel.from_env()
-    ops.set_math_mode(args.math)
-    if dp.world_size != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, dp.world_size, args.gpus))
-    per_gpu, H = {'c4': (8, 1024), 'c3': (32, 512), 'small': (2, 256)}[args.workload]
+    per_gpu, H = WORKLOADS[args.workload]
     W = H
     full = configs.hpnn()
     model = Homogeneous_Poisson_NN_Legacy(**full['model'])
@@ -111,63 +233,115 @@ def main():
         if dp.rank == 0:
             print('[bench] ' + msg, file=sys.stderr, flush=True)
 
-    note('model built, %d params; warm-up' % model.count_params())
-    for _ in range(args.warmup):
-        model.train_step(batch)
-    torch.cuda.synchronize()
-    note('warm-up done; timing %d steps' % args.steps)
-    prof = ops.KernelTimer()
-    dp.barrier()
-    torch.cuda.synchronize()
-    ops.set_kernel_timer(prof)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logs = model.train_step(batch)
-    torch.cuda.synchronize()
-    dp.barrier()
-    elapsed = time.perf_counter() - t0
-    ops.set_kernel_timer(None)
-    elapsed = dp.max_over_ranks(elapsed)
-    note('timed region: %.3f s' % elapsed)
-    loss = float(logs['loss'])
+    modes = [args.math] if args.math else [m for m in args.modes.split(',') if m]
+    note('model built, %d params; modes %s' % (model.count_params(), modes))
 
-    if dp.rank == 0:
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (PMC collection
-        # cannot be combined with the timed run); the committed summary is reported for the workload it was measured on.
-        traffic = None
-        wgrad_traffic = None
-        pmc_name = 'r01_c4_pmc_summary.json' if args.math == 'fp32' else 'r01_c4_pmc_summary_split.json'
-        pmc = os.path.join(ROOT, 'profiles', pmc_name)
-        if args.workload == 'c4' and os.path.exists(pmc):
-            with open(pmc) as f:
-                allk = json.load(f)['kernels']
-                ks = [v for k, v in allk.items() if k.startswith('conv_fwd')]   # all tile variants = all 'conv_fwd' launches
-            wk = [v for k, v in allk.items() if k.startswith('wgrad')]
-            if wk:
-                wgrad_traffic = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in wk) / max(sum(v['launches'] for v in wk), 1)
-            traffic = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in ks) / max(sum(v['launches'] for v in ks), 1)
-        peak = PEAK_FP32_MFMA_TFLOPS if args.math == 'fp32' else PEAK_SPLIT_TFLOPS
+    # ---- accuracy gate on the benchmark batch itself: same weights, same inputs, the two math modes side by side (no optimizer step)
+    accuracy = None
+    if 'split_f16' in modes and 'fp32' in modes:
+        res = {}
+        for mode in ('fp32', 'split_f16'):
+            ops.set_math_mode(mode)
+            _, pred = model._loss_and_grads(rhs, dx.reshape(per_gpu, -1)[:, :1].contiguous(), target)
+            torch.cuda.synchronize()
+            res[mode] = (pred.double().clone(), model.store.flat_g.double().clone())
+
+        def cmp(a, b):
+            d = (a - b).abs()
+            sig = b.abs() >= 1e-3 * b.abs().max()
+            return {'rel_l2': float((a - b).norm() / b.norm()), 'max_abs_err_over_max_abs': float(d.max() / b.abs().max()),
+                    'max_rel_err_where_ref_above_1e-3_of_max': float((d[sig] / b.abs()[sig]).max())}
+        accuracy = {'what': 'split_f16 mode vs fp32 mode on this benchmark batch (rank 0 shard), identical weights and inputs',
+                    'forward_output': cmp(res['split_f16'][0], res['fp32'][0]), 'flat_gradient': cmp(res['split_f16'][1], res['fp32'][1])}
+        note('accuracy gate: forward rel-L2 %.3g, gradient rel-L2 %.3g' % (accuracy['forward_output']['rel_l2'], accuracy['flat_gradient']['rel_l2']))
+        del res
+
+    def timed(mode):
+        ops.set_math_mode(mode)
+        for _ in range(args.warmup):
+            model.train_step(batch)
+        torch.cuda.synchronize()
+        note('%s: warm-up done; timing %d steps' % (mode, args.steps))
+        prof = ops.KernelTimer()
+        dp.barrier()
+        torch.cuda.synchronize()
+        ops.set_kernel_timer(prof)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            logs = model.train_step(batch)
+        torch.cuda.synchronize()
+        dp.barrier()
+        elapsed = time.perf_counter() - t0
+        ops.set_kernel_timer(None)
+        elapsed = dp.max_over_ranks(elapsed)
+        note('%s: timed region %.3f s' % (mode, elapsed))
+        return elapsed, prof, float(logs['loss'])
+
+    def roofline(mode, prof):
+        peak = PEAK_FP32_MFMA_TFLOPS if mode == 'fp32' else PEAK_SPLIT_TFLOPS
         flops, secs, calls = prof.totals('conv_fwd')
         wf, ws_, wc = prof.totals('conv_wgrad')
-        out = {
-            'metric': 'grids/sec (fwd+bwd) at %d^2' % H, 'value': gbs * args.steps / elapsed, 'unit': 'grids/s',
-            'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.math == 'fp32' else 'f32 (operands split into 2 x fp16, 3 MFMA products, fp32 accumulate; parity-tested at the fp32 tolerances)',
-            'data': 'synthetic',
-            'config': {'workload': '%s: Homogeneous_Poisson_NN_Legacy(hpnn.json) full train step (fwd+bwd+loss+Adam%s), %d x %dx%d Dirichlet grids per GPU'
-                                   % (args.workload, '+RCCL all-reduce' if dp.world_size > 1 else '', per_gpu, H, W),
-                       'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': args.math, 'overlap_wgrad': bool(args.overlap_wgrad), 'final_loss': loss},
-            'roofline': {'bound': 'mfma', 'kernel': ('conv_fwd_kernel' if args.math == 'fp32' else 'conv_fwd_split_kernel') + ' (fused pad+conv fwd and data-gradient; all launches of a step)', 'achieved': flops / secs / 1e12 if secs else None,
-                         'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)', 'frac': flops / secs / 1e12 / peak if secs else None,
-                         'traffic': traffic, 'algorithmic_bytes_per_launch': prof.total_bytes('conv_fwd') / calls if calls else None, 'traffic_unit': 'bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/%s)' % pmc_name, 'launches': calls, 'avg_launch_ms': 1e3 * secs / calls if calls else None,
-                         'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / peak if ws_ else None,
-                                          'launches': wc, 'avg_launch_ms': 1e3 * ws_ / wc if wc else None, 'traffic': wgrad_traffic}},
-        }
-        if dp.world_size == 1 and not args.no_cpu_baseline:
-            note('cpu baseline (bounded sample) ...')
-            out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        traffic, tsrc = traffic_from_profiles(mode, args.workload, 'conv_fwd')
+        wtraffic, _ = traffic_from_profiles(mode, args.workload, 'wgrad')
+        ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
+        hf, hb, hs, hc = prof.select(lambda k, f, b: k == 'conv_fwd' and b > 0 and f / b < ridge)
+        df, db, ds, dc = prof.select(lambda k, f, b: k == 'deconv_fwd')
+        rf, rb, rs, rc = prof.select(lambda k, f, b: k == 'resize_fwd')
+        return {'bound': 'mfma', 'kernel': ('conv_fwd_kernel' if mode == 'fp32' else 'conv_fwd_split_kernel') + ' (fused pad+conv fwd and data-gradient; all launches of the timed steps)',
+                'achieved': flops / secs / 1e12 if secs else None, 'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)',
+                'frac': flops / secs / 1e12 / peak if secs else None, 'traffic': traffic, 'traffic_source': tsrc,
+                'algorithmic_bytes_per_launch': prof.total_bytes('conv_fwd') / calls if calls else None, 'launches': calls,
+                'avg_launch_ms': 1e3 * secs / calls if calls else None,
+                'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / peak if ws_ else None, 'launches': wc,
+                                 'avg_launch_ms': 1e3 * ws_ / wc if wc else None, 'traffic': wtraffic},
+                'hbm_bound': {'what': 'conv forward / data-gradient launches below the fp32 ridge (%.1f FLOP/B: the 3x3 tail with <= 8 channels and the Scaling convs)' % ridge,
+                              'bound': 'hbm', 'achieved': hb / hs / 1e9 if hs else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s (algorithmic bytes)',
+                              'frac': hb / hs / 1e9 / PEAK_HBM_GBS if hs else None, 'launches': hc, 'avg_launch_ms': 1e3 * hs / hc if hc else None,
+                              'deconv_fwd': {'achieved': db / ds / 1e9 if ds else None, 'frac': db / ds / 1e9 / PEAK_HBM_GBS if ds else None, 'launches': dc},
+                              'resize_fwd': {'achieved': rb / rs / 1e9 if rs else None, 'frac': rb / rs / 1e9 / PEAK_HBM_GBS if rs else None, 'launches': rc}}}
+
+    DTYPE = {'fp32': 'f32', 'split_f16': 'f32 tensors and accumulate; products as 3 x fp16 MFMA on 2 x fp16 splits of the fp32 operands (opt-in mode)'}
+    blocks = {}
+    for mode in modes:
+        elapsed, prof, loss = timed(mode)
+        blocks[mode] = {'value': gbs * args.steps / elapsed, 'unit': 'grids/s', 'ms_per_step': 1e3 * elapsed / args.steps, 'dtype': DTYPE[mode],
+                        'final_loss': loss, 'roofline': roofline(mode, prof) if dp.rank == 0 else None}
+        del prof
+    if dp.rank != 0:
+        return
+    head = modes[-1]
+    hb = blocks[head]
+    out = {
+        'metric': 'grids/sec (fwd+bwd) at %d^2' % H, 'value': hb['value'], 'unit': 'grids/s',
+        'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': hb['ms_per_step'],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': hb['dtype'], 'data': 'synthetic',
+        'config': {'workload': '%s: Homogeneous_Poisson_NN_Legacy(hpnn.json) full train step (fwd+bwd+loss+Adam%s), %d x %dx%d Dirichlet grids per GPU'
+                               % (args.workload, ('+' + dp.collective_name()) if dp.world_size > 1 else '', per_gpu, H, W),
+                   'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': head, 'library_default_math': 'fp32',
+                   'overlap_wgrad': bool(args.overlap_wgrad), 'final_loss': hb['final_loss'], 'collective': dp.collective_name() if dp.world_size > 1 else None},
+        'roofline': hb['roofline'],
+    }
+    for mode in modes[:-1]:
+        out[mode] = blocks[mode]
+        if mode == 'split_f16' and accuracy is not None:
+            out[mode]['accuracy_vs_fp32'] = accuracy
+    if dp.world_size == 1 and not args.no_cpu_baseline:
+        note('cpu baseline (bounded sample: one %d^2 grid) ...' % args.cpu_baseline_hw)
+        out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_hw)
+    if dp.world_size == 1 and not args.no_dataset:
+        note('dataset generator block ...')
+        try:
+            out['dataset'] = dataset_block()
+        except Exception as e:   # the headline must not die on the side measurement
+            out['dataset'] = {'error': repr(e)}
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+    run(args)
 
 
 if __name__ == '__main__':

@@ -23,6 +23,22 @@ class ConvDesc(Structure):
 _lib = None
 
 
+def source_hash():
+    """sha256 over the kernel sources this tree builds libpcnn.so from (csrc/*.hip, csrc/*.h, include/pcnn.h): the stamp that ties a
+    committed counter summary (profiles/*pmc_summary*.json) to the kernels it was measured on - bench.py reports `traffic` only when
+    the stamp matches the tree it runs from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.hip')) + glob.glob(os.path.join(_HERE, 'csrc', '*.h')))
+    files.append(os.path.join(os.path.dirname(_HERE), 'include', 'pcnn.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Loads libpcnn.so (built by `make -C poisson_cnn_amd/csrc` / __graft_entry__.build())."""
     global _lib

@@ -127,6 +127,7 @@ class Context:
         self.side_allowed = os.environ.get('PCNN_WGRAD_STREAM', '1') != '0'
         self.side = None
         self.ws_side = ops.Workspace()
+        self.side_reads = {}                                   # data_ptr -> event: tensors a side-stream weight gradient is still reading
 
     def enable_side_stream(self):
         self.use_side = self.side_allowed
@@ -142,6 +143,14 @@ class Context:
         """Main stream waits for the weight gradients enqueued on the side stream (call before the gradients are consumed)."""
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        self.side_reads.clear()
+
+    def before_inplace_write(self, t):
+        """The main stream is about to overwrite `t` in place: if a weight gradient on the side stream still reads it (its dz can alias the
+        incoming gradient when the layer's epilogue is trivial - linear activation, no BN), wait for that launch first."""
+        ev = self.side_reads.pop(t.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def wflip(self, shape, device):
         n = int(np.prod(shape))
@@ -254,6 +263,9 @@ class ConvUnit:
                         t.record_stream(side)
                 ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
                                  out=g[self.name + '/kernel'], ws=self.ctx.ws_side, x_absmax=x_absmax, dz_absmax=amax)
+                done = torch.cuda.Event()
+                done.record()
+            self.ctx.side_reads[dz.data_ptr()] = done          # see Context.before_inplace_write
         if not need_dx:
             return None
         kh, kw = self.kh, self.kw
@@ -262,6 +274,7 @@ class ConvUnit:
             return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to)
         gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1))
         if add_to is not None and add_to.is_contiguous():
+            self.ctx.before_inplace_write(add_to)
             return ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode, out=add_to, accumulate=True)
         dx = ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode)
         return dx if add_to is None else ops.axpby(1.0, add_to, 1.0, dx)

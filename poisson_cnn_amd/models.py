@@ -101,15 +101,33 @@ class _ModelBase:
         self.loss_fn = loss
         optimizer.bind(self.stores)
 
+    metric_sync = None   # set by parallel.DataParallel.attach: (loss, mse) -> their GLOBAL values (one tiny all-reduce)
+
+    def _logs(self, loss, mse):
+        """What train_step returns.  Under data parallelism each rank's loss is its share of the global-batch loss (already divided by
+        the global batch size, losses/loss_wrapper.py:46-49) and its mse the mean over its own samples; callbacks (ReduceLROnPlateau,
+        TerminateOnNaN, ModelCheckpoint) must see the same GLOBAL numbers on every rank or the replicas' learning rates / stop decisions
+        diverge - MirroredStrategy reduces the per-replica results the same way before Keras hands them to callbacks."""
+        if self.metric_sync is not None:
+            loss, mse = self.metric_sync(loss, mse)
+        return {'loss': loss, 'mse': mse, 'lr': self.optimizer.learning_rate}
+
     def fit(self, dataset, epochs=1, callbacks=(), verbose=1, steps_per_epoch=None):
-        """Minimal Keras-style loop over a Sequence-like dataset (`__len__`, `__getitem__` -> ([rhs, dx], soln))."""
-        history = {'loss': [], 'mse': [], 'lr': []}
+        """Minimal Keras-style loop over a Sequence-like dataset (`__len__`, `__getitem__` -> ([rhs, dx], soln)).
+
+        Keras semantics for a custom train_step that returns plain values (models/Homogeneous_Poisson_NN_Legacy.py:291): the dict handed
+        to on_epoch_end / History is the LAST batch's (tf.keras Model.fit: `epoch_logs = copy.copy(logs)`), not an epoch average - so that
+        is what ReduceLROnPlateau and ModelCheckpoint monitor here too.  The epoch means are added under `loss_epoch_mean` / `mse_epoch_mean`.
+        Under data parallelism the values are global (see _logs), so every rank's callbacks decide alike."""
+        history = {'loss': [], 'mse': [], 'lr': [], 'loss_epoch_mean': [], 'mse_epoch_mean': []}
         self.stop_training = False
         for cb in callbacks:
             cb.set_model(self)
         for epoch in range(epochs):
             n = steps_per_epoch if steps_per_epoch is not None else len(dataset)
             agg = {'loss': 0.0, 'mse': 0.0}
+            logs = {'loss': float('nan'), 'mse': float('nan')}
+            step = -1
             for step in range(n):
                 inp, tar = dataset[step]
                 logs = self.train_step((tuple(inp), tar))
@@ -120,11 +138,13 @@ class _ModelBase:
                     cb.on_batch_end(step, logs)
                 if self.stop_training:
                     break
-            logs = {'loss': agg['loss'] / max(step + 1, 1), 'mse': agg['mse'] / max(step + 1, 1), 'lr': self.optimizer.learning_rate}
+            logs = {'loss': logs['loss'], 'mse': logs['mse'], 'lr': self.optimizer.learning_rate,
+                    'loss_epoch_mean': agg['loss'] / max(step + 1, 1), 'mse_epoch_mean': agg['mse'] / max(step + 1, 1)}
             for k in history:
                 history[k].append(logs[k])
             if verbose:
-                print('Epoch %d/%d - loss: %.6g - mse: %.6g - lr: %.3g' % (epoch + 1, epochs, logs['loss'], logs['mse'], logs['lr']), flush=True)
+                print('Epoch %d/%d - loss: %.6g - mse: %.6g - lr: %.3g (epoch mean loss %.6g)'
+                      % (epoch + 1, epochs, logs['loss'], logs['mse'], logs['lr'], logs['loss_epoch_mean']), flush=True)
             for cb in callbacks:
                 cb.on_epoch_end(epoch, logs)
             if hasattr(dataset, 'on_epoch_end'):
@@ -351,7 +371,7 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         if self.grad_sync is not None:
             self.grad_sync(S.flat_g)
         self.optimizer.apply_gradients()
-        return {'loss': loss, 'mse': self.loss_fn.mse_metric(gt, pred), 'lr': self.optimizer.learning_rate}
+        return self._logs(loss, self.loss_fn.mse_metric(gt, pred))
 
 
 # =====================================================================================================================
@@ -533,7 +553,7 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         if self.grad_sync is not None:
             self.grad_sync(self.store.flat_g)
         self.optimizer.apply_gradients()
-        return {'loss': loss, 'mse': self.loss_fn.mse_metric(y_true, pred), 'lr': self.optimizer.learning_rate}
+        return self._logs(loss, self.loss_fn.mse_metric(y_true, pred))
 
 
     # ------------------------------------------------------------------ used by Poisson_CNN_Legacy: several calls per step share the weights
@@ -676,4 +696,4 @@ class Poisson_CNN_Legacy(_ModelBase):
             for s in self.stores:
                 self.grad_sync(s.flat_g)
         self.optimizer.apply_gradients()
-        return {'loss': loss, 'mse': self.loss_fn.mse_metric(y_true, pred), 'lr': self.optimizer.learning_rate}
+        return self._logs(loss, self.loss_fn.mse_metric(y_true, pred))

@@ -122,6 +122,12 @@ class KernelTimer:
     def total_bytes(self, kind):
         return sum(r[4] for r in self.records if r[0] == kind)
 
+    def select(self, pred):
+        """(flops, bytes, seconds, launches) over the records for which pred(kind, flops, bytes) holds."""
+        torch.cuda.synchronize()
+        sel = [r for r in self.records if pred(r[0], r[1], r[4])]
+        return sum(r[1] for r in sel), sum(r[4] for r in sel), sum(r[2].elapsed_time(r[3]) for r in sel) * 1e-3, len(sel)
+
     def totals(self, kind):
         torch.cuda.synchronize()
         sel = [r for r in self.records if r[0] == kind]
@@ -279,8 +285,11 @@ def deconv_fwd(x, k, bias, out_hw, f, *, alpha=1.0, beta=0.0, out=None):
     Cout = k.shape[2]
     H, W = out_hw
     y = out if out is not None else empty((N, H, W, Cout), x.device)
-    handle().call('pcnn_deconv_fwd', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(x), c_int(_ld(x)),
-                  _p(k), _p(bias), c_float(alpha), c_float(beta), _p(y), c_int(_ld(y)))
+    # algorithmic bytes: x read once, y written once (+ read once when the branch merge accumulates in place, beta != 0), filter
+    _launch('deconv_fwd', 2.0 * N * H * W * Cin * Cout,
+            lambda: handle().call('pcnn_deconv_fwd', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(x), c_int(_ld(x)),
+                                  _p(k), _p(bias), c_float(alpha), c_float(beta), _p(y), c_int(_ld(y))),
+            4.0 * (N * hc * wc * Cin + N * H * W * Cout * (2 if beta != 0.0 else 1) + f * f * Cin * Cout))
     return y
 
 
@@ -331,8 +340,10 @@ def resize_fwd(x, out_hw, method, *, alpha=1.0, beta=0.0, out=None):
     iy, wy = resize_tables(method, hc, Ho, x.device)
     ix, wx = resize_tables(method, wc, Wo, x.device)
     y = out if out is not None else empty((N, Ho, Wo, C), x.device)
-    handle().call('pcnn_resize_fwd', c_int(N), c_int(hc), c_int(wc), c_int(C), c_int(Ho), c_int(Wo), _p(x), c_int(_ld(x)), _p(iy), _p(wy), _p(ix), _p(wx),
-                  c_float(alpha), c_float(beta), _p(y), c_int(_ld(y)))
+    _launch('resize_fwd', 0.0,
+            lambda: handle().call('pcnn_resize_fwd', c_int(N), c_int(hc), c_int(wc), c_int(C), c_int(Ho), c_int(Wo), _p(x), c_int(_ld(x)), _p(iy), _p(wy), _p(ix), _p(wx),
+                                  c_float(alpha), c_float(beta), _p(y), c_int(_ld(y))),
+            4.0 * (N * hc * wc * C + N * Ho * Wo * C * (2 if beta != 0.0 else 1)))
     return y
 
 

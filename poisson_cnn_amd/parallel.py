@@ -57,7 +57,23 @@ class DataParallel:
             self.broadcast(store.flat_w)
             self.broadcast(store.flat_stats)
         model.grad_sync = self.all_reduce_sum
+        model.metric_sync = self.global_metrics
         return model
+
+    def global_metrics(self, loss, mse):
+        """Per-rank (loss share, local mse) -> (global loss, global mean mse) on every rank: a 2-element all-reduce(SUM).  Callbacks that
+        act on these (learning-rate schedule, NaN termination, best-checkpoint) then take identical decisions on all ranks."""
+        if self.world_size == 1:
+            return loss, mse
+        t = torch.stack([torch.as_tensor(loss, dtype=torch.float32).reshape(()), torch.as_tensor(mse, dtype=torch.float32).reshape(()) / self.world_size])
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t[0], t[1]
+
+    def collective_name(self):
+        """The collective actually in use, for reports: backend "nccl" is RCCL on ROCm."""
+        if self.world_size == 1:
+            return 'none (single rank)'
+        return {'nccl': 'RCCL all-reduce', 'gloo': 'gloo all-reduce (CPU)'}.get(self.backend, '%s all-reduce' % self.backend)
 
     def barrier(self):
         if self.world_size > 1:

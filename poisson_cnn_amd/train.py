@@ -26,10 +26,22 @@ class _Optimizer:
         pass
 
 
+def _reject_unsupported_optimizer_kwargs(who, kwargs):
+    """tf.keras optimizers also take clipnorm / clipvalue / decay (/ lr as an alias): options that change the update must not be
+    swallowed silently - a config that sets them would train differently from the reference."""
+    for k, v in kwargs.items():
+        if k in ('clipnorm', 'clipvalue', 'global_clipnorm') and v is None:
+            continue
+        if k == 'decay' and not v:
+            continue
+        raise NotImplementedError('%s: optimizer option %r=%r is not implemented' % (who, k, v))
+
+
 class Adam(_Optimizer):
     """tf.keras.optimizers.Adam defaults (train/utils.py:3-8; experiments/hpnn.json optimizer_parameters)."""
 
-    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, **unused):
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, name='Adam', **kwargs):
+        _reject_unsupported_optimizer_kwargs('Adam', kwargs)
         self.amsgrad = bool(amsgrad)
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
@@ -48,7 +60,10 @@ class Adam(_Optimizer):
 
 
 class SGD(_Optimizer):
-    def __init__(self, learning_rate=0.01, **unused):
+    def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False, name='SGD', **kwargs):
+        _reject_unsupported_optimizer_kwargs('SGD', kwargs)
+        if float(momentum) != 0.0 or nesterov:
+            raise NotImplementedError('SGD: momentum / nesterov are not implemented (pcnn_sgd_step is plain gradient descent)')
         self.learning_rate = float(learning_rate)
         self.iterations = 0
 
@@ -93,20 +108,36 @@ class ModelCheckpoint(Callback):
 
 
 class ReduceLROnPlateau(Callback):
-    def __init__(self, patience=4, monitor='loss', min_lr=0.0, factor=0.1):
-        self.patience, self.monitor, self.min_lr, self.factor = patience, monitor, min_lr, factor
-        self.best, self.wait = math.inf, 0
+    """tf.keras.callbacks.ReduceLROnPlateau, mode 'min' (train/hpnn_legacy_train.py:48 passes patience and min_lr; everything else is
+    the Keras default: factor 0.1, min_delta 1e-4, cooldown 0).  An epoch counts as an improvement only if monitor < best - min_delta.
+    The monitored value is what fit() hands to on_epoch_end: the last batch's (global) loss, as in Keras."""
+
+    def __init__(self, monitor='loss', factor=0.1, patience=10, verbose=0, mode='auto', min_delta=1e-4, cooldown=0, min_lr=0.0):
+        if factor >= 1.0:
+            raise ValueError('ReduceLROnPlateau does not support a factor >= 1.0.')
+        if mode not in ('auto', 'min'):
+            raise NotImplementedError("ReduceLROnPlateau: only mode 'min' / 'auto' on a loss is implemented")
+        self.monitor, self.factor, self.patience, self.verbose = monitor, factor, patience, verbose
+        self.min_delta, self.cooldown, self.min_lr = min_delta, cooldown, min_lr
+        self.best, self.wait, self.cooldown_counter = math.inf, 0, 0
 
     def on_epoch_end(self, epoch, logs):
-        v = logs[self.monitor]
-        if v < self.best:
-            self.best, self.wait = v, 0
-        else:
+        current = logs[self.monitor]
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if current < self.best - self.min_delta:
+            self.best, self.wait = current, 0
+        elif self.cooldown_counter <= 0:
             self.wait += 1
             if self.wait >= self.patience:
                 opt = self.model.optimizer
-                opt.learning_rate = max(opt.learning_rate * self.factor, self.min_lr)
-                self.wait = 0
+                if opt.learning_rate > self.min_lr:
+                    opt.learning_rate = max(opt.learning_rate * self.factor, self.min_lr)
+                    if self.verbose:
+                        print('Epoch %d: ReduceLROnPlateau reducing learning rate to %g.' % (epoch + 1, opt.learning_rate))
+                    self.cooldown_counter = self.cooldown
+                    self.wait = 0
 
 
 class TerminateOnNaN(Callback):

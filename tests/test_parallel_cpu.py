@@ -78,3 +78,63 @@ def test_single_rank_is_a_no_op():
     dp = parallel.DataParallel()
     g = torch.ones(5)
     assert dp.all_reduce_sum(g) is g and dp.max_over_ranks(3.5) == 3.5 and dp.local_batch(6) == 6
+
+
+def test_bench_self_launches_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` started BARE (no torchrun, no WORLD_SIZE): the parent spawns one fresh process per rank before touching
+    any GPU, the ranks rendezvous on 127.0.0.1 (gloo here), all-reduce the 22.2 MB gradient bucket and rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'launch-check', '--steps', '3', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['dry_run'] is True
+    assert 'gloo' in out['config']['collective'] and out['value'] > 0
+
+
+def test_global_metrics_are_identical_on_all_ranks():
+    """callbacks must see the GLOBAL loss.  Two ranks with different local (loss share, mse) get the same pair back."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metric_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1:] == res[1][1:]
+    assert abs(res[0][1] - 0.75) < 1e-6 and abs(res[0][2] - 3.0) < 1e-6     # loss: sum of shares; mse: mean over ranks
+    assert res[0][3] == res[1][3] and res[0][3] < 1e-3                       # ReduceLROnPlateau cut the rate identically on both ranks
+
+
+def _metric_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from poisson_cnn_amd import parallel
+    from poisson_cnn_amd.train import ReduceLROnPlateau
+    dp = parallel.DataParallel.from_env(backend='gloo')
+    loss, mse = dp.global_metrics(torch.tensor(0.25 + 0.25 * rank), torch.tensor(2.0 + 2.0 * rank))
+
+    class _Opt:
+        learning_rate = 1e-3
+
+    class _M:
+        optimizer = _Opt()
+    cb = ReduceLROnPlateau(patience=2, min_lr=1e-7)
+    cb.set_model(_M())
+    # rank 0's share falls (1.0, 0.8, 0.6, 0.4), rank 1's rises (1.0, 1.2, 1.4, 1.6): on its own rank 0 would never cut the rate and rank 1
+    # would; the GLOBAL loss is flat at 2.0, so both must cut it, at the same epoch
+    for e in range(4):
+        local = 1.0 + (-0.2 if rank == 0 else 0.2) * e
+        gl, _ = dp.global_metrics(torch.tensor(local), torch.tensor(0.0))
+        assert abs(float(gl) - 2.0) < 1e-6
+        cb.on_epoch_end(e, {'loss': float(gl)})
+    q.put((rank, float(loss), float(mse), _M.optimizer.learning_rate))
+    torch.distributed.destroy_process_group()
