@@ -48,6 +48,16 @@ enum { PCNN_MATH_FP32 = 0, PCNN_MATH_SPLIT_F16 = 1 };
 int pcnn_set_math_mode(pcnn_handle h, int mode);
 int pcnn_get_math_mode(pcnn_handle h);
 
+/* Algorithm of pcnn_conv2d_fwd / pcnn_conv2d_wgrad for wide filters (replaces the same tf.nn.conv2d / backprop-filter calls):
+ *   tiled spectral convolution - overlap-save on 32 x 32 tiles, the DFT applied as fp32 MFMA matrix products, per-frequency channel
+ *   mixing, inverse transform fused with the conv epilogue (csrc/spectral_conv.hip).  Exact fp32 products and accumulation like the
+ *   direct kernel, ~k*k/25 times fewer of them.  PCNN_SPECTRAL_AUTO (default; environment PCNN_SPECTRAL=-1|0|1): a cost model picks the
+ *   route per layer and math mode; _OFF: always the direct implicit GEMM; _FORCE: spectral whenever the shape allows
+ *   (kh, kw <= 15, Cin <= 64, Cout <= 32).  The handle owns the workspace (tile spectra), grown on demand. */
+enum { PCNN_SPECTRAL_AUTO = -1, PCNN_SPECTRAL_OFF = 0, PCNN_SPECTRAL_FORCE = 1 };
+int pcnn_set_spectral_mode(pcnn_handle h, int mode);
+int pcnn_get_spectral_mode(pcnn_handle h);
+
 /* ---- 2-D convolution: tf.pad + tf.nn.conv2d(VALID) + bias + activation (+ BN affine) (+ residual) ----------
  * Replaces pad_and_apply_convolution (utils/apply_advanced_padding_and_call_conv_layer.py:16-20), Keras
  * Conv2D(padding='same') (models/Homogeneous_Poisson_NN_Legacy.py:71,75,95; layers/Scaling.py:28), the fused

@@ -11,6 +11,9 @@
 // fixed order (bit-reproducible run to run - no float atomics).
 #include "pcnn_internal.h"
 
+int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw);   // spectral_conv.hip
+bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad);
+
 namespace {
 
 constexpr int WTH = 8, WTW = 32, WAVES = 4;
@@ -731,6 +734,7 @@ extern "C" int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, co
   PCNN_REQUIRE(h, d->Cin >= 1 && d->Cin <= 128 && d->Cout >= 1 && d->Cout <= 64, "pcnn_conv2d_wgrad: channels %d->%d unsupported (<=64)", d->Cin, d->Cout);
   PCNN_REQUIRE(h, d->ldx >= d->Cin && d->ldy >= d->Cout, "pcnn_conv2d_wgrad: channel stride smaller than channel count");
   PCNN_REQUIRE(h, workspace_bytes >= pcnn_conv2d_wgrad_workspace(d), "pcnn_conv2d_wgrad: workspace too small");
+  if (pcnn_spectral_eligible(h, d, true)) return pcnn_spectral_conv_wgrad(h, d, x, dz, dw);
   const pcnn_conv_desc pd = padded_desc(d);
   const WgradPlan pls = make_split_plan(&pd);
   const bool split_ok = h->math_mode == PCNN_MATH_SPLIT_F16 && split_eligible(&pd, pls);

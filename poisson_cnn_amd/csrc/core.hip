@@ -1,5 +1,6 @@
 // Handle management for libpcnn.
 #include "pcnn_internal.h"
+#include <stdlib.h>
 
 extern "C" int pcnn_version(void) { return 100; }
 
@@ -11,12 +12,14 @@ extern "C" int pcnn_create(int device, void* hip_stream, pcnn_handle* out) {
   pcnn_handle h = new pcnn_handle_s();
   h->device = device;
   h->stream = static_cast<hipStream_t>(hip_stream);
+  if (const char* e = getenv("PCNN_SPECTRAL")) h->spectral_mode = atoi(e);
   *out = h;
   return 0;
 }
 
 extern "C" int pcnn_destroy(pcnn_handle h) {
   if (h && h->scratch) (void)hipFree(h->scratch);
+  if (h && h->spec_ws) (void)hipFree(h->spec_ws);
   delete h;
   return 0;
 }
@@ -44,3 +47,12 @@ extern "C" int pcnn_set_math_mode(pcnn_handle h, int mode) {
 }
 
 extern "C" int pcnn_get_math_mode(pcnn_handle h) { return h ? h->math_mode : -1; }
+
+extern "C" int pcnn_set_spectral_mode(pcnn_handle h, int mode) {
+  if (!h) return 1;
+  PCNN_REQUIRE(h, mode >= -1 && mode <= 1, "pcnn_set_spectral_mode: unknown mode %d", mode);
+  h->spectral_mode = mode;
+  return 0;
+}
+
+extern "C" int pcnn_get_spectral_mode(pcnn_handle h) { return h ? h->spectral_mode : -2; }

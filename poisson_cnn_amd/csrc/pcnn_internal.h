@@ -14,6 +14,9 @@ struct pcnn_handle_s {
   size_t scratch_bytes = 0;
   int math_mode = 0;              // PCNN_MATH_FP32 (exact fp32 MFMA) or PCNN_MATH_SPLIT_F16 (3 x fp16 split, fp32 accumulate)
   float* y_absmax = nullptr;      // set by pcnn_conv2d_fwd_absmax for the duration of one forward launch: receives max|y|
+  void* spec_ws = nullptr;        // spectral-convolution workspace (tables, filter spectrum, tile spectra; grown on demand, owned by the handle)
+  size_t spec_ws_bytes = 0;
+  int spectral_mode = -1;         // PCNN_SPECTRAL_AUTO (cost model) / _OFF / _FORCE, see pcnn_set_spectral_mode
 };
 
 #define PCNN_FAIL(h, ...)                                   \

@@ -1,0 +1,538 @@
+// Tiled spectral convolution in exact fp32 on the CDNA4 matrix cores: the DFT itself is a GEMM.
+//
+// For the wide filters of the Poisson CNN (15x15 ... 5x5, 32 channels) the direct implicit GEMM spends k*k*Cin*Cout MACs per pixel -
+// at the fp32 MFMA rate that is what bounds the whole training step.  Overlap-save in the frequency domain needs ~40x fewer FLOP, but an
+// FFT butterfly network is VALU/LDS work.  On an MFMA machine the 32-point DFT is instead applied as a 32x32 real matrix product
+// (v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation - the same instruction, hence the same arithmetic class, as the direct
+// kernel), with the CHANNEL index in the N / lane dimension, so that every global access of every kernel below is a pixel's (or a
+// spectrum row's) 128-byte channel vector and nothing is ever transposed:
+//
+//   spec_fwd_kernel   window (32 x 32 pixels, boundary-condition padding applied by the loader) -> 1024 spectrum rows per tile:
+//                     x axis real -> half-complex (G), y axis: the two real columns (fx = 0, 16) half-complex again, the 15 complex
+//                     columns a full complex DFT (Fc).  Intermediate U[y][s][c] lives in LDS (128 KB), one workgroup of 8 waves per tile.
+//   spec_mix_kernel   per frequency slot: [Yr | Yi] = [Xr | Xi] M_f over all tiles (M = tiles, K = 2 Cin, N = 2 Cout); M_f holds
+//                     conj(W^)[f] as a real 2x2 block matrix and stays in registers while the tiles stream through.
+//   spec_inv_kernel   inverse transforms + the fused conv epilogue (bias, activation, BN affine, residual, act_out, max|y|) on the valid
+//                     (33-k)^2 outputs of the tile, stored as NHWC channel rows straight from the accumulators.
+//   spec_wmix_kernel  weight gradient: P_f = sum_tiles [Xr | Xi]^T [Dr | Di] (K = tiles), combined to X^ conj(D^) and inverse-transformed
+//                     by spec_inv_kernel as a one-tile "image" with Cin*Cout channels; the first k x k taps are dw.
+// The filter spectrum is produced by spec_fwd_kernel too (the filter is a kh x kw image with Cin*Cout channels).
+// Index conventions: tools/spectral_model.py (numpy model, checked against direct correlation).
+#include "pcnn_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+
+int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
+                           const float* bn_shift, const float* residual, float* y, float* act_out);
+int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw);
+bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad);
+
+namespace {
+
+constexpr int T = 32, ROWS = 1024, NSLOT = 512;
+constexpr int TAB_G = 0, TAB_GI = 1024, TAB_FC = 2048, TAB_FI = 2048 + 4096, TAB_FLOATS = 2048 + 8192;
+constexpr size_t LDS_U = (size_t)T * T * 32 * sizeof(float);   // 128 KB
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+// accumulator register r of lane (half) <-> row of the 32x32 tile
+__device__ __forceinline__ int acc_row(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
+
+// ------------------------------------------------------------------------------------------------------------------ forward transform
+struct FwdParams {
+  const float* x; float* sp; const float* tab;
+  int H, W, C, ld, groups, cstride, cvalid;
+  int tiles_x, tiles_y, tile0;
+  int Vy, Vx, oy, ox, pad_mode; float pad_value;
+  int ylim, xlim;
+};
+
+__global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*32 + c]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int g = blockIdx.y;
+  int t = p.tile0 + blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int wy0 = ty * p.Vy - p.oy, wx0 = tx * p.Vx - p.ox;
+  const int chan = g * p.cstride + c;
+  const bool cok = c < p.cvalid && chan < p.C;
+  const float* xin = p.x + (int64_t)n * p.H * p.W * p.ld + (cok ? chan : 0);
+
+  // ---- x axis: D_y[s][c] = sum_x G[s][x] xw[y][x][c]; A = G (lane = s), B = the pixel's channel row (lane = c), two x per MFMA
+  float greg[16];
+#pragma unroll
+  for (int xs = 0; xs < 16; ++xs) greg[xs] = p.tab[TAB_G + (2 * xs + half) * 32 + c];
+  int sxo[16];                                                         // source column offset (floats) of this lane-half, -1: constant
+#pragma unroll
+  for (int xs = 0; xs < 16; ++xs) {
+    const int xc = 2 * xs + half;
+    const int sx = pcnn_pad_index(wx0 + xc, p.W, p.pad_mode);
+    sxo[xs] = xc >= p.xlim ? -2 : (sx < 0 ? -1 : sx * p.ld);
+  }
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int y = wave + 8 * i;
+    const int sy = pcnn_pad_index(wy0 + y, p.H, p.pad_mode);
+    const bool rowzero = y >= p.ylim || !cok;
+    const float* row = xin + (int64_t)(sy < 0 ? 0 : sy) * p.W * p.ld;
+    float v[16];
+#pragma unroll
+    for (int xs = 0; xs < 16; ++xs) v[xs] = row[sxo[xs] < 0 ? 0 : sxo[xs]];
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int xs = 0; xs < 16; ++xs) {
+      float val = (sy < 0 || sxo[xs] == -1) ? p.pad_value : v[xs];
+      if (rowzero || sxo[xs] == -2) val = 0.f;
+      acc = mfma(greg[xs], val, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) U[(y * 32 + acc_row(r, half)) * 32 + c] = acc[r];
+  }
+  // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = 0 -> real part rows, h = 1 -> imaginary part rows.
+  const int h = wave & 1, q = wave >> 1;
+  float fcreg[32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) fcreg[ks] = p.tab[TAB_FC + (2 * ks + half) * 64 + 32 * h + c];
+  __syncthreads();
+  float* out = p.sp + ((int64_t)blockIdx.x * p.groups + g) * ROWS * 32;
+#pragma unroll 1
+  for (int fx = 1 + q; fx <= 15; fx += 4) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const int yk = (2 * ks + half) & 31, s = ks < 16 ? fx : 16 + fx;
+      acc = mfma(fcreg[ks], U[(yk * 32 + s) * 32 + c], acc);
+    }
+    float* o = out + (64 + 64 * (fx - 1) + 32 * h) * 32 + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[acc_row(r, half) * 32] = acc[r];
+  }
+  if (q == 3) {                                                        // the two real columns: fx = 0 (wave 6), fx = 16 (wave 7)
+    const int col = h ? 16 : 0;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = mfma(greg[ks], U[((2 * ks + half) * 32 + col) * 32 + c], acc);
+    float* o = out + (h ? 32 : 0) * 32 + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[acc_row(r, half) * 32] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ inverse transform + epilogue
+struct InvParams {
+  const float* sp; const float* tab;
+  float* y; const float* bias; const float* bn_scale; const float* bn_shift; const float* res; float* act_out; unsigned* absmax;
+  int Ho, Wo, C, ldy, ld_res, ld_act, groups, cstride, cvalid, act; float alpha;
+  int tiles_x, tiles_y, tile0, Vy, Vx;
+};
+
+__global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float U[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int g = blockIdx.y;
+  int t = p.tile0 + blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int y0 = ty * p.Vy, x0 = tx * p.Vx;
+  const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0);
+  const float* in = p.sp + ((int64_t)blockIdx.x * p.groups + g) * ROWS * 32 + c;
+  const int h = wave & 1, q = wave >> 1;
+  float fireg[32], gireg[16];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) fireg[ks] = p.tab[TAB_FI + (2 * ks + half) * 64 + 32 * h + c];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) gireg[ks] = p.tab[TAB_GI + (2 * ks + half) * 32 + c];
+  // ---- y axis inverse: complex columns -> U[y][fx] (h = 0) / U[y][16 + fx] (h = 1); real columns -> U[y][0], U[y][16]
+#pragma unroll 1
+  for (int fx = 1 + q; fx <= 15; fx += 4) {
+    const float* src = in + (64 + 64 * (fx - 1)) * 32;
+    float b[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) b[ks] = src[(2 * ks + half) * 32];
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) acc = mfma(fireg[ks], b[ks], acc);
+    const int s = h ? 16 + fx : fx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) U[(acc_row(r, half) * 32 + s) * 32 + c] = acc[r];
+  }
+  if (q == 3) {
+    const float* src = in + (h ? 32 : 0) * 32;
+    float b[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) b[ks] = src[(2 * ks + half) * 32];
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], b[ks], acc);
+    const int s = h ? 16 : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) U[(acc_row(r, half) * 32 + s) * 32 + c] = acc[r];
+  }
+  __syncthreads();
+  // ---- x axis inverse on the valid rows + epilogue (lane = channel: per-channel constants are per-lane scalars)
+  const int chan = g * p.cstride + c;
+  const bool cok = c < p.cvalid && chan < p.C;
+  const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
+  const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
+  float ymax = 0.f;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int yy = wave + 8 * i;
+    if (yy >= vy) break;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], U[(yy * 32 + 2 * ks + half) * 32 + c], acc);
+    const int64_t rowpix = ((int64_t)n * p.Ho + y0 + yy) * p.Wo + x0;
+    if (cok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int xx = acc_row(r, half);
+        if (xx < vx) {
+          const int64_t pix = rowpix + xx;
+          float v = pcnn_act(acc[r] + bias, p.act, p.alpha);
+          if (p.act_out) p.act_out[pix * p.ld_act + chan] = v;
+          v = v * sc + sh;
+          if (p.res) v += p.res[pix * p.ld_res + chan];
+          p.y[pix * p.ldy + chan] = v;
+          ymax = fmaxf(ymax, fabsf(v));
+        }
+      }
+    }
+  }
+  if (p.absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (lane == 0) {
+      const unsigned bits = __float_as_uint(ymax <= 3.0e38f ? ymax : 3.0e38f);
+      if (bits > __atomic_load_n(p.absmax, __ATOMIC_RELAXED)) atomicMax(p.absmax, bits);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ per-frequency channel mixing
+struct MixParams { const float* xs; float* ys; const float* M; const int4* slots; int ntile, gin; };
+
+// K order inside one 64-row block of M_f (one input channel group): step ks = 16 p + j pairs channel j (lanes 0-31) with channel 16 + j
+// (lanes 32-63) of part p (0: real row, 1: imaginary row) - so a lane's A operands are 16 CONSECUTIVE channels of its tile's row.
+template <int GIN>
+__global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int slot = blockIdx.x;
+  const int4 sl = p.slots[slot];
+  const int rr = sl.x, ri = sl.y;
+  float breg[GIN][32][2];
+#pragma unroll
+  for (int gi = 0; gi < GIN; ++gi)
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const int k = (ks >> 4) * 32 + (ks & 15) + 16 * half;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) breg[gi][ks][nt] = p.M[(((int64_t)slot * GIN + gi) * 64 + k) * 64 + nt * 32 + c];
+    }
+  const int nMt = (p.ntile + 31) >> 5;
+  for (int mt = blockIdx.y * 4 + wave; mt < nMt; mt += gridDim.y * 4) {
+    const int tile = min(mt * 32 + c, p.ntile - 1);
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int gi = 0; gi < GIN; ++gi) {
+      const float* base = p.xs + ((int64_t)tile * GIN + gi) * ROWS * 32 + 16 * half;
+      f32x4 a[2][4];
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * 32 + 4 * j4);
+        a[1][j4] = *reinterpret_cast<const f32x4*>(base + ri * 32 + 4 * j4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        const float av = a[ks >> 4][(ks & 15) >> 2][ks & 3];
+        acc[0] = mfma(av, breg[gi][ks][0], acc[0]);
+        acc[1] = mfma(av, breg[gi][ks][1], acc[1]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = nt ? ri : rr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = mt * 32 + acc_row(r, half);
+        if (trow < p.ntile) p.ys[((int64_t)trow * ROWS + row) * 32 + c] = acc[nt][r];
+      }
+    }
+  }
+}
+
+// M_f from the filter spectrum Wsp[ci][row][co] (conj: correlation).  M[slot][gi][k = 32 part_in + ci%32][n = 32 part_out + co]
+__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin) {
+  const int64_t total = (int64_t)NSLOT * gin * 64 * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int nn = i & 63; int64_t r = i >> 6; const int k = r & 63; r >>= 6; const int gi = r % gin; const int slot = r / gin;
+    const int pin = k >> 5, cil = k & 31, pout = nn >> 5, co = nn & 31;
+    const int ci = gi * 32 + cil;
+    const int4 sl = slots[slot];
+    float v = 0.f;
+    if (ci < Cin) {
+      const float wr = wsp[((int64_t)ci * ROWS + sl.x) * 32 + co], wi = wsp[((int64_t)ci * ROWS + sl.y) * 32 + co];
+      if (sl.z == 1) v = (pin == 0 && pout == 0) ? wr : ((pin == 1 && pout == 1) ? wi : 0.f);     // two real frequencies packed in one slot
+      else v = pin == pout ? wr : (pin == 0 ? -wi : wi);                                          // [[Hr, Hi], [-Hi, Hr]], H = conj(W)
+    }
+    M[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ weight gradient
+struct WMixParams { const float* xs; const float* ds; float* part; const int4* slots; int ntile, gin, S, accumulate; };
+
+// P[slot][gi][quadrant (mq, nq)][ci][co] = sum over this split's tiles of X[tile][row(mq)][ci] * D[tile][row(nq)][co]
+__global__ __launch_bounds__(256) void spec_wmix_kernel(WMixParams p) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int slot = blockIdx.x, s = blockIdx.y, gi = blockIdx.z;
+  const int4 sl = p.slots[slot];
+  const int rowA = (wave & 1) ? sl.y : sl.x, rowB = (wave >> 1) ? sl.y : sl.x;
+  const int per = (((p.ntile + p.S - 1) / p.S) + 1) & ~1;
+  const int t0 = s * per, t1 = min(t0 + per, p.ntile);
+  const float* xa = p.xs + ((int64_t)gi * ROWS + rowA) * 32 + c;
+  const float* db = p.ds + (int64_t)rowB * 32 + c;
+  const int64_t xstride = (int64_t)p.gin * ROWS * 32, dstride = (int64_t)ROWS * 32;
+  f32x16 acc = zero16();
+  for (int tb = t0; tb < t1; tb += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int tt = tb + 2 * u + half;
+      const int tc = tt < t1 ? tt : t0;
+      a[u] = xa[tc * xstride]; b[u] = db[tc * dstride];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int tt = tb + 2 * u + half;
+      acc = mfma(tt < t1 ? a[u] : 0.f, b[u], acc);
+    }
+  }
+  float* o = p.part + ((((int64_t)s * NSLOT + slot) * p.gin + gi) * 4 + wave) * 1024 + c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float* e = o + acc_row(r, half) * 32;
+    *e = p.accumulate ? *e + acc[r] : acc[r];
+  }
+}
+
+// C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
+// Output: spectrum of a one-tile image with Cin*Cout channels, group = ci, lane = co.
+__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin) {
+  const int64_t total = (int64_t)NSLOT * gin * 1024;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = i & 1023; int64_t r = i >> 10; const int gi = r % gin; const int slot = r / gin;
+    const int cil = e >> 5, co = e & 31, ci = gi * 32 + cil;
+    if (ci >= Cin) continue;
+    float P[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+      const float* b = part + (((int64_t)s * NSLOT + slot) * gin + gi) * 4 * 1024 + e;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) P[qd] += b[qd * 1024];
+    }
+    const int4 sl = slots[slot];
+    // quadrant = (wave & 1 ? imag row of X : real) + 2 * (wave >> 1 ? imag row of D : real): P[0] = 11, P[1] = 21, P[2] = 12, P[3] = 22
+    const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : P[1] - P[2];
+    csp[((int64_t)ci * ROWS + sl.x) * 32 + co] = cr;
+    csp[((int64_t)ci * ROWS + sl.y) * 32 + co] = cim;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ host side
+void build_tables(std::vector<float>& tab, std::vector<int>& slots) {
+  tab.assign(TAB_FLOATS, 0.f);
+  const double tp = 2.0 * M_PI / T;
+  auto G = [&](int s, int x) { return s <= 16 ? cos(tp * s * x) : -sin(tp * (s - 16) * x); };
+  auto Gi = [&](int n, int s) {
+    if (s == 0) return 1.0 / T;
+    if (s == 16) return ((n & 1) ? -1.0 : 1.0) / T;
+    return s < 16 ? 2.0 * cos(tp * s * n) / T : -2.0 * sin(tp * (s - 16) * n) / T;
+  };
+  auto Fc = [&](int m, int k) {                      // [[C, S], [-S, C]]
+    const int a = m & 31, b = k & 31;
+    const double cs = cos(tp * ((a * b) & 31)), sn = sin(tp * ((a * b) & 31));
+    return (m < 32) == (k < 32) ? cs : (m < 32 ? sn : -sn);
+  };
+  for (int k = 0; k < 32; ++k)
+    for (int m = 0; m < 32; ++m) { tab[TAB_G + k * 32 + m] = (float)G(m, k); tab[TAB_GI + k * 32 + m] = (float)Gi(m, k); }
+  for (int k = 0; k < 64; ++k)
+    for (int m = 0; m < 64; ++m) { tab[TAB_FC + k * 64 + m] = (float)Fc(m, k); tab[TAB_FI + k * 64 + m] = (float)(Fc(k, m) / T); }
+  slots.clear();
+  for (int b = 0; b < 2; ++b) {
+    const int base = b ? 32 : 0;
+    slots.insert(slots.end(), {base, base + 16, 1, 0});
+    for (int fy = 1; fy < 16; ++fy) slots.insert(slots.end(), {base + fy, base + 16 + fy, 0, 0});
+  }
+  for (int fx = 1; fx < 16; ++fx)
+    for (int fy = 0; fy < 32; ++fy) slots.insert(slots.end(), {64 + 64 * (fx - 1) + fy, 64 + 64 * (fx - 1) + 32 + fy, 0, 0});
+}
+
+struct Workspace {           // carved out of the handle's spectral workspace
+  float* tab; int4* slots; float* wsp; float* M; float* xs; float* ys; float* part; float* csp;
+};
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int chunk_tiles() {
+  static const int v = getenv("PCNN_SPEC_CHUNK") ? atoi(getenv("PCNN_SPEC_CHUNK")) : 4096;
+  return v < 32 ? 32 : v;
+}
+int wgrad_splits() { return 4; }
+
+// grows the handle's workspace; the constant tables live at its start and are (re)uploaded after every growth
+int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, int gin, int cin, int chunk, bool wgrad) {
+  const size_t o_tab = 0, o_slots = align256(TAB_FLOATS * 4), o_rest = o_slots + align256(NSLOT * 16);
+  const size_t need = o_rest + bytes_after_tables;
+  if (h->spec_ws_bytes < need) {
+    if (h->spec_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->spec_ws); h->spec_ws = nullptr; h->spec_ws_bytes = 0; }
+    const size_t cap = need + need / 8;
+    if (hipMalloc(&h->spec_ws, cap) != hipSuccess) PCNN_FAIL(h, "spectral convolution: cannot allocate %zu B of workspace", cap);
+    h->spec_ws_bytes = cap;
+    static std::vector<float> tab; static std::vector<int> slots;          // static: the async copies below read them after this call returns
+    if (tab.empty()) build_tables(tab, slots);
+    if (hipMemcpyAsync(static_cast<char*>(h->spec_ws) + o_tab, tab.data(), TAB_FLOATS * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(static_cast<char*>(h->spec_ws) + o_slots, slots.data(), NSLOT * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+      PCNN_FAIL(h, "spectral convolution: table upload failed");
+  }
+  char* b = static_cast<char*>(h->spec_ws);
+  ws.tab = reinterpret_cast<float*>(b + o_tab);
+  ws.slots = reinterpret_cast<int4*>(b + o_slots);
+  char* r = b + o_rest;
+  const size_t wsp_b = align256((size_t)cin * ROWS * 32 * 4), M_b = align256((size_t)NSLOT * gin * 64 * 64 * 4);
+  const size_t xs_b = align256((size_t)chunk * gin * ROWS * 32 * 4), ys_b = align256((size_t)chunk * ROWS * 32 * 4);
+  ws.wsp = reinterpret_cast<float*>(r); r += wsp_b;                        // filter spectrum (forward) / C^ (weight gradient)
+  ws.M = reinterpret_cast<float*>(r); r += M_b;
+  ws.xs = reinterpret_cast<float*>(r); r += xs_b;
+  ws.ys = reinterpret_cast<float*>(r); r += ys_b;
+  ws.part = reinterpret_cast<float*>(r);
+  ws.csp = ws.wsp;
+  (void)wgrad;
+  return 0;
+}
+
+size_t workspace_bytes(int gin, int cin, int chunk, bool wgrad) {
+  size_t b = align256((size_t)cin * ROWS * 32 * 4) + align256((size_t)NSLOT * gin * 64 * 64 * 4) + align256((size_t)chunk * gin * ROWS * 32 * 4) +
+             align256((size_t)chunk * ROWS * 32 * 4);
+  if (wgrad) b += align256((size_t)wgrad_splits() * NSLOT * gin * 4 * 1024 * 4);
+  return b;
+}
+
+template <typename K>
+void set_lds(K kernel) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_U); }
+
+void launch_fwd(pcnn_handle h, const FwdParams& p, int ntile) {
+  set_lds(spec_fwd_kernel);
+  hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)ntile, (unsigned)p.groups), dim3(512), LDS_U, h->stream, p);
+}
+void launch_inv(pcnn_handle h, const InvParams& p, int ntile) {
+  set_lds(spec_inv_kernel);
+  hipLaunchKernelGGL(spec_inv_kernel, dim3((unsigned)ntile, (unsigned)p.groups), dim3(512), LDS_U, h->stream, p);
+}
+
+}  // namespace
+
+// Estimated times (seconds) of the two routes for the layer; the spectral route is taken when it is clearly ahead.
+bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad) {
+  const int mode = h->spectral_mode;                       // 0: never, 1: whenever the shape allows, -1: cost model
+  if (mode == 0) return false;
+  if (d->kh > 15 || d->kw > 15 || d->kh < 2 || d->kw < 2 || d->Cin > 64 || d->Cout > 32) return false;
+  if (wgrad && (d->pad_mode != PCNN_PAD_CONSTANT && (d->pad_top > d->H || d->pad_left > d->W))) return false;
+  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const double tiles = (double)d->N * ((d->Ho + Vy - 1) / Vy) * ((d->Wo + Vx - 1) / Vx);
+  if (mode == 1) return true;
+  const int gin = (d->Cin + 31) / 32;
+  const double mf = wgrad ? (gin * 1504.0 + 1100.0 + gin * 1028.0) : (gin * 1504.0 + 1280.0 + gin * 1028.0);      // 32x32x2 MFMAs per tile
+  const double t_spec = tiles * mf * 64.0 / (256.0 * 4 * 2.0e9) / 0.6 + 60e-6;
+  const int cin8 = (d->Cin + 7) & ~7, co32 = (d->Cout + 31) & ~31;
+  const double flop = 2.0 * d->N * d->Ho * d->Wo * d->kh * d->kw * cin8 * co32;
+  const double t_dir = flop / (h->math_mode == PCNN_MATH_SPLIT_F16 ? 330e12 : (wgrad ? 95e12 : 118e12));
+  return t_spec < 0.8 * t_dir;
+}
+
+int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
+                           const float* bn_shift, const float* residual, float* y, float* act_out) {
+  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const int tiles_y = pcnn_cdiv(d->Ho, Vy), tiles_x = pcnn_cdiv(d->Wo, Vx);
+  const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
+  PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
+  const int gin = pcnn_cdiv(d->Cin, 32);
+  const int chunk = (int)std::min<int64_t>(chunk_tiles(), ntile);
+  Workspace ws;
+  if (int rc = ensure_workspace(h, workspace_bytes(gin, d->Cin, chunk, false), ws, gin, d->Cin, chunk, false)) return rc;
+  // filter spectrum: the filter as a kh x kw image with Cin*Cout channels, group = ci, lane = co
+  FwdParams fw;
+  fw.x = w; fw.sp = ws.wsp; fw.tab = ws.tab; fw.H = d->kh; fw.W = d->kw; fw.C = d->Cin * d->Cout; fw.ld = d->Cin * d->Cout; fw.groups = d->Cin;
+  fw.cstride = d->Cout; fw.cvalid = d->Cout; fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
+  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T;
+  launch_fwd(h, fw, 1);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, ws.wsp, ws.slots, ws.M, d->Cin, gin);
+  PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
+  FwdParams fx;
+  fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
+  fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
+  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T;
+  InvParams iv;
+  iv.sp = ws.ys; iv.tab = ws.tab; iv.y = y; iv.bias = bias; iv.bn_scale = bn_scale; iv.bn_shift = bn_shift; iv.res = residual; iv.act_out = act_out;
+  iv.absmax = reinterpret_cast<unsigned*>(h->y_absmax);
+  iv.Ho = d->Ho; iv.Wo = d->Wo; iv.C = d->Cout; iv.ldy = d->ldy; iv.ld_res = d->ld_res; iv.ld_act = d->ld_act_out; iv.groups = 1; iv.cstride = 32; iv.cvalid = 32;
+  iv.act = d->act; iv.alpha = d->act_alpha; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx;
+  MixParams mx;
+  mx.xs = ws.xs; mx.ys = ws.ys; mx.M = ws.M; mx.slots = ws.slots; mx.gin = gin;
+  for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
+    const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
+    fx.tile0 = (int)t0; iv.tile0 = (int)t0; mx.ntile = nt;
+    launch_fwd(h, fx, nt);
+    const int nMt = pcnn_cdiv(nt, 32);
+    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 4));
+    if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy), dim3(256), 0, h->stream, mx);
+    else hipLaunchKernelGGL(spec_mix_kernel<2>, dim3(NSLOT, gy), dim3(256), 0, h->stream, mx);
+    launch_inv(h, iv, nt);
+  }
+  PCNN_CHECK_LAUNCH(h, "spectral convolution");
+  return 0;
+}
+
+int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw) {
+  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const int tiles_y = pcnn_cdiv(d->Ho, Vy), tiles_x = pcnn_cdiv(d->Wo, Vx);
+  const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
+  PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
+  const int gin = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();
+  const int chunk = (int)std::min<int64_t>(chunk_tiles(), ntile);
+  Workspace ws;
+  if (int rc = ensure_workspace(h, workspace_bytes(gin, d->Cin, chunk, true), ws, gin, d->Cin, chunk, true)) return rc;
+  FwdParams fx;
+  fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
+  fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
+  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T;
+  FwdParams fz = fx;                                    // dz: the tile's own Vy x Vx outputs, zero elsewhere in the window
+  fz.x = dz; fz.sp = ws.ys; fz.H = d->Ho; fz.W = d->Wo; fz.C = d->Cout; fz.ld = d->ldy; fz.groups = 1; fz.oy = 0; fz.ox = 0;
+  fz.pad_mode = PCNN_PAD_CONSTANT; fz.pad_value = 0.f; fz.ylim = Vy; fz.xlim = Vx;
+  WMixParams wm;
+  wm.xs = ws.xs; wm.ds = ws.ys; wm.part = ws.part; wm.slots = ws.slots; wm.gin = gin; wm.S = S;
+  for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
+    const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
+    fx.tile0 = (int)t0; fz.tile0 = (int)t0; wm.ntile = nt; wm.accumulate = t0 > 0;
+    launch_fwd(h, fx, nt);
+    launch_fwd(h, fz, nt);
+    hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S, gin), dim3(256), 0, h->stream, wm);
+  }
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, ws.part, ws.slots, ws.csp, S, gin, d->Cin);
+  InvParams iv;
+  iv.sp = ws.csp; iv.tab = ws.tab; iv.y = dw; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = nullptr; iv.act_out = nullptr;
+  iv.absmax = nullptr; iv.Ho = d->kh; iv.Wo = d->kw; iv.C = d->Cin * d->Cout; iv.ldy = d->Cin * d->Cout; iv.ld_res = 0; iv.ld_act = 0;
+  iv.groups = d->Cin; iv.cstride = d->Cout; iv.cvalid = d->Cout; iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f;
+  iv.tiles_x = 1; iv.tiles_y = 1; iv.tile0 = 0; iv.Vy = T; iv.Vx = T;
+  launch_inv(h, iv, 1);
+  PCNN_CHECK_LAUNCH(h, "spectral weight gradient");
+  return 0;
+}

@@ -31,23 +31,37 @@ def set_math_mode(mode):
         h.call('pcnn_set_math_mode', c_int(_math_mode))
 
 
+_spectral_mode = int(__import__('os').environ.get('PCNN_SPECTRAL', '-1'))
+
+
+def set_spectral_mode(mode):
+    """-1 / 'auto' (cost model per layer, default), 0 / 'off' (direct implicit GEMM only), 1 / 'force' (tiled spectral convolution
+    whenever the shape allows): include/pcnn.h pcnn_set_spectral_mode.  Environment: PCNN_SPECTRAL."""
+    global _spectral_mode
+    _spectral_mode = {'auto': -1, 'off': 0, 'force': 1}.get(mode, mode)
+    for h in _handles.values():
+        h.call('pcnn_set_spectral_mode', c_int(_spectral_mode))
+
+
+def get_spectral_mode():
+    return _spectral_mode
+
+
 def get_math_mode():
     return [k for k, v in MATH_MODES.items() if v == _math_mode][0]
 
 
 def handle():
-    """Handle bound to the current device and torch's current stream."""
+    """The libpcnn handle of (current device, torch's current stream): one handle per stream (include/pcnn.h), so the weight gradients on
+    the side stream have their own filter scratch and spectral workspace and never share library state with the main stream."""
     dev = torch.cuda.current_device()
     st = torch.cuda.current_stream().cuda_stream
-    h = _handles.get(dev)
+    h = _handles.get((dev, st))
     if h is None:
         h = _lib.Handle(dev, st)
-        h._stream = st
         h.call('pcnn_set_math_mode', c_int(_math_mode))
-        _handles[dev] = h
-    elif h._stream != st:
-        h.set_stream(st)
-        h._stream = st
+        h.call('pcnn_set_spectral_mode', c_int(_spectral_mode))
+        _handles[(dev, st)] = h
     return h
 
 

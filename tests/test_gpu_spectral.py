@@ -1,0 +1,89 @@
+"""The tiled spectral convolution route (csrc/spectral_conv.hip: overlap-save on 32 x 32 tiles, DFT as fp32 MFMA products) against the
+same fp64 oracle and at the same per-layer tolerance as the direct implicit-GEMM kernels: forward with every epilogue option, data
+gradient, weight gradient, all padding modes, ragged channel counts, tiles that overhang the image, and the whole model."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def spectral_forced():
+    from poisson_cnn_amd import ops
+    prev = ops.get_spectral_mode()
+    ops.set_spectral_mode('force')
+    yield
+    ops.set_spectral_mode(prev)
+
+
+def test_route_is_taken_and_differs_from_direct_only_by_rounding():
+    """Same layer through both routes: results agree to fp32 rounding but are not bit-identical (different summation order) - i.e. the
+    forced mode really runs the spectral kernels."""
+    from poisson_cnn_amd import ops
+    assert ops.handle().lib.pcnn_get_spectral_mode(ops.handle()._h) == 1
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(2, 70, 83, 32, device='cuda', generator=g)
+    w = torch.randn(15, 15, 32, 32, device='cuda', generator=g) * 0.02
+    ys = ops.conv2d_fwd(x, w, None, pad_top=7, pad_left=7)
+    ops.set_spectral_mode('off')
+    yd = ops.conv2d_fwd(x, w, None, pad_top=7, pad_left=7)
+    err = float((ys - yd).double().norm() / yd.double().norm())
+    assert 0 < err < 2e-6
+
+
+def test_forward_cases():
+    import test_gpu_conv as t
+    for case in t.CASES:
+        t.test_padded_conv_matches_oracle(*case)
+    t.test_conv_epilogue_bn_residual_slices()
+    t.test_flip_transpose_and_data_gradient()
+
+
+def test_backward_cases():
+    import test_gpu_ops as t
+    for case in t.BWD_CASES:
+        t.test_conv_backward_matches_autograd(*case)
+
+
+@pytest.mark.parametrize('k,Cin,Cout,H,W', [(15, 32, 32, 120, 101), (13, 28, 28, 75, 140), (7, 64, 32, 90, 90), (5, 20, 16, 64, 64)])
+def test_many_tiles_forward_and_weight_gradient(k, Cin, Cout, H, W):
+    """Several tiles per image in both directions (interior tiles, overhanging last tiles, N > 1) against torch-CPU fp64."""
+    import torch.nn.functional as F
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(k + Cin)
+    N, p = 3, k // 2
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    dz = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xt, wt.permute(3, 2, 0, 1), padding=p)
+    (y * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    xd = torch.tensor(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), device='cuda')
+    dzd = torch.tensor(np.ascontiguousarray(dz.transpose(0, 2, 3, 1)), device='cuda')
+    wd = torch.tensor(w, device='cuda')
+    got = ops.conv2d_fwd(xd, wd, None, pad_top=p, pad_left=p).cpu().numpy().transpose(0, 3, 1, 2)
+    ref = y.detach().numpy()
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-6
+    dw = ops.conv2d_wgrad(xd, dzd, w.shape, pad_top=p, pad_left=p).cpu().numpy()
+    assert np.linalg.norm(dw - wt.grad.numpy()) / np.linalg.norm(wt.grad.numpy()) < 5e-6
+    dx = ops.conv2d_fwd(dzd, ops.flip_transpose_weights(wd), None, pad_top=k - 1 - p, pad_left=k - 1 - p).cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.linalg.norm(dx - xt.grad.numpy()) / np.linalg.norm(xt.grad.numpy()) < 2e-6
+
+
+def test_whole_model_forward_and_gradients():
+    import test_gpu_model as t
+    t.test_hpnn_forward_matches_oracle('dirichlet')
+    t.test_forward_matches_committed_golden_vectors()
+    t.test_tiny_model_train_step('neumann', 6e-4)
+    t.test_hpnn_train_step_gradients('tf.nn.tanh', 3e-4)
+
+
+def test_adjoint_identities_at_full_size():
+    """8 x 1024^2, 15 x 15, 32 -> 32: <conv(x; w), g> = <w, wgrad(x, g)> = <x, dgrad(g; w)> through the spectral route."""
+    import test_gpu_fullsize as t
+    t.test_conv_adjoint_identities_at_full_size('fp32', 'CONSTANT')
+    t.test_conv_adjoint_identities_at_full_size('fp32', 'SYMMETRIC')
