@@ -33,6 +33,7 @@ namespace {
 constexpr int T = 32, ROWS = 1024, NSLOT = 512;
 constexpr int TAB_G = 0, TAB_GI = 1024, TAB_FC = 2048, TAB_FI = 2048 + 4096, TAB_FLOATS = 2048 + 8192;
 constexpr size_t LDS_U = (size_t)T * T * 32 * sizeof(float);   // 128 KB
+constexpr size_t LDS_INV = LDS_U + (64 * 64 + 32 * 32) * sizeof(float);   // + the inverse tables
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 zero16() {
@@ -48,81 +49,127 @@ __device__ __forceinline__ int acc_row(int r, int half) { return 8 * (r >> 2) + 
 struct FwdParams {
   const float* x; float* sp; const float* tab;
   int H, W, C, ld, groups, cstride, cvalid;
-  int tiles_x, tiles_y, tile0;
+  int tiles_x, tiles_y, tile0, ntile;
   int Vy, Vx, oy, ox, pad_mode; float pad_value;
   int ylim, xlim;
 };
 
-__global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*32 + c]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
-  const int g = blockIdx.y;
-  int t = p.tile0 + blockIdx.x;
+// one (tile, channel group) work item as the loader sees it: a wave-uniform image base plus 32-bit per-lane offsets (so the loads take
+// the scalar-base + vector-offset form and no 64-bit address lives in vector registers)
+struct FwdItem {
+  const float* img;      // uniform: image n
+  int wy0;               // uniform: window origin row
+  unsigned off[16];      // lane: float offset of window column 2 xs + half (clamped into the image) + this lane's channel
+  unsigned cmask, zmask; // bit xs: column is constant padding / lies beyond xlim (zero)
+  bool cok;              // this lane's channel exists
+};
+
+__device__ __forceinline__ void fwd_item(const FwdParams& p, int item, int half, int c, FwdItem& it) {
+  const int g = item % p.groups;
+  int t = p.tile0 + item / p.groups;
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y;
   const int n = t / p.tiles_y;
-  const int wy0 = ty * p.Vy - p.oy, wx0 = tx * p.Vx - p.ox;
   const int chan = g * p.cstride + c;
-  const bool cok = c < p.cvalid && chan < p.C;
-  const float* xin = p.x + (int64_t)n * p.H * p.W * p.ld + (cok ? chan : 0);
-
-  // ---- x axis: D_y[s][c] = sum_x G[s][x] xw[y][x][c]; A = G (lane = s), B = the pixel's channel row (lane = c), two x per MFMA
-  float greg[16];
-#pragma unroll
-  for (int xs = 0; xs < 16; ++xs) greg[xs] = p.tab[TAB_G + (2 * xs + half) * 32 + c];
-  int sxo[16];                                                         // source column offset (floats) of this lane-half, -1: constant
+  it.cok = c < p.cvalid && chan < p.C;
+  it.img = p.x + (int64_t)n * p.H * p.W * p.ld;
+  it.wy0 = ty * p.Vy - p.oy;
+  const int wx0 = tx * p.Vx - p.ox;
+  it.cmask = 0u; it.zmask = 0u;
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) {
     const int xc = 2 * xs + half;
     const int sx = pcnn_pad_index(wx0 + xc, p.W, p.pad_mode);
-    sxo[xs] = xc >= p.xlim ? -2 : (sx < 0 ? -1 : sx * p.ld);
+    if (sx < 0) it.cmask |= 1u << xs;
+    if (xc >= p.xlim) it.zmask |= 1u << xs;
+    it.off[xs] = (unsigned)((sx < 0 ? 0 : sx) * p.ld + (it.cok ? chan : 0));
   }
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    const int y = wave + 8 * i;
-    const int sy = pcnn_pad_index(wy0 + y, p.H, p.pad_mode);
-    const bool rowzero = y >= p.ylim || !cok;
-    const float* row = xin + (int64_t)(sy < 0 ? 0 : sy) * p.W * p.ld;
-    float v[16];
+}
+// issues the 16 loads of window row y (always-valid addresses; padding is applied when the values are consumed).  y is wave-uniform.
+__device__ __forceinline__ void fwd_load_row(const FwdParams& p, const FwdItem& it, int y, float (&v)[16]) {
+  const int sy = pcnn_pad_index(it.wy0 + y, p.H, p.pad_mode);
+  const float* row = it.img + (int64_t)(sy < 0 ? 0 : sy) * p.W * p.ld;
 #pragma unroll
-    for (int xs = 0; xs < 16; ++xs) v[xs] = row[sxo[xs] < 0 ? 0 : sxo[xs]];
-    f32x16 acc = zero16();
+  for (int xs = 0; xs < 16; ++xs) v[xs] = row[it.off[xs]];
+}
+__device__ __forceinline__ f32x16 fwd_row_mfma(const FwdParams& p, const FwdItem& it, int y, const float (&greg)[16], const float (&v)[16]) {
+  const int sy = pcnn_pad_index(it.wy0 + y, p.H, p.pad_mode);
+  const bool rowzero = y >= p.ylim || !it.cok;
+  f32x16 acc = zero16();
 #pragma unroll
-    for (int xs = 0; xs < 16; ++xs) {
-      float val = (sy < 0 || sxo[xs] == -1) ? p.pad_value : v[xs];
-      if (rowzero || sxo[xs] == -2) val = 0.f;
-      acc = mfma(greg[xs], val, acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) U[(y * 32 + acc_row(r, half)) * 32 + c] = acc[r];
+  for (int xs = 0; xs < 16; ++xs) {
+    float val = (sy < 0 || ((it.cmask >> xs) & 1u)) ? p.pad_value : v[xs];
+    if (rowzero || ((it.zmask >> xs) & 1u)) val = 0.f;
+    acc = mfma(greg[xs], val, acc);
   }
-  // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = 0 -> real part rows, h = 1 -> imaginary part rows.
+  return acc;
+}
+
+// Persistent: one workgroup (8 waves) per CU walks the (tile, group) items; the first window row of the next item is requested before
+// the y-axis phase of the current one, every other row one row ahead (two register sets, ping-pong), so the global-load latency sits
+// under MFMAs.
+__global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*32 + c]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = wave & 1, q = wave >> 1;
-  float fcreg[32];
+  const int total = p.ntile * p.groups;
+  int item = blockIdx.x;
+  if (item >= total) return;
+  float greg[16], fcreg[32];
+#pragma unroll
+  for (int xs = 0; xs < 16; ++xs) greg[xs] = p.tab[TAB_G + (2 * xs + half) * 32 + c];
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) fcreg[ks] = p.tab[TAB_FC + (2 * ks + half) * 64 + 32 * h + c];
-  __syncthreads();
-  float* out = p.sp + ((int64_t)blockIdx.x * p.groups + g) * ROWS * 32;
-#pragma unroll 1
-  for (int fx = 1 + q; fx <= 15; fx += 4) {
-    f32x16 acc = zero16();
+  FwdItem cur;
+  fwd_item(p, item, half, c, cur);
+  float v0[16], v1[16];
+  fwd_load_row(p, cur, wave, v0);
+  for (;;) {
+    const int next = item + gridDim.x;
+    // ---- x axis: D_y[s][c] = sum_x G[s][x] xw[y][x][c]; A = G (lane = s), B = the pixel's channel row (lane = c), two x per MFMA
+    auto store_u = [&](int y, const f32x16& acc) {
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {
-      const int yk = (2 * ks + half) & 31, s = ks < 16 ? fx : 16 + fx;
-      acc = mfma(fcreg[ks], U[(yk * 32 + s) * 32 + c], acc);
+      for (int r = 0; r < 16; ++r) U[(y * 32 + acc_row(r, half)) * 32 + c] = acc[r];
+    };
+    fwd_load_row(p, cur, wave + 8, v1);
+    store_u(wave, fwd_row_mfma(p, cur, wave, greg, v0));
+    fwd_load_row(p, cur, wave + 16, v0);
+    store_u(wave + 8, fwd_row_mfma(p, cur, wave + 8, greg, v1));
+    fwd_load_row(p, cur, wave + 24, v1);
+    store_u(wave + 16, fwd_row_mfma(p, cur, wave + 16, greg, v0));
+    {
+      const f32x16 acc = fwd_row_mfma(p, cur, wave + 24, greg, v1);
+      if (next < total) { fwd_item(p, next, half, c, cur); fwd_load_row(p, cur, wave, v0); }   // `cur` now describes the next item
+      store_u(wave + 24, acc);
     }
-    float* o = out + (64 + 64 * (fx - 1) + 32 * h) * 32 + c;
+    __syncthreads();
+    // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = 0 -> real part rows, h = 1 -> imaginary part rows.
+    float* out = p.sp + (int64_t)item * ROWS * 32;
+#pragma unroll 1
+    for (int fx = 1 + q; fx <= 15; fx += 4) {
+      f32x16 acc = zero16();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[acc_row(r, half) * 32] = acc[r];
-  }
-  if (q == 3) {                                                        // the two real columns: fx = 0 (wave 6), fx = 16 (wave 7)
-    const int col = h ? 16 : 0;
-    f32x16 acc = zero16();
+      for (int ks = 0; ks < 32; ++ks) {
+        const int yk = (2 * ks + half) & 31, s = ks < 16 ? fx : 16 + fx;
+        acc = mfma(fcreg[ks], U[(yk * 32 + s) * 32 + c], acc);
+      }
+      float* o = out + (64 + 64 * (fx - 1) + 32 * h) * 32;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) acc = mfma(greg[ks], U[((2 * ks + half) * 32 + col) * 32 + c], acc);
-    float* o = out + (h ? 32 : 0) * 32 + c;
+      for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
+    }
+    if (q == 3) {                                                        // the two real columns: fx = 0 (wave 6), fx = 16 (wave 7)
+      const int col = h ? 16 : 0;
+      f32x16 acc = zero16();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[acc_row(r, half) * 32] = acc[r];
+      for (int ks = 0; ks < 16; ++ks) acc = mfma(greg[ks], U[((2 * ks + half) * 32 + col) * 32 + c], acc);
+      float* o = out + (h ? 32 : 0) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
+    }
+    if (next >= total) break;
+    item = next;
+    __syncthreads();                                                     // U is free for the next item
   }
 }
 
@@ -131,82 +178,108 @@ struct InvParams {
   const float* sp; const float* tab;
   float* y; const float* bias; const float* bn_scale; const float* bn_shift; const float* res; float* act_out; unsigned* absmax;
   int Ho, Wo, C, ldy, ld_res, ld_act, groups, cstride, cvalid, act; float alpha;
-  int tiles_x, tiles_y, tile0, Vy, Vx;
+  int tiles_x, tiles_y, tile0, ntile, Vy, Vx;
 };
+
+// unit u of wave (q, h): complex column fx = 1 + q + 4u (32 K steps), or - q == 3, u == 3 - the real column 0 / 16 (16 K steps).
+// `in` is the item's uniform base, `loff` = 32 half + c the lane's offset.
+__device__ __forceinline__ void inv_load_unit(const float* in, int q, int h, unsigned loff, int u, float (&b)[32]) {
+  const bool realcol = q == 3 && u == 3;
+  const float* src = in + (realcol ? (h ? 32 : 0) : 64 + 64 * (q + 4 * u)) * 32;
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks)
+    if (ks < 16 || !realcol) b[ks] = src[loff + 64u * ks];
+}
 
 __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   extern __shared__ __attribute__((aligned(16))) float U[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
-  const int g = blockIdx.y;
-  int t = p.tile0 + blockIdx.x;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int n = t / p.tiles_y;
-  const int y0 = ty * p.Vy, x0 = tx * p.Vx;
-  const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0);
-  const float* in = p.sp + ((int64_t)blockIdx.x * p.groups + g) * ROWS * 32 + c;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = wave & 1, q = wave >> 1;
-  float fireg[32], gireg[16];
-#pragma unroll
-  for (int ks = 0; ks < 32; ++ks) fireg[ks] = p.tab[TAB_FI + (2 * ks + half) * 64 + 32 * h + c];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) gireg[ks] = p.tab[TAB_GI + (2 * ks + half) * 32 + c];
-  // ---- y axis inverse: complex columns -> U[y][fx] (h = 0) / U[y][16 + fx] (h = 1); real columns -> U[y][0], U[y][16]
-#pragma unroll 1
-  for (int fx = 1 + q; fx <= 15; fx += 4) {
-    const float* src = in + (64 + 64 * (fx - 1)) * 32;
-    float b[32];
-#pragma unroll
-    for (int ks = 0; ks < 32; ++ks) b[ks] = src[(2 * ks + half) * 32];
-    f32x16 acc = zero16();
-#pragma unroll
-    for (int ks = 0; ks < 32; ++ks) acc = mfma(fireg[ks], b[ks], acc);
-    const int s = h ? 16 + fx : fx;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) U[(acc_row(r, half) * 32 + s) * 32 + c] = acc[r];
-  }
-  if (q == 3) {
-    const float* src = in + (h ? 32 : 0) * 32;
-    float b[16];
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) b[ks] = src[(2 * ks + half) * 32];
-    f32x16 acc = zero16();
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], b[ks], acc);
-    const int s = h ? 16 : 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) U[(acc_row(r, half) * 32 + s) * 32 + c] = acc[r];
-  }
+  const unsigned loff = 32u * half + c;
+  const int total = p.ntile * p.groups;
+  int item = blockIdx.x;
+  if (item >= total) return;
+  // the inverse tables live in LDS behind U (registers hold two prefetched operand sets instead): FI[k][m] 64 x 64, GI[k][m] 32 x 32
+  float* const FI = U + T * T * 32;
+  float* const GI = FI + 64 * 64;
+  for (int i = tid; i < 64 * 64; i += 512) FI[i] = p.tab[TAB_FI + i];
+  for (int i = tid; i < 32 * 32; i += 512) GI[i] = p.tab[TAB_GI + i];
   __syncthreads();
-  // ---- x axis inverse on the valid rows + epilogue (lane = channel: per-channel constants are per-lane scalars)
-  const int chan = g * p.cstride + c;
-  const bool cok = c < p.cvalid && chan < p.C;
-  const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
-  const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
+  const float* const fi = FI + half * 64 + 32 * h + c;      // + 128 ks
+  const float* const gi = GI + half * 32 + c;               // + 64 ks
+  float b0[32], b1[32];
+  inv_load_unit(p.sp + (int64_t)item * ROWS * 32, q, h, loff, 0, b0);
   float ymax = 0.f;
+  for (;;) {
+    const int next = item + gridDim.x;
+    const float* in = p.sp + (int64_t)item * ROWS * 32;
+    // ---- y axis inverse: complex columns -> U[y][fx] (h = 0) / U[y][16 + fx] (h = 1); real columns -> U[y][0], U[y][16]
+    auto unit = [&](int u, const float (&b)[32]) {
+      const bool realcol = q == 3 && u == 3;
+      f32x16 acc = zero16();
+      if (!realcol) {
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) acc = mfma(fi[128 * ks], b[ks], acc);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(gi[64 * ks], b[ks], acc);
+      }
+      const int fx = 1 + q + 4 * u;
+      const int s = realcol ? (h ? 16 : 0) : (h ? 16 + fx : fx);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) U[(acc_row(r, half) * 32 + s) * 32 + c] = acc[r];
+    };
+    inv_load_unit(in, q, h, loff, 1, b1);
+    unit(0, b0);
+    inv_load_unit(in, q, h, loff, 2, b0);
+    unit(1, b1);
+    inv_load_unit(in, q, h, loff, 3, b1);
+    unit(2, b0);
+    if (next < total) inv_load_unit(p.sp + (int64_t)next * ROWS * 32, q, h, loff, 0, b0);
+    unit(3, b1);
+    __syncthreads();
+    // ---- x axis inverse on the valid rows + epilogue (lane = channel: per-channel constants are per-lane scalars)
+    {
+      const int g = item % p.groups;
+      int t = p.tile0 + item / p.groups;
+      const int tx = t % p.tiles_x; t /= p.tiles_x;
+      const int ty = t % p.tiles_y;
+      const int n = t / p.tiles_y;
+      const int y0 = ty * p.Vy, x0 = tx * p.Vx;
+      const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0);
+      const int chan = g * p.cstride + c;
+      const bool cok = c < p.cvalid && chan < p.C;
+      const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
+      const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
 #pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    const int yy = wave + 8 * i;
-    if (yy >= vy) break;
-    f32x16 acc = zero16();
+      for (int yy = wave; yy < vy; yy += 8) {
+        f32x16 acc = zero16();
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], U[(yy * 32 + 2 * ks + half) * 32 + c], acc);
-    const int64_t rowpix = ((int64_t)n * p.Ho + y0 + yy) * p.Wo + x0;
-    if (cok) {
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(gi[64 * ks], U[(yy * 32 + 2 * ks + half) * 32 + c], acc);
+        const int64_t rowpix = ((int64_t)n * p.Ho + y0 + yy) * p.Wo + x0;
+        float* yrow = p.y + rowpix * p.ldy;
+        float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
+        const float* rrow = p.res ? p.res + rowpix * p.ld_res : nullptr;
+        if (cok) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int xx = acc_row(r, half);
-        if (xx < vx) {
-          const int64_t pix = rowpix + xx;
-          float v = pcnn_act(acc[r] + bias, p.act, p.alpha);
-          if (p.act_out) p.act_out[pix * p.ld_act + chan] = v;
-          v = v * sc + sh;
-          if (p.res) v += p.res[pix * p.ld_res + chan];
-          p.y[pix * p.ldy + chan] = v;
-          ymax = fmaxf(ymax, fabsf(v));
+          for (int r = 0; r < 16; ++r) {
+            const int xx = acc_row(r, half);
+            if (xx < vx) {
+              float v = pcnn_act(acc[r] + bias, p.act, p.alpha);
+              if (arow) arow[(unsigned)(xx * p.ld_act + chan)] = v;
+              v = v * sc + sh;
+              if (rrow) v += rrow[(unsigned)(xx * p.ld_res + chan)];
+              yrow[(unsigned)(xx * p.ldy + chan)] = v;
+              ymax = fmaxf(ymax, fabsf(v));
+            }
+          }
         }
       }
     }
+    if (next >= total) break;
+    item = next;
+    __syncthreads();                                                     // U is free for the next item
   }
   if (p.absmax) {
 #pragma unroll
@@ -239,24 +312,36 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
       for (int nt = 0; nt < 2; ++nt) breg[gi][ks][nt] = p.M[(((int64_t)slot * GIN + gi) * 64 + k) * 64 + nt * 32 + c];
     }
   const int nMt = (p.ntile + 31) >> 5;
-  for (int mt = blockIdx.y * 4 + wave; mt < nMt; mt += gridDim.y * 4) {
+  const int mstride = gridDim.y * 4;
+  auto load_a = [&](int mt, int gi, f32x4 (&a)[2][4]) {
     const int tile = min(mt * 32 + c, p.ntile - 1);
+    const float* base = p.xs + ((int64_t)tile * GIN + gi) * ROWS * 32 + 16 * half;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * 32 + 4 * j4);
+      a[1][j4] = *reinterpret_cast<const f32x4*>(base + ri * 32 + 4 * j4);
+    }
+  };
+  f32x4 a[2][4], an[2][4];
+  int mt = blockIdx.y * 4 + wave;
+  if (mt < nMt) load_a(mt, 0, a);
+  for (; mt < nMt; mt += mstride) {
     f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll
     for (int gi = 0; gi < GIN; ++gi) {
-      const float* base = p.xs + ((int64_t)tile * GIN + gi) * ROWS * 32 + 16 * half;
-      f32x4 a[2][4];
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * 32 + 4 * j4);
-        a[1][j4] = *reinterpret_cast<const f32x4*>(base + ri * 32 + 4 * j4);
-      }
+      // the next operand block (next channel group, or the next M-tile's first group) is requested before this one's MFMAs
+      if (gi + 1 < GIN) load_a(mt, gi + 1, an);
+      else if (mt + mstride < nMt) load_a(mt + mstride, 0, an);
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) {
         const float av = a[ks >> 4][(ks & 15) >> 2][ks & 3];
         acc[0] = mfma(av, breg[gi][ks][0], acc[0]);
         acc[1] = mfma(av, breg[gi][ks][1], acc[1]);
       }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) a[pp][j4] = an[pp][j4];
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -383,7 +468,7 @@ struct Workspace {           // carved out of the handle's spectral workspace
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int chunk_tiles() {
-  static const int v = getenv("PCNN_SPEC_CHUNK") ? atoi(getenv("PCNN_SPEC_CHUNK")) : 4096;
+  static const int v = getenv("PCNN_SPEC_CHUNK") ? atoi(getenv("PCNN_SPEC_CHUNK")) : 8192;
   return v < 32 ? 32 : v;
 }
 int wgrad_splits() { return 4; }
@@ -429,33 +514,39 @@ size_t workspace_bytes(int gin, int cin, int chunk, bool wgrad) {
 template <typename K>
 void set_lds(K kernel) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_U); }
 
-void launch_fwd(pcnn_handle h, const FwdParams& p, int ntile) {
+// persistent kernels: one 8-wave workgroup per CU (128 KB of LDS each) walking the (tile, channel group) items
+void launch_fwd(pcnn_handle h, FwdParams p, int ntile) {
   set_lds(spec_fwd_kernel);
-  hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)ntile, (unsigned)p.groups), dim3(512), LDS_U, h->stream, p);
+  p.ntile = ntile;
+  hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)std::min(ntile * p.groups, 256)), dim3(512), LDS_U, h->stream, p);
 }
-void launch_inv(pcnn_handle h, const InvParams& p, int ntile) {
-  set_lds(spec_inv_kernel);
-  hipLaunchKernelGGL(spec_inv_kernel, dim3((unsigned)ntile, (unsigned)p.groups), dim3(512), LDS_U, h->stream, p);
+void launch_inv(pcnn_handle h, InvParams p, int ntile) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spec_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INV);
+  p.ntile = ntile;
+  hipLaunchKernelGGL(spec_inv_kernel, dim3((unsigned)std::min(ntile * p.groups, 256)), dim3(512), LDS_INV, h->stream, p);
 }
 
 }  // namespace
 
-// Estimated times (seconds) of the two routes for the layer; the spectral route is taken when it is clearly ahead.
+// Route choice.  Both estimates are calibrated on MI355X measurements at 8 x 1024^2 (tools/probe_spectral.py, profiles/r02_probe_spectral.txt):
+// the spectral route costs a fixed time per 32 x 32 tile whatever the filter size (0.26 us per tile with <= 32 input channels, 0.39 us with
+// 64; its three kernels are HBM-bound on the tile spectra), the direct route the layer's padded MAC count over the rate its kernel sustains.
 bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad) {
   const int mode = h->spectral_mode;                       // 0: never, 1: whenever the shape allows, -1: cost model
   if (mode == 0) return false;
   if (d->kh > 15 || d->kw > 15 || d->kh < 2 || d->kw < 2 || d->Cin > 64 || d->Cout > 32) return false;
-  if (wgrad && (d->pad_mode != PCNN_PAD_CONSTANT && (d->pad_top > d->H || d->pad_left > d->W))) return false;
-  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
-  const double tiles = (double)d->N * ((d->Ho + Vy - 1) / Vy) * ((d->Wo + Vx - 1) / Vx);
   if (mode == 1) return true;
-  const int gin = (d->Cin + 31) / 32;
-  const double mf = wgrad ? (gin * 1504.0 + 1100.0 + gin * 1028.0) : (gin * 1504.0 + 1280.0 + gin * 1028.0);      // 32x32x2 MFMAs per tile
-  const double t_spec = tiles * mf * 64.0 / (256.0 * 4 * 2.0e9) / 0.6 + 60e-6;
+  // decided on ONE image, so that a sample's arithmetic never depends on its batch neighbours (the model's per-sample results are
+  // bit-identical for any batch size); images of fewer than 4 tiles stay on the direct route (launch overheads dominate there)
+  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const double tiles = (double)((d->Ho + Vy - 1) / Vy) * ((d->Wo + Vx - 1) / Vx);
+  if (tiles < 4) return false;
+  const double t_spec = tiles * (d->Cin > 32 ? 0.39e-6 : 0.26e-6);
   const int cin8 = (d->Cin + 7) & ~7, co32 = (d->Cout + 31) & ~31;
-  const double flop = 2.0 * d->N * d->Ho * d->Wo * d->kh * d->kw * cin8 * co32;
-  const double t_dir = flop / (h->math_mode == PCNN_MATH_SPLIT_F16 ? 330e12 : (wgrad ? 95e12 : 118e12));
-  return t_spec < 0.8 * t_dir;
+  const double flop = 2.0 * d->Ho * d->Wo * d->kh * d->kw * cin8 * co32;
+  const bool split = h->math_mode == PCNN_MATH_SPLIT_F16;
+  const double rate = split ? (wgrad ? 210e12 : 330e12) : (wgrad ? 95e12 : 118e12);
+  return t_spec < 0.9 * flop / rate;
 }
 
 int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
