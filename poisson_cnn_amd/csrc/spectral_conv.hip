@@ -33,7 +33,6 @@ namespace {
 constexpr int T = 32, ROWS = 1024, NSLOT = 512;
 constexpr int TAB_G = 0, TAB_GI = 1024, TAB_FC = 2048, TAB_FI = 2048 + 4096, TAB_FLOATS = 2048 + 8192;
 constexpr size_t LDS_U = (size_t)T * T * 32 * sizeof(float);   // 128 KB
-constexpr size_t LDS_INV = LDS_U + (64 * 64 + 32 * 32) * sizeof(float);   // + the inverse tables
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 zero16() {
@@ -42,6 +41,10 @@ __device__ __forceinline__ f32x16 zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+// All LDS reads issued so far have landed; nothing moves across.  Without it the compiler sinks every ds_read next to the MFMA that
+// consumes it (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, one LDS round trip exposed per MFMA); with it a unit's operands are
+// fetched as one burst and the MFMA chain then issues back to back.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // accumulator register r of lane (half) <-> row of the 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
 
@@ -86,21 +89,26 @@ __device__ __forceinline__ void fwd_item(const FwdParams& p, int item, int half,
   }
 }
 // issues the 16 loads of window row y (always-valid addresses; padding is applied when the values are consumed).  y is wave-uniform.
+template <bool MASKED>
 __device__ __forceinline__ void fwd_load_row(const FwdParams& p, const FwdItem& it, int y, float (&v)[16]) {
+  if (MASKED && y >= p.ylim) return;                                             // zero row (gradient windows hold Vy x Vx values): nothing to fetch
   const int sy = pcnn_pad_index(it.wy0 + y, p.H, p.pad_mode);
   const float* row = it.img + (int64_t)(sy < 0 ? 0 : sy) * p.W * p.ld;
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) v[xs] = row[it.off[xs]];
 }
+template <bool MASKED>
 __device__ __forceinline__ f32x16 fwd_row_mfma(const FwdParams& p, const FwdItem& it, int y, const float (&greg)[16], const float (&v)[16]) {
   const int sy = pcnn_pad_index(it.wy0 + y, p.H, p.pad_mode);
-  const bool rowzero = y >= p.ylim || !it.cok;
   f32x16 acc = zero16();
+  if (MASKED && y >= p.ylim) return acc;
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) {
-    float val = (sy < 0 || ((it.cmask >> xs) & 1u)) ? p.pad_value : v[xs];
-    if (rowzero || ((it.zmask >> xs) & 1u)) val = 0.f;
-    acc = mfma(greg[xs], val, acc);
+    if (!MASKED || 2 * xs < p.xlim) {                                             // uniform: columns beyond xlim are zero, their K steps are skipped
+      float val = (sy < 0 || ((it.cmask >> xs) & 1u)) ? p.pad_value : v[xs];
+      if (!it.cok || (MASKED && ((it.zmask >> xs) & 1u))) val = 0.f;
+      acc = mfma(greg[xs], val, acc);
+    }
   }
   return acc;
 }
@@ -108,6 +116,9 @@ __device__ __forceinline__ f32x16 fwd_row_mfma(const FwdParams& p, const FwdItem
 // Persistent: one workgroup (8 waves) per CU walks the (tile, group) items; the first window row of the next item is requested before
 // the y-axis phase of the current one, every other row one row ahead (two register sets, ping-pong), so the global-load latency sits
 // under MFMAs.
+// MASKED: the window holds values only in its first ylim x xlim entries (gradient tiles): their zero rows / columns are skipped.
+// FENCE: fetch a unit's LDS operands as one burst before its MFMA chain (see lds_fence).
+template <bool MASKED, bool FENCE>
 __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*32 + c]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
   FwdItem cur;
   fwd_item(p, item, half, c, cur);
   float v0[16], v1[16];
-  fwd_load_row(p, cur, wave, v0);
+  fwd_load_row<MASKED>(p, cur, wave, v0);
   for (;;) {
     const int next = item + gridDim.x;
     // ---- x axis: D_y[s][c] = sum_x G[s][x] xw[y][x][c]; A = G (lane = s), B = the pixel's channel row (lane = c), two x per MFMA
@@ -132,15 +143,15 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) U[(y * 32 + acc_row(r, half)) * 32 + c] = acc[r];
     };
-    fwd_load_row(p, cur, wave + 8, v1);
-    store_u(wave, fwd_row_mfma(p, cur, wave, greg, v0));
-    fwd_load_row(p, cur, wave + 16, v0);
-    store_u(wave + 8, fwd_row_mfma(p, cur, wave + 8, greg, v1));
-    fwd_load_row(p, cur, wave + 24, v1);
-    store_u(wave + 16, fwd_row_mfma(p, cur, wave + 16, greg, v0));
+    fwd_load_row<MASKED>(p, cur, wave + 8, v1);
+    store_u(wave, fwd_row_mfma<MASKED>(p, cur, wave, greg, v0));
+    fwd_load_row<MASKED>(p, cur, wave + 16, v0);
+    store_u(wave + 8, fwd_row_mfma<MASKED>(p, cur, wave + 8, greg, v1));
+    fwd_load_row<MASKED>(p, cur, wave + 24, v1);
+    store_u(wave + 16, fwd_row_mfma<MASKED>(p, cur, wave + 16, greg, v0));
     {
-      const f32x16 acc = fwd_row_mfma(p, cur, wave + 24, greg, v1);
-      if (next < total) { fwd_item(p, next, half, c, cur); fwd_load_row(p, cur, wave, v0); }   // `cur` now describes the next item
+      const f32x16 acc = fwd_row_mfma<MASKED>(p, cur, wave + 24, greg, v1);
+      if (next < total) { fwd_item(p, next, half, c, cur); fwd_load_row<MASKED>(p, cur, wave, v0); }   // `cur` now describes the next item
       store_u(wave + 24, acc);
     }
     __syncthreads();
@@ -148,21 +159,32 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
     float* out = p.sp + (int64_t)item * ROWS * 32;
 #pragma unroll 1
     for (int fx = 1 + q; fx <= 15; fx += 4) {
-      f32x16 acc = zero16();
+      float bu[32];
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) {
         const int yk = (2 * ks + half) & 31, s = ks < 16 ? fx : 16 + fx;
-        acc = mfma(fcreg[ks], U[(yk * 32 + s) * 32 + c], acc);
+        if (!MASKED || 2 * (ks & 15) < p.ylim) bu[ks] = U[(yk * 32 + s) * 32 + c];      // rows beyond ylim are zero: K steps skipped (uniform)
       }
+      if (FENCE) lds_fence();
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks)
+        if (!MASKED || 2 * (ks & 15) < p.ylim) acc = mfma(fcreg[ks], bu[ks], acc);
       float* o = out + (64 + 64 * (fx - 1) + 32 * h) * 32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
     }
     if (q == 3) {                                                        // the two real columns: fx = 0 (wave 6), fx = 16 (wave 7)
       const int col = h ? 16 : 0;
+      float bu[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        if (!MASKED || 2 * ks < p.ylim) bu[ks] = U[((2 * ks + half) * 32 + col) * 32 + c];
+      if (FENCE) lds_fence();
       f32x16 acc = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) acc = mfma(greg[ks], U[((2 * ks + half) * 32 + col) * 32 + c], acc);
+      for (int ks = 0; ks < 16; ++ks)
+        if (!MASKED || 2 * ks < p.ylim) acc = mfma(greg[ks], bu[ks], acc);
       float* o = out + (h ? 32 : 0) * 32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
@@ -191,6 +213,9 @@ __device__ __forceinline__ void inv_load_unit(const float* in, int q, int h, uns
     if (ks < 16 || !realcol) b[ks] = src[loff + 64u * ks];
 }
 
+// TANH = false: linear / relu / leaky-relu as one select with the negative-side slope in p.alpha (1 / 0 / alpha) - sixteen inlined
+// tanhf bodies would otherwise cost every layer ~90 registers and spills
+template <bool TANH>
 __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   extern __shared__ __attribute__((aligned(16))) float U[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
@@ -200,14 +225,11 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   const int total = p.ntile * p.groups;
   int item = blockIdx.x;
   if (item >= total) return;
-  // the inverse tables live in LDS behind U (registers hold two prefetched operand sets instead): FI[k][m] 64 x 64, GI[k][m] 32 x 32
-  float* const FI = U + T * T * 32;
-  float* const GI = FI + 64 * 64;
-  for (int i = tid; i < 64 * 64; i += 512) FI[i] = p.tab[TAB_FI + i];
-  for (int i = tid; i < 32 * 32; i += 512) GI[i] = p.tab[TAB_GI + i];
-  __syncthreads();
-  const float* const fi = FI + half * 64 + 32 * h + c;      // + 128 ks
-  const float* const gi = GI + half * 32 + c;               // + 64 ks
+  float fireg[32], gireg[16];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) fireg[ks] = p.tab[TAB_FI + (2 * ks + half) * 64 + 32 * h + c];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) gireg[ks] = p.tab[TAB_GI + (2 * ks + half) * 32 + c];
   float b0[32], b1[32];
   inv_load_unit(p.sp + (int64_t)item * ROWS * 32, q, h, loff, 0, b0);
   float ymax = 0.f;
@@ -220,10 +242,10 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
       f32x16 acc = zero16();
       if (!realcol) {
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) acc = mfma(fi[128 * ks], b[ks], acc);
+        for (int ks = 0; ks < 32; ++ks) acc = mfma(fireg[ks], b[ks], acc);
       } else {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = mfma(gi[64 * ks], b[ks], acc);
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], b[ks], acc);
       }
       const int fx = 1 + q + 4 * u;
       const int s = realcol ? (h ? 16 : 0) : (h ? 16 + fx : fx);
@@ -254,23 +276,32 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
       const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
 #pragma unroll 1
       for (int yy = wave; yy < vy; yy += 8) {
+        float bu[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bu[ks] = U[(yy * 32 + 2 * ks + half) * 32 + c];
+        lds_fence();
         f32x16 acc = zero16();
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = mfma(gi[64 * ks], U[(yy * 32 + 2 * ks + half) * 32 + c], acc);
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], bu[ks], acc);
         const int64_t rowpix = ((int64_t)n * p.Ho + y0 + yy) * p.Wo + x0;
         float* yrow = p.y + rowpix * p.ldy;
         float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
         const float* rrow = p.res ? p.res + rowpix * p.ld_res : nullptr;
+        // the per-pixel offsets below are invariant across rows and items: left alone, the compiler hoists all 48 of them out of the
+        // persistent loop and keeps them in registers (256 VGPRs + spills); an opaque channel index makes it recompute them (one v_mad each)
+        unsigned chv = (unsigned)chan;
+        asm volatile("" : "+v"(chv));
         if (cok) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int xx = acc_row(r, half);
             if (xx < vx) {
-              float v = pcnn_act(acc[r] + bias, p.act, p.alpha);
-              if (arow) arow[(unsigned)(xx * p.ld_act + chan)] = v;
+              float v = acc[r] + bias;
+              v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+              if (arow) arow[(unsigned)(xx * p.ld_act) + chv] = v;
               v = v * sc + sh;
-              if (rrow) v += rrow[(unsigned)(xx * p.ld_res + chan)];
-              yrow[(unsigned)(xx * p.ldy + chan)] = v;
+              if (rrow) v += rrow[(unsigned)(xx * p.ld_res) + chv];
+              yrow[(unsigned)(xx * p.ldy) + chv] = v;
               ymax = fmaxf(ymax, fabsf(v));
             }
           }
@@ -292,14 +323,14 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ per-frequency channel mixing
-struct MixParams { const float* xs; float* ys; const float* M; const int4* slots; int ntile, gin; };
+struct MixParams { const float* xs; float* ys; const float* M; const int4* slots; int ntile, gin, gout; };
 
 // K order inside one 64-row block of M_f (one input channel group): step ks = 16 p + j pairs channel j (lanes 0-31) with channel 16 + j
 // (lanes 32-63) of part p (0: real row, 1: imaginary row) - so a lane's A operands are 16 CONSECUTIVE channels of its tile's row.
 template <int GIN>
 __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
-  const int slot = blockIdx.x;
+  const int slot = blockIdx.x, go = blockIdx.z;
   const int4 sl = p.slots[slot];
   const int rr = sl.x, ri = sl.y;
   float breg[GIN][32][2];
@@ -309,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
     for (int ks = 0; ks < 32; ++ks) {
       const int k = (ks >> 4) * 32 + (ks & 15) + 16 * half;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) breg[gi][ks][nt] = p.M[(((int64_t)slot * GIN + gi) * 64 + k) * 64 + nt * 32 + c];
+      for (int nt = 0; nt < 2; ++nt) breg[gi][ks][nt] = p.M[((((int64_t)slot * p.gout + go) * GIN + gi) * 64 + k) * 64 + nt * 32 + c];
     }
   const int nMt = (p.ntile + 31) >> 5;
   const int mstride = gridDim.y * 4;
@@ -349,23 +380,25 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int trow = mt * 32 + acc_row(r, half);
-        if (trow < p.ntile) p.ys[((int64_t)trow * ROWS + row) * 32 + c] = acc[nt][r];
+        if (trow < p.ntile) p.ys[(((int64_t)trow * p.gout + go) * ROWS + row) * 32 + c] = acc[nt][r];
       }
     }
   }
 }
 
-// M_f from the filter spectrum Wsp[ci][row][co] (conj: correlation).  M[slot][gi][k = 32 part_in + ci%32][n = 32 part_out + co]
-__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin) {
-  const int64_t total = (int64_t)NSLOT * gin * 64 * 64;
+// M_f from the filter spectrum Wsp[ci * gout + go][row][co % 32] (conj: correlation).
+// M[slot][go][gi][k = 32 part_in + ci % 32][n = 32 part_out + co % 32]
+__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout) {
+  const int64_t total = (int64_t)NSLOT * gout * gin * 64 * 64;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int nn = i & 63; int64_t r = i >> 6; const int k = r & 63; r >>= 6; const int gi = r % gin; const int slot = r / gin;
+    const int nn = i & 63; int64_t r = i >> 6; const int k = r & 63; r >>= 6; const int gi = r % gin; r /= gin; const int go = r % gout; const int slot = r / gout;
     const int pin = k >> 5, cil = k & 31, pout = nn >> 5, co = nn & 31;
     const int ci = gi * 32 + cil;
     const int4 sl = slots[slot];
     float v = 0.f;
     if (ci < Cin) {
-      const float wr = wsp[((int64_t)ci * ROWS + sl.x) * 32 + co], wi = wsp[((int64_t)ci * ROWS + sl.y) * 32 + co];
+      const float* wg = wsp + ((int64_t)(ci * gout + go) * ROWS) * 32 + co;
+      const float wr = wg[sl.x * 32], wi = wg[sl.y * 32];
       if (sl.z == 1) v = (pin == 0 && pout == 0) ? wr : ((pin == 1 && pout == 1) ? wi : 0.f);     // two real frequencies packed in one slot
       else v = pin == pout ? wr : (pin == 0 ? -wi : wi);                                          // [[Hr, Hi], [-Hi, Hr]], H = conj(W)
     }
@@ -376,38 +409,47 @@ __global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4*
 // ------------------------------------------------------------------------------------------------------------------ weight gradient
 struct WMixParams { const float* xs; const float* ds; float* part; const int4* slots; int ntile, gin, S, accumulate; };
 
-// P[slot][gi][quadrant (mq, nq)][ci][co] = sum over this split's tiles of X[tile][row(mq)][ci] * D[tile][row(nq)][co]
-__global__ __launch_bounds__(256) void spec_wmix_kernel(WMixParams p) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
-  const int slot = blockIdx.x, s = blockIdx.y, gi = blockIdx.z;
+// P[slot][gi][quadrant][ci][co] = sum over tiles of [Xr | Xi]^T [Dr | Di]: quadrant 0 = Xr^T Dr, 1 = Xi^T Dr, 2 = Xr^T Di, 3 = Xi^T Di.
+// One wave owns all four quadrants (each operand row is loaded once per tile pair: 4 loads feed 4 MFMAs) for its share of the tiles:
+// K is split over gridDim.y workgroups x 4 waves; the partial sums are combined in a fixed order by spec_wcombine_kernel.
+__global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = blockIdx.x, gi = blockIdx.z;
+  const int part = blockIdx.y * 4 + wave, nparts = p.S * 4;
   const int4 sl = p.slots[slot];
-  const int rowA = (wave & 1) ? sl.y : sl.x, rowB = (wave >> 1) ? sl.y : sl.x;
-  const int per = (((p.ntile + p.S - 1) / p.S) + 1) & ~1;
-  const int t0 = s * per, t1 = min(t0 + per, p.ntile);
-  const float* xa = p.xs + ((int64_t)gi * ROWS + rowA) * 32 + c;
-  const float* db = p.ds + (int64_t)rowB * 32 + c;
-  const int64_t xstride = (int64_t)p.gin * ROWS * 32, dstride = (int64_t)ROWS * 32;
-  f32x16 acc = zero16();
-  for (int tb = t0; tb < t1; tb += 16) {
-    float a[8], b[8];
+  const int per = (((p.ntile + nparts - 1) / nparts) + 1) & ~1;
+  const int t0 = part * per, t1 = min(t0 + per, p.ntile);
+  const float* xr = p.xs + ((int64_t)gi * ROWS + sl.x) * 32, *xi = p.xs + ((int64_t)gi * ROWS + sl.y) * 32;
+  const float* dr = p.ds + (int64_t)sl.x * 32, *di = p.ds + (int64_t)sl.y * 32;
+  const unsigned xstride = (unsigned)p.gin * ROWS * 32, dstride = (unsigned)ROWS * 32;
+  f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+  for (int tb = t0; tb < t1; tb += 8) {
+    float ar[4], ai[4], br[4], bi[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const int tt = tb + 2 * u + half;
-      const int tc = tt < t1 ? tt : t0;
-      a[u] = xa[tc * xstride]; b[u] = db[tc * dstride];
+      const unsigned tc = (unsigned)(tt < t1 ? tt : t0);
+      ar[u] = xr[tc * xstride + c]; ai[u] = xi[tc * xstride + c]; br[u] = dr[tc * dstride + c]; bi[u] = di[tc * dstride + c];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int tt = tb + 2 * u + half;
-      acc = mfma(tt < t1 ? a[u] : 0.f, b[u], acc);
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = tb + 2 * u + half < t1;
+      const float a0 = ok ? ar[u] : 0.f, a1 = ok ? ai[u] : 0.f;
+      acc[0] = mfma(a0, br[u], acc[0]);
+      acc[1] = mfma(a1, br[u], acc[1]);
+      acc[2] = mfma(a0, bi[u], acc[2]);
+      acc[3] = mfma(a1, bi[u], acc[3]);
     }
   }
-  float* o = p.part + ((((int64_t)s * NSLOT + slot) * p.gin + gi) * 4 + wave) * 1024 + c;
+  float* o = p.part + (((int64_t)part * NSLOT + slot) * p.gin + gi) * 4 * 1024 + c;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float* e = o + acc_row(r, half) * 32;
-    *e = p.accumulate ? *e + acc[r] : acc[r];
-  }
+  for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* e = o + qd * 1024 + acc_row(r, half) * 32;
+      *e = p.accumulate ? *e + acc[qd][r] : acc[qd][r];
+    }
 }
 
 // C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
@@ -425,7 +467,7 @@ __global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4*
       for (int qd = 0; qd < 4; ++qd) P[qd] += b[qd * 1024];
     }
     const int4 sl = slots[slot];
-    // quadrant = (wave & 1 ? imag row of X : real) + 2 * (wave >> 1 ? imag row of D : real): P[0] = 11, P[1] = 21, P[2] = 12, P[3] = 22
+    // P[0] = Xr^T Dr, P[1] = Xi^T Dr, P[2] = Xr^T Di, P[3] = Xi^T Di
     const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : P[1] - P[2];
     csp[((int64_t)ci * ROWS + sl.x) * 32 + co] = cr;
     csp[((int64_t)ci * ROWS + sl.y) * 32 + co] = cim;
@@ -471,10 +513,10 @@ int chunk_tiles() {
   static const int v = getenv("PCNN_SPEC_CHUNK") ? atoi(getenv("PCNN_SPEC_CHUNK")) : 8192;
   return v < 32 ? 32 : v;
 }
-int wgrad_splits() { return 4; }
+int wgrad_splits() { return 8; }   // partial sums of the weight-gradient GEMM: 2 workgroups x 4 waves per (slot, channel group)
 
 // grows the handle's workspace; the constant tables live at its start and are (re)uploaded after every growth
-int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, int gin, int cin, int chunk, bool wgrad) {
+int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, int gin, int gout, int cin, int chunk) {
   const size_t o_tab = 0, o_slots = align256(TAB_FLOATS * 4), o_rest = o_slots + align256(NSLOT * 16);
   const size_t need = o_rest + bytes_after_tables;
   if (h->spec_ws_bytes < need) {
@@ -492,21 +534,20 @@ int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, in
   ws.tab = reinterpret_cast<float*>(b + o_tab);
   ws.slots = reinterpret_cast<int4*>(b + o_slots);
   char* r = b + o_rest;
-  const size_t wsp_b = align256((size_t)cin * ROWS * 32 * 4), M_b = align256((size_t)NSLOT * gin * 64 * 64 * 4);
-  const size_t xs_b = align256((size_t)chunk * gin * ROWS * 32 * 4), ys_b = align256((size_t)chunk * ROWS * 32 * 4);
+  const size_t wsp_b = align256((size_t)cin * gout * ROWS * 32 * 4), M_b = align256((size_t)NSLOT * gin * gout * 64 * 64 * 4);
+  const size_t xs_b = align256((size_t)chunk * gin * ROWS * 32 * 4), ys_b = align256((size_t)chunk * gout * ROWS * 32 * 4);
   ws.wsp = reinterpret_cast<float*>(r); r += wsp_b;                        // filter spectrum (forward) / C^ (weight gradient)
   ws.M = reinterpret_cast<float*>(r); r += M_b;
   ws.xs = reinterpret_cast<float*>(r); r += xs_b;
   ws.ys = reinterpret_cast<float*>(r); r += ys_b;
   ws.part = reinterpret_cast<float*>(r);
   ws.csp = ws.wsp;
-  (void)wgrad;
   return 0;
 }
 
-size_t workspace_bytes(int gin, int cin, int chunk, bool wgrad) {
-  size_t b = align256((size_t)cin * ROWS * 32 * 4) + align256((size_t)NSLOT * gin * 64 * 64 * 4) + align256((size_t)chunk * gin * ROWS * 32 * 4) +
-             align256((size_t)chunk * ROWS * 32 * 4);
+size_t workspace_bytes(int gin, int gout, int cin, int chunk, bool wgrad) {
+  size_t b = align256((size_t)cin * gout * ROWS * 32 * 4) + align256((size_t)NSLOT * gin * gout * 64 * 64 * 4) +
+             align256((size_t)chunk * gin * ROWS * 32 * 4) + align256((size_t)chunk * gout * ROWS * 32 * 4);
   if (wgrad) b += align256((size_t)wgrad_splits() * NSLOT * gin * 4 * 1024 * 4);
   return b;
 }
@@ -515,33 +556,48 @@ template <typename K>
 void set_lds(K kernel) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_U); }
 
 // persistent kernels: one 8-wave workgroup per CU (128 KB of LDS each) walking the (tile, channel group) items
+template <bool MASKED, bool FENCE>
+void launch_fwd_t(pcnn_handle h, const FwdParams& p, int ntile) {
+  set_lds(spec_fwd_kernel<MASKED, FENCE>);
+  hipLaunchKernelGGL((spec_fwd_kernel<MASKED, FENCE>), dim3((unsigned)std::min(ntile * p.groups, 256)), dim3(512), LDS_U, h->stream, p);
+}
 void launch_fwd(pcnn_handle h, FwdParams p, int ntile) {
-  set_lds(spec_fwd_kernel);
+  static const int fence = getenv("PCNN_SPEC_FENCE") ? atoi(getenv("PCNN_SPEC_FENCE")) : 0;
   p.ntile = ntile;
-  hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)std::min(ntile * p.groups, 256)), dim3(512), LDS_U, h->stream, p);
+  const bool masked = p.ylim < T || p.xlim < T;
+  if (masked) { if (fence) launch_fwd_t<true, true>(h, p, ntile); else launch_fwd_t<true, false>(h, p, ntile); }
+  else { if (fence) launch_fwd_t<false, true>(h, p, ntile); else launch_fwd_t<false, false>(h, p, ntile); }
 }
 void launch_inv(pcnn_handle h, InvParams p, int ntile) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spec_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_INV);
   p.ntile = ntile;
-  hipLaunchKernelGGL(spec_inv_kernel, dim3((unsigned)std::min(ntile * p.groups, 256)), dim3(512), LDS_INV, h->stream, p);
+  const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
+  if (p.act == PCNN_ACT_TANH) {
+    set_lds(spec_inv_kernel<true>);
+    hipLaunchKernelGGL(spec_inv_kernel<true>, grid, dim3(512), LDS_U, h->stream, p);
+  } else {
+    p.alpha = p.act == PCNN_ACT_LINEAR ? 1.f : (p.act == PCNN_ACT_RELU ? 0.f : p.alpha);     // slope of the negative side
+    set_lds(spec_inv_kernel<false>);
+    hipLaunchKernelGGL(spec_inv_kernel<false>, grid, dim3(512), LDS_U, h->stream, p);
+  }
 }
 
 }  // namespace
 
 // Route choice.  Both estimates are calibrated on MI355X measurements at 8 x 1024^2 (tools/probe_spectral.py, profiles/r02_probe_spectral.txt):
-// the spectral route costs a fixed time per 32 x 32 tile whatever the filter size (0.26 us per tile with <= 32 input channels, 0.39 us with
+// the spectral route costs a fixed time per 32 x 32 tile whatever the filter size (0.21 us per tile with <= 32 channels, 0.33 us with
 // 64; its three kernels are HBM-bound on the tile spectra), the direct route the layer's padded MAC count over the rate its kernel sustains.
 bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad) {
   const int mode = h->spectral_mode;                       // 0: never, 1: whenever the shape allows, -1: cost model
   if (mode == 0) return false;
-  if (d->kh > 15 || d->kw > 15 || d->kh < 2 || d->kw < 2 || d->Cin > 64 || d->Cout > 32) return false;
+  if (d->kh > 15 || d->kw > 15 || d->kh < 2 || d->kw < 2 || d->Cin > 64) return false;
+  if (d->Cout > 32 && (wgrad || d->Cout != 64)) return false;      // 64 output channels: two exact lane groups (forward / data gradient only)
   if (mode == 1) return true;
   // decided on ONE image, so that a sample's arithmetic never depends on its batch neighbours (the model's per-sample results are
   // bit-identical for any batch size); images of fewer than 4 tiles stay on the direct route (launch overheads dominate there)
   const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
   const double tiles = (double)((d->Ho + Vy - 1) / Vy) * ((d->Wo + Vx - 1) / Vx);
   if (tiles < 4) return false;
-  const double t_spec = tiles * (d->Cin > 32 ? 0.39e-6 : 0.26e-6);
+  const double t_spec = tiles * ((d->Cin > 32 || d->Cout > 32) ? 0.33e-6 : 0.21e-6);
   const int cin8 = (d->Cin + 7) & ~7, co32 = (d->Cout + 31) & ~31;
   const double flop = 2.0 * d->Ho * d->Wo * d->kh * d->kw * cin8 * co32;
   const bool split = h->math_mode == PCNN_MATH_SPLIT_F16;
@@ -555,17 +611,18 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   const int tiles_y = pcnn_cdiv(d->Ho, Vy), tiles_x = pcnn_cdiv(d->Wo, Vx);
   const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
-  const int gin = pcnn_cdiv(d->Cin, 32);
-  const int chunk = (int)std::min<int64_t>(chunk_tiles(), ntile);
+  const int gin = pcnn_cdiv(d->Cin, 32), gout = pcnn_cdiv(d->Cout, 32);
+  const int chunk = (int)std::min<int64_t>(chunk_tiles() / (gin > gout ? gin : gout), ntile);
   Workspace ws;
-  if (int rc = ensure_workspace(h, workspace_bytes(gin, d->Cin, chunk, false), ws, gin, d->Cin, chunk, false)) return rc;
+  if (int rc = ensure_workspace(h, workspace_bytes(gin, gout, d->Cin, chunk, false), ws, gin, gout, d->Cin, chunk)) return rc;
   // filter spectrum: the filter as a kh x kw image with Cin*Cout channels, group = ci, lane = co
   FwdParams fw;
-  fw.x = w; fw.sp = ws.wsp; fw.tab = ws.tab; fw.H = d->kh; fw.W = d->kw; fw.C = d->Cin * d->Cout; fw.ld = d->Cin * d->Cout; fw.groups = d->Cin;
-  fw.cstride = d->Cout; fw.cvalid = d->Cout; fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
+  fw.x = w; fw.sp = ws.wsp; fw.tab = ws.tab; fw.H = d->kh; fw.W = d->kw; fw.C = d->Cin * d->Cout; fw.ld = d->Cin * d->Cout; fw.groups = d->Cin * gout;
+  fw.cstride = gout > 1 ? 32 : d->Cout; fw.cvalid = gout > 1 ? 32 : d->Cout;     // group ci * gout + go holds output channels 32 go .. 32 go + 31
+  fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
   fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T;
   launch_fwd(h, fw, 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, ws.wsp, ws.slots, ws.M, d->Cin, gin);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, ws.wsp, ws.slots, ws.M, d->Cin, gin, gout);
   PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
   FwdParams fx;
   fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
@@ -574,18 +631,18 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   InvParams iv;
   iv.sp = ws.ys; iv.tab = ws.tab; iv.y = y; iv.bias = bias; iv.bn_scale = bn_scale; iv.bn_shift = bn_shift; iv.res = residual; iv.act_out = act_out;
   iv.absmax = reinterpret_cast<unsigned*>(h->y_absmax);
-  iv.Ho = d->Ho; iv.Wo = d->Wo; iv.C = d->Cout; iv.ldy = d->ldy; iv.ld_res = d->ld_res; iv.ld_act = d->ld_act_out; iv.groups = 1; iv.cstride = 32; iv.cvalid = 32;
+  iv.Ho = d->Ho; iv.Wo = d->Wo; iv.C = d->Cout; iv.ldy = d->ldy; iv.ld_res = d->ld_res; iv.ld_act = d->ld_act_out; iv.groups = gout; iv.cstride = 32; iv.cvalid = 32;
   iv.act = d->act; iv.alpha = d->act_alpha; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx;
   MixParams mx;
-  mx.xs = ws.xs; mx.ys = ws.ys; mx.M = ws.M; mx.slots = ws.slots; mx.gin = gin;
+  mx.xs = ws.xs; mx.ys = ws.ys; mx.M = ws.M; mx.slots = ws.slots; mx.gin = gin; mx.gout = gout;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
     fx.tile0 = (int)t0; iv.tile0 = (int)t0; mx.ntile = nt;
     launch_fwd(h, fx, nt);
     const int nMt = pcnn_cdiv(nt, 32);
     const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 4));
-    if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy), dim3(256), 0, h->stream, mx);
-    else hipLaunchKernelGGL(spec_mix_kernel<2>, dim3(NSLOT, gy), dim3(256), 0, h->stream, mx);
+    if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy, gout), dim3(256), 0, h->stream, mx);
+    else hipLaunchKernelGGL(spec_mix_kernel<2>, dim3(NSLOT, gy, gout), dim3(256), 0, h->stream, mx);
     launch_inv(h, iv, nt);
   }
   PCNN_CHECK_LAUNCH(h, "spectral convolution");
@@ -598,9 +655,9 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
   const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gin = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();
-  const int chunk = (int)std::min<int64_t>(chunk_tiles(), ntile);
+  const int chunk = (int)std::min<int64_t>(chunk_tiles() / gin, ntile);
   Workspace ws;
-  if (int rc = ensure_workspace(h, workspace_bytes(gin, d->Cin, chunk, true), ws, gin, d->Cin, chunk, true)) return rc;
+  if (int rc = ensure_workspace(h, workspace_bytes(gin, 1, d->Cin, chunk, true), ws, gin, 1, d->Cin, chunk)) return rc;
   FwdParams fx;
   fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
   fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
@@ -609,13 +666,13 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
   fz.x = dz; fz.sp = ws.ys; fz.H = d->Ho; fz.W = d->Wo; fz.C = d->Cout; fz.ld = d->ldy; fz.groups = 1; fz.oy = 0; fz.ox = 0;
   fz.pad_mode = PCNN_PAD_CONSTANT; fz.pad_value = 0.f; fz.ylim = Vy; fz.xlim = Vx;
   WMixParams wm;
-  wm.xs = ws.xs; wm.ds = ws.ys; wm.part = ws.part; wm.slots = ws.slots; wm.gin = gin; wm.S = S;
+  wm.xs = ws.xs; wm.ds = ws.ys; wm.part = ws.part; wm.slots = ws.slots; wm.gin = gin; wm.S = S / 4;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
     fx.tile0 = (int)t0; fz.tile0 = (int)t0; wm.ntile = nt; wm.accumulate = t0 > 0;
     launch_fwd(h, fx, nt);
     launch_fwd(h, fz, nt);
-    hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S, gin), dim3(256), 0, h->stream, wm);
+    hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S / 4, gin), dim3(256), 0, h->stream, wm);
   }
   hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, ws.part, ws.slots, ws.csp, S, gin, d->Cin);
   InvParams iv;
