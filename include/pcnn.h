@@ -186,6 +186,11 @@ int pcnn_dense_bwd(pcnn_handle h, int N, int In, int Out, const float* x, const 
 /* ---- elementwise / layout helpers -------------------------------------------------------------------------- */
 /* input assembly: out[n,y,x,0]=rhs, [1]=cos(pi*y/(H-1)), [2]=cos(pi*x/(W-1))  (models/..Legacy.py:172-180,198) */
 int pcnn_assemble_input(pcnn_handle h, int N, int H, int W, const float* rhs, int use_pos, float* out, int ldo);
+/* Strided convolutions (blocks/bottleneck_block.py:28-34, downsampling_method='conv'): the reference pads exactly as for stride 1
+ * (utils/apply_advanced_padding_and_call_conv_layer.py:9-11) and lets the VALID convolution stride, i.e. it keeps every stride-th output
+ * of the stride-1 result.  adjoint = 0: y (N, ceil(H/s), ceil(W/s), C) = x[:, ::s, ::s, :];  adjoint = 1: x is the coarse gradient, y the
+ * full-resolution one (zero except at the kept positions). */
+int pcnn_subsample(pcnn_handle h, int N, int H, int W, int C, int stride, const float* x, int ldx, float* y, int ldy, int adjoint);
 /* y = alpha*x + beta*y over npix x C with channel strides */
 int pcnn_axpby(pcnn_handle h, int64_t npix, int C, float alpha, const float* x, int ldx, float beta, float* y, int ldy);
 /* y[n,p,c] = x[n,p,c]*s[n,c]  (tf.einsum('ijkl,ij->ijkl'), models/..Legacy.py:231); bwd gives dx and ds */
@@ -245,6 +250,16 @@ int pcnn_dst_setup(int n, double* S /* (n-2)^2, host */, double* lam /* n-2, hos
 int pcnn_fd_poisson_dst(pcnn_handle h, int N, int H, int W, const float* rhs, const float* left, const float* right,
                         const float* bottom, const float* top, const float* dx, const double* S_h, const double* lam_h,
                         const double* S_w, const double* lam_w, double* tmp, float* soln);
+/* Mixed Dirichlet / Neumann 5-point solve on the same vertex-centred grid (the consumer in the reference is the
+ * pressure projection of Navier_Stokes_2D/solvers.py:225-335, whose pure-Neumann system carries a zero-integral constraint, :258-259).
+ * neumann_mask bit 0/1/2/3: left / right / bottom / top edge is Neumann - its array then holds du/dn (outward normal), its nodes are
+ * unknowns closed by the second-order ghost node; otherwise the array holds the Dirichlet values.  All four Neumann: the singular mode
+ * is dropped (solution with zero trapezoidal integral; the data need not be compatible).  Per axis the caller passes the eigen-decomposition
+ * of the 1-D operator on that axis' mh (mw) unknowns: Vinv_h, V_h (mh x mh, row-major), lam_h; VinvT_w, VT_w (mw x mw, transposed), lam_w.
+ * tmp: 2*N*mh*mw doubles. */
+int pcnn_fd_poisson_mixed(pcnn_handle h, int N, int H, int W, int neumann_mask, const float* rhs, const float* left, const float* right,
+                          const float* bottom, const float* top, const float* dx, const double* Vinv_h, const double* V_h,
+                          const double* lam_h, const double* VinvT_w, const double* VT_w, const double* lam_w, double* tmp, float* soln);
 /* C[b] = A[b] * B[b] in fp64 (row-major, stride 0 broadcasts an operand) on v_mfma_f64_16x16x4_f64 */
 int pcnn_batched_gemm_f64(pcnn_handle h, int batch, int M, int Nn, int K, const double* A, int64_t strideA, int lda,
                           const double* B, int64_t strideB, int ldb, double* C, int64_t strideC, int ldc);

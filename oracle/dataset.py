@@ -72,3 +72,75 @@ def polynomial_and_second_derivative(roots, x):
 def five_point_laplacian(u, dx):
     """(u[i+1,j] + u[i-1,j] + u[i,j+1] + u[i,j-1] - 4u)/dx^2 on the interior, uniform spacing."""
     return (u[..., 2:, 1:-1] + u[..., :-2, 1:-1] + u[..., 1:-1, 2:] + u[..., 1:-1, :-2] - 4 * u[..., 1:-1, 1:-1]) / dx ** 2
+
+
+def _axis_operator(n, neumann_lo, neumann_hi):
+    """1-D operator of the mixed-BC 5-point system on one axis' unknowns: -second difference, the mirrored neighbour counted twice in a
+    Neumann end's row (second-order ghost node).  Returns (matrix, first unknown index, last unknown index, trapezoid weights)."""
+    a, b = (0 if neumann_lo else 1), (n - 1 if neumann_hi else n - 2)
+    m = b - a + 1
+    M = sp.lil_matrix((m, m))
+    M.setdiag(2.0)
+    M.setdiag(-1.0, 1)
+    M.setdiag(-1.0, -1)
+    w = np.ones(m)
+    if neumann_lo:
+        M[0, 1] = -2.0
+        w[0] = 0.5
+    if neumann_hi:
+        M[m - 1, m - 2] = -2.0
+        w[m - 1] = 0.5
+    return M.tocsr(), a, b, w
+
+
+def mixed_bc_poisson_solve(rhses, boundaries, dx, neumann):
+    """Reference for the mixed Dirichlet / Neumann 5-point solve: same grid and edge naming as
+    multigrid_poisson_solve; neumann = dict edge -> bool.  A Neumann edge's array holds du/dn along the outward normal.  The all-Neumann
+    system is singular: like Navier_Stokes_2D/solvers.py:258-259 it is closed with a Lagrange multiplier, here enforcing a zero
+    trapezoidal integral (sum_ij w_i w_j u_ij = 0).  Sparse direct solve, one sample at a time."""
+    N, H, W = rhses.shape
+    Mh, i0, i1, wh = _axis_operator(H, neumann['left'], neumann['right'])
+    Mw, j0, j1, ww = _axis_operator(W, neumann['bottom'], neumann['top'])
+    mh, mw = i1 - i0 + 1, j1 - j0 + 1
+    A = (sp.kron(Mh, sp.eye(mw)) + sp.kron(sp.eye(mh), Mw)).tocsc()
+    singular = all(neumann[k] for k in ('left', 'right', 'bottom', 'top'))
+    if singular:
+        wvec = np.outer(wh, ww).reshape(-1)
+        A = sp.bmat([[A, sp.csc_matrix(np.ones((mh * mw, 1)))], [sp.csc_matrix(wvec[None, :]), None]]).tocsc()
+    lu = spla.splu(A)
+    out = np.zeros((N, H, W))
+    for n in range(N):
+        h = dx[n]
+        full = -h * h * np.array(rhses[n], dtype=np.float64)
+        L, R, B, T = (np.asarray(boundaries[k][n], dtype=np.float64) for k in ('left', 'right', 'bottom', 'top'))
+        if neumann['left']:
+            full[0, :] += 2 * h * L
+        else:
+            full[1, :] += L
+        if neumann['right']:
+            full[-1, :] += 2 * h * R
+        else:
+            full[-2, :] += R
+        if neumann['bottom']:
+            full[:, 0] += 2 * h * B
+        else:
+            full[:, 1] += B
+        if neumann['top']:
+            full[:, -1] += 2 * h * T
+        else:
+            full[:, -2] += T
+        b = full[i0:i1 + 1, j0:j1 + 1].reshape(-1)
+        if singular:
+            b = np.concatenate([b, [0.0]])
+        u = lu.solve(b)[:mh * mw].reshape(mh, mw)
+        # Dirichlet values: top, bottom, then left, right (the corner convention of multigrid.py:145-148)
+        if not neumann['top']:
+            out[n, :, -1] = T
+        if not neumann['bottom']:
+            out[n, :, 0] = B
+        if not neumann['left']:
+            out[n, 0, :] = L
+        if not neumann['right']:
+            out[n, -1, :] = R
+        out[n, i0:i1 + 1, j0:j1 + 1] = u
+    return out

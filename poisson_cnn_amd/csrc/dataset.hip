@@ -111,6 +111,66 @@ __global__ void dst_write_soln_kernel(int N, int H, int W, const double* __restr
   }
 }
 
+// ---------------------------------------------------------------- mixed Dirichlet / Neumann 5-point solve
+// Vertex-centred grid as above; an edge is Dirichlet (its nodes are given) or Neumann (du/dn = g along the outward normal; its nodes are
+// unknowns, closed by the second-order ghost node u_ghost = u_inner + 2 dx g).  The unknowns are rows i0..i1 x columns j0..j1:
+//   4 u_ij - [neighbours] = -dx^2 f_ij + (Dirichlet neighbours' values) + 2 dx g on Neumann edges, the mirrored neighbour counted twice.
+// types bit 0/1/2/3 = left / right / bottom / top is Neumann.
+__global__ void mixed_build_rhs_kernel(int N, int H, int W, int types, const float* __restrict__ rhs, const float* __restrict__ left,
+                                       const float* __restrict__ right, const float* __restrict__ bottom, const float* __restrict__ top,
+                                       const float* __restrict__ dx, double* __restrict__ Bm) {
+  const int i0 = (types & 1) ? 0 : 1, i1 = (types & 2) ? H - 1 : H - 2, j0 = (types & 4) ? 0 : 1, j1 = (types & 8) ? W - 1 : W - 2;
+  const int mh = i1 - i0 + 1, mw = j1 - j0 + 1;
+  const int64_t total = (int64_t)N * mh * mw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int jj = idx % mw; const int ii = (idx / mw) % mh; const int n = idx / ((int64_t)mh * mw);
+    const int i = i0 + ii, j = j0 + jj;
+    const double h = (double)dx[n];
+    double v = -h * h * (double)rhs[((int64_t)n * H + i) * W + j];
+    // axis -2 (index i): left edge i = 0, right edge i = H-1; their values are indexed by j
+    if (i == 0) v += 2.0 * h * (double)left[(int64_t)n * W + j];                       // Neumann node on the left edge
+    else if (i == 1 && !(types & 1)) v += (double)left[(int64_t)n * W + j];            // Dirichlet neighbour
+    if (i == H - 1) v += 2.0 * h * (double)right[(int64_t)n * W + j];
+    else if (i == H - 2 && !(types & 2)) v += (double)right[(int64_t)n * W + j];
+    // axis -1 (index j): bottom edge j = 0, top edge j = W-1; values indexed by i.  A Dirichlet corner takes the left / right value
+    // (the write order of dataset/solvers/multigrid.py:145-148 lets left / right overwrite bottom / top there)
+    if (j == 0) v += 2.0 * h * (double)bottom[(int64_t)n * H + i];
+    else if (j == 1 && !(types & 4)) v += (double)bottom[(int64_t)n * H + i];
+    if (j == W - 1) v += 2.0 * h * (double)top[(int64_t)n * H + i];
+    else if (j == W - 2 && !(types & 8)) v += (double)top[(int64_t)n * H + i];
+    Bm[idx] = v;
+  }
+}
+
+// coefficient / (lam_h + lam_w); the null mode of the all-Neumann problem (lam = 0) is dropped, which is the solution whose
+// trapezoidal integral vanishes - the zero-integral constraint Navier_Stokes_2D/solvers.py:258-259 imposes with a Lagrange multiplier
+__global__ void mixed_divide_kernel(int N, int mh, int mw, const double* __restrict__ lam_h, const double* __restrict__ lam_w, double* __restrict__ T) {
+  const int64_t total = (int64_t)N * mh * mw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx % mw; const int i = (idx / mw) % mh;
+    const double l = lam_h[i] + lam_w[j];
+    T[idx] = fabs(l) > 1e-13 ? T[idx] / l : 0.0;
+  }
+}
+
+__global__ void mixed_write_soln_kernel(int N, int H, int W, int types, const double* __restrict__ U, const float* __restrict__ left,
+                                        const float* __restrict__ right, const float* __restrict__ bottom, const float* __restrict__ top,
+                                        float* __restrict__ soln) {
+  const int i0 = (types & 1) ? 0 : 1, i1 = (types & 2) ? H - 1 : H - 2, j0 = (types & 4) ? 0 : 1, j1 = (types & 8) ? W - 1 : W - 2;
+  const int mh = i1 - i0 + 1, mw = j1 - j0 + 1;
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx % W; const int i = (idx / W) % H; const int n = idx / ((int64_t)H * W);
+    float v;
+    if (i < i0) v = left[(int64_t)n * W + j];
+    else if (i > i1) v = right[(int64_t)n * W + j];
+    else if (j < j0) v = bottom[(int64_t)n * H + i];
+    else if (j > j1) v = top[(int64_t)n * H + i];
+    else v = (float)U[((int64_t)n * mh + (i - i0)) * mw + (j - j0)];
+    soln[idx] = v;
+  }
+}
+
 // ---------------------------------------------------------------- series synthesis
 // out[n,a,b] (+)= sum_{A<ka,B<kb} c[n,A,B] f((A+1) x_a) g((B+1) y_b), x = linspace(0,pi,H), y = linspace(0,pi,W)
 constexpr int SYN_ROWS = 16, SYN_MAXK = 16;
@@ -260,5 +320,31 @@ extern "C" int pcnn_scale_samples(pcnn_handle h, int N, int64_t per, const float
   PCNN_REQUIRE(h, h && s && x, "pcnn_scale_samples: null argument");
   hipLaunchKernelGGL(scale_samples_kernel, grid1d((int64_t)N * per), dim3(256), 0, h->stream, N, per, s, x);
   PCNN_CHECK_LAUNCH(h, "pcnn_scale_samples");
+  return 0;
+}
+
+// Mixed Dirichlet / Neumann solve.  Per axis the host supplies the eigen-decomposition of the 1-D operator on that axis' unknowns
+// (M = V diag(lam) V^-1: dataset/__init__.py axis_decomposition): Vinv_h (mh x mh), V_h, lam_h, and for the second axis the TRANSPOSED
+// matrices VinvT_w, VT_w (applied from the right).  u = V_h ((Vinv_h B VinvT_w) ./ (lam_h + lam_w)) VT_w.
+extern "C" int pcnn_fd_poisson_mixed(pcnn_handle h, int N, int H, int W, int neumann_mask, const float* rhs, const float* left, const float* right,
+                                     const float* bottom, const float* top, const float* dx, const double* Vinv_h, const double* V_h,
+                                     const double* lam_h, const double* VinvT_w, const double* VT_w, const double* lam_w, double* tmp, float* soln) {
+  PCNN_REQUIRE(h, h && rhs && left && right && bottom && top && dx && Vinv_h && V_h && lam_h && VinvT_w && VT_w && lam_w && tmp && soln,
+               "pcnn_fd_poisson_mixed: null argument");
+  PCNN_REQUIRE(h, H >= 3 && W >= 3 && N >= 1 && neumann_mask >= 0 && neumann_mask < 16, "pcnn_fd_poisson_mixed: bad shape or mask");
+  const int mh = H - 2 + (neumann_mask & 1) + ((neumann_mask >> 1) & 1), mw = W - 2 + ((neumann_mask >> 2) & 1) + ((neumann_mask >> 3) & 1);
+  const int64_t per = (int64_t)mh * mw;
+  double* Bm = tmp; double* T = tmp + (int64_t)N * per;
+  hipLaunchKernelGGL(mixed_build_rhs_kernel, grid1d(N * per), dim3(256), 0, h->stream, N, H, W, neumann_mask, rhs, left, right, bottom, top, dx, Bm);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_mixed(build)");
+  int rc;
+  if ((rc = pcnn_batched_gemm_f64(h, N, mh, mw, mh, Vinv_h, 0, mh, Bm, per, mw, T, per, mw))) return rc;
+  if ((rc = pcnn_batched_gemm_f64(h, N, mh, mw, mw, T, per, mw, VinvT_w, 0, mw, Bm, per, mw))) return rc;
+  hipLaunchKernelGGL(mixed_divide_kernel, grid1d(N * per), dim3(256), 0, h->stream, N, mh, mw, lam_h, lam_w, Bm);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_mixed(divide)");
+  if ((rc = pcnn_batched_gemm_f64(h, N, mh, mw, mh, V_h, 0, mh, Bm, per, mw, T, per, mw))) return rc;
+  if ((rc = pcnn_batched_gemm_f64(h, N, mh, mw, mw, T, per, mw, VT_w, 0, mw, Bm, per, mw))) return rc;
+  hipLaunchKernelGGL(mixed_write_soln_kernel, grid1d((int64_t)N * H * W), dim3(256), 0, h->stream, N, H, W, neumann_mask, Bm, left, right, bottom, top, soln);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_mixed(write)");
   return 0;
 }

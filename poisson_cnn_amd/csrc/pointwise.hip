@@ -408,6 +408,35 @@ extern "C" int pcnn_pad_fold_bwd(pcnn_handle h, int N, int H, int W, int C, int 
   return 0;
 }
 
+// strided sub-sampling y[n,i,j,c] = x[n, i*s, j*s, c] and its adjoint (zero-fill + scatter): a strided convolution of the reference is the
+// stride-1 fused pad+conv followed by this (utils/apply_advanced_padding_and_call_conv_layer.py pads the same whatever the stride)
+__global__ void subsample_kernel(int N, int H, int W, int C, int s, int Ho, int Wo, const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                 int adjoint) {
+  if (!adjoint) {
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int c = i % C; int64_t r = i / C; const int ox = r % Wo; r /= Wo; const int oy = r % Ho; const int n = r / Ho;
+      y[(((int64_t)n * Ho + oy) * Wo + ox) * ldy + c] = x[(((int64_t)n * H + (int64_t)oy * s) * W + (int64_t)ox * s) * ldx + c];
+    }
+  } else {   // x: coarse gradient (N,Ho,Wo,C), y: full-resolution gradient (N,H,W,C)
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int c = i % C; int64_t r = i / C; const int xx = r % W; r /= W; const int yy = r % H; const int n = r / H;
+      const bool hit = (yy % s == 0) && (xx % s == 0);
+      y[(((int64_t)n * H + yy) * W + xx) * ldy + c] = hit ? x[(((int64_t)n * Ho + yy / s) * Wo + xx / s) * ldx + c] : 0.f;
+    }
+  }
+}
+
+extern "C" int pcnn_subsample(pcnn_handle h, int N, int H, int W, int C, int stride, const float* x, int ldx, float* y, int ldy, int adjoint) {
+  PCNN_REQUIRE(h, h && x && y && stride >= 1 && N >= 1 && H >= 1 && W >= 1 && C >= 1, "pcnn_subsample: bad argument");
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  hipLaunchKernelGGL(subsample_kernel, grid1d((int64_t)N * (adjoint ? (int64_t)H * W : (int64_t)Ho * Wo) * C), dim3(256), 0, h->stream, N, H, W, C, stride, Ho, Wo,
+                     x, ldx, y, ldy, adjoint);
+  PCNN_CHECK_LAUNCH(h, "pcnn_subsample");
+  return 0;
+}
+
 extern "C" int pcnn_axpby(pcnn_handle h, int64_t npix, int C, float alpha, const float* x, int ldx, float beta, float* y, int ldy) {
   PCNN_REQUIRE(h, h && x && y, "pcnn_axpby: null argument");
   hipLaunchKernelGGL(axpby_kernel, grid1d(npix * C), dim3(256), 0, h->stream, npix, C, alpha, x, ldx, beta, y, ldy);

@@ -285,9 +285,13 @@ class numerical_dataset_generator:
     def numerical_dataset(self, output_shape='random', dx='random', boundaries='random', rhses='random', rhs_smoothness=None, boundary_smoothness=None,
                           rhs_max_magnitude=1.0, boundary_max_magnitude=None, nonzero_boundaries=_BOUNDARY_KEYS, solver_method='multigrid',
                           return_rhs=True, return_boundaries=False, return_dx=False, return_shape=False, random_output_shape_range=((64, 85), (64, 85)),
-                          random_dx_range=(0.005, 0.05), normalize_by_domain_size=False, uniformly_distributed_aspect_ratios=True):
+                          random_dx_range=(0.005, 0.05), normalize_by_domain_size=False, uniformly_distributed_aspect_ratios=True, boundary_types=None):
         """numerical_dataset (dataset/generators/numerical.py:74-150).  solver_method 'multigrid' / 'multigrid_gpu' / 'cholesky' all map
-        to the DST-I direct solve of the same 5-point system."""
+        to the DST-I direct solve of the same 5-point system.
+
+        boundary_types (extension): dict edge -> 'dirichlet' | 'neumann' (default all Dirichlet).  A Neumann
+        edge's random smooth boundary function is its normal derivative du/dn; the discrete mixed-BC system is solved directly
+        (mixed_bc_poisson_solve) - a true mixed Dirichlet/Neumann ground truth for BASELINE configs[2]."""
         N, rng = self.batch_size, self.rng
         boundary_max_magnitude = boundary_max_magnitude or {k: 1.0 for k in _BOUNDARY_KEYS}
         if isinstance(output_shape, str) and output_shape == 'random':
@@ -333,7 +337,10 @@ class numerical_dataset_generator:
                     bc[k] = torch.zeros((N, lengths[k]), dtype=torch.float32, device=self.device)
         else:
             bc = {k: self._dev(np.asarray(boundaries[k])).view(N, lengths[k]) for k in _BOUNDARY_KEYS}
-        soln = K.fd_poisson_dst(rhs, bc['left'], bc['right'], bc['bottom'], bc['top'], self._dev(dx[:, 0]))
+        if boundary_types is not None and any(str(v).lower() == 'neumann' for v in boundary_types.values()):
+            soln = K.fd_poisson_mixed(rhs, bc['left'], bc['right'], bc['bottom'], bc['top'], self._dev(dx[:, 0]), _neumann_flags(boundary_types))
+        else:
+            soln = K.fd_poisson_dst(rhs, bc['left'], bc['right'], bc['bottom'], bc['top'], self._dev(dx[:, 0]))
         if normalize_by_domain_size:
             K.scale_samples(soln, self._dev(10.0 / (dx[:, 0] ** 2 * (H - 1) * (W - 1))))
         inp = []
@@ -367,6 +374,15 @@ class numerical_dataset_generator:
         return inp, out
 
 
+def _neumann_flags(boundary_types):
+    bt = {k: 'dirichlet' for k in _BOUNDARY_KEYS}
+    for k, v in (boundary_types or {}).items():
+        if k not in bt or str(v).lower() not in ('dirichlet', 'neumann'):
+            raise ValueError("boundary_types maps 'left'/'right'/'bottom'/'top' to 'dirichlet' or 'neumann' (got %r: %r)" % (k, v))
+        bt[k] = str(v).lower()
+    return tuple(bt[k] == 'neumann' for k in ('left', 'right', 'bottom', 'top'))
+
+
 # ----------------------------------------------------------------------------- solver entry points (dataset/solvers)
 def multigrid_poisson_solve(rhses, boundaries, dx, dy=None, system_matrix=None, tol=1e-10, solver_init_parameters=None, solver_run_parameters=None,
                             use_pyamgx=False, initial_guesses=None, device=None):
@@ -390,3 +406,22 @@ def multigrid_poisson_solve(rhses, boundaries, dx, dy=None, system_matrix=None, 
 def cholesky_poisson_solve(rhses, boundaries, h, system_matrix=None, system_matrix_is_decomposed=False, device=None):
     """dataset/solvers/cholesky.py:122-186 (dense Cholesky of the same 5-point matrix): same system, same direct DST-I solve."""
     return multigrid_poisson_solve(rhses, boundaries, h, device=device)
+
+
+def mixed_bc_poisson_solve(rhses, boundaries, dx, boundary_types, device=None):
+    """5-point FD Poisson solve with per-edge Dirichlet / Neumann conditions on the reference's vertex-centred grid (same edge naming and
+    array shapes as multigrid_poisson_solve).  The reference has no such solver in its dataset path - its only Neumann data are analytic
+    cosine series (dataset/generators/reverse_neumann.py) - but its Navier-Stokes projection step solves exactly this system
+    (Navier_Stokes_2D/solvers.py:225-335, zero-integral constraint for the singular all-Neumann case, :258-259).
+    boundary_types: dict edge -> 'dirichlet' | 'neumann'; a Neumann edge's array holds du/dn along the outward normal."""
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).to(device=dev, dtype=torch.float32)
+    r = t(rhses)
+    if r.dim() == 4:
+        r = r[:, 0]
+    N, H, W = r.shape
+    b = {k: t(boundaries[k]).reshape(-1, W if k in ('left', 'right') else H).expand(N, -1).contiguous() for k in _BOUNDARY_KEYS}
+    d = t(dx).reshape(-1)
+    d = d.expand(N).contiguous() if d.numel() == 1 else d.reshape(N, -1)[:, 0].contiguous()
+    out = K.fd_poisson_mixed(r.contiguous(), b['left'], b['right'], b['bottom'], b['top'], d, _neumann_flags(boundary_types))
+    return out.view(N, 1, H, W)

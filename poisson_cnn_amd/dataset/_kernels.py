@@ -36,6 +36,59 @@ def fd_poisson_dst(rhs, left, right, bottom, top, dx):
     return soln
 
 
+_axis_cache = {}
+
+
+def axis_decomposition(n, neumann_lo, neumann_hi, device):
+    """Eigen-decomposition M = V diag(lam) V^-1 of the 1-D operator (2 on the diagonal, -1 beside it, the mirrored neighbour counted twice
+    in a Neumann end's row) on the unknowns of an n-point axis: Dirichlet ends are not unknowns.  With W = diag(1/2 at Neumann ends, 1
+    elsewhere) W M is symmetric, so the generalised symmetric problem (W M) v = lam W v gives V with V^T W V = I, i.e. V^-1 = V^T W (fp64,
+    host, cached per (n, end types); Dirichlet-Dirichlet reproduces the DST-I basis of pcnn_dst_setup).
+    Returns device tensors (Vinv, V, lam) and the index range (a, b) of the unknowns."""
+    key = (n, bool(neumann_lo), bool(neumann_hi), str(device))
+    if key not in _axis_cache:
+        import scipy.linalg
+        a, b = (0 if neumann_lo else 1), (n - 1 if neumann_hi else n - 2)
+        m = b - a + 1
+        M = 2.0 * np.eye(m) - np.eye(m, k=1) - np.eye(m, k=-1)
+        w = np.ones(m)
+        if neumann_lo:
+            M[0, 1] = -2.0
+            w[0] = 0.5
+        if neumann_hi:
+            M[m - 1, m - 2] = -2.0
+            w[m - 1] = 0.5
+        Wm = np.diag(w)
+        lam, V = scipy.linalg.eigh(Wm @ M, Wm)
+        if neumann_lo and neumann_hi:
+            lam[0] = 0.0                                        # exact null mode (constants)
+        Vinv = V.T * w[None, :]
+        # scipy hands V back in Fortran order and torch.tensor keeps those strides: the kernels read raw row-major memory
+        _axis_cache[key] = (torch.tensor(np.ascontiguousarray(Vinv), device=device).contiguous(), torch.tensor(np.ascontiguousarray(V), device=device).contiguous(),
+                            torch.tensor(np.ascontiguousarray(lam), device=device), (a, b))
+    return _axis_cache[key]
+
+
+def fd_poisson_mixed(rhs, left, right, bottom, top, dx, neumann=(False, False, False, False)):
+    """5-point solve with per-edge Dirichlet / Neumann conditions; `neumann` = (left, right, bottom, top).  A Neumann edge's array holds
+    du/dn (outward normal), a Dirichlet edge's its values.  rhs (N,H,W); left/right (N,W); bottom/top (N,H); dx (N,) -> soln (N,H,W)."""
+    N, H, W = rhs.shape
+    nl, nr, nb, nt = [bool(v) for v in neumann]
+    Vih, Vh, lh, _ = axis_decomposition(H, nl, nr, rhs.device)
+    Viw, Vw, lw, _ = axis_decomposition(W, nb, nt, rhs.device)
+    mh, mw = Vh.shape[0], Vw.shape[0]
+    key = ('T', W, nb, nt, str(rhs.device))
+    if key not in _axis_cache:
+        _axis_cache[key] = (Viw.t().contiguous(), Vw.t().contiguous())
+    ViwT, VwT = _axis_cache[key]
+    tmp = torch.empty(2 * N * mh * mw, dtype=torch.float64, device=rhs.device)
+    soln = torch.empty_like(rhs)
+    mask = int(nl) | (int(nr) << 1) | (int(nb) << 2) | (int(nt) << 3)
+    handle().call('pcnn_fd_poisson_mixed', c_int(N), c_int(H), c_int(W), c_int(mask), _p(rhs.contiguous()), _p(left.contiguous()), _p(right.contiguous()),
+                  _p(bottom.contiguous()), _p(top.contiguous()), _p(dx.contiguous()), _p(Vih), _p(Vh), _p(lh), _p(ViwT), _p(VwT), _p(lw), _p(tmp), _p(soln))
+    return soln
+
+
 def series_synthesis(coef, H, W, trig, out=None, accumulate=False):
     """coef (N,ka,kb) -> (N,H,W): sum c[A,B] f((A+1)x) f((B+1)y), f = sin (trig=0) / cos (trig=1)."""
     N, ka, kb = coef.shape

@@ -164,9 +164,14 @@ class ConvUnit:
     """tf.pad + Conv2D(VALID) + bias + activation [+ BatchNormalization] [+ residual] = ONE fused kernel launch."""
 
     def __init__(self, store, ctx, name, k, cin, cout, *, pad='advanced', padding_mode='CONSTANT', pad_value=0.0, activation='linear',
-                 use_bias=True, bn_name=None):
-        """k: int (square kernel) or (kh, kw); a Conv1D of the reference is a (1, k) kernel on an (N, 1, L, C) tensor."""
+                 use_bias=True, bn_name=None, stride=1):
+        """k: int (square kernel) or (kh, kw); a Conv1D of the reference is a (1, k) kernel on an (N, 1, L, C) tensor.
+        stride > 1 (blocks/bottleneck_block.py:28-34): the reference pads as for stride 1 and lets the VALID convolution stride, i.e. it keeps
+        every stride-th output - computed here as the fused stride-1 launch followed by pcnn_subsample (unused by the shipped configs)."""
         self.store, self.ctx, self.name = store, ctx, name
+        self.stride = int(stride)
+        if self.stride > 1 and pad != 'advanced':
+            raise NotImplementedError('strided convolutions are implemented for the advanced-padding form (the only strided use in the reference)')
         self.kh, self.kw = (int(k), int(k)) if np.isscalar(k) else (int(k[0]), int(k[1]))
         self.k = self.kw
         self.cin, self.cout = int(cin), int(cout)
@@ -196,6 +201,15 @@ class ConvUnit:
     def forward(self, x, residual=None, out=None, training=True, x_absmax=None):
         """x_absmax: optional 1-element device tensor holding max|x| (the producing layer's `out_absmax`): saved for the weight gradient,
         which would otherwise spend a pass over x on it (split math mode).  After the call `self.out_absmax` holds this layer's."""
+        if self.stride > 1:
+            assert residual is None and out is None
+            full = self._forward(x, training=training, x_absmax=x_absmax)
+            self.out_absmax = None
+            self._full_hw = (full.shape[1], full.shape[2])
+            return ops.subsample(full, self.stride)
+        return self._forward(x, residual=residual, out=out, training=training, x_absmax=x_absmax)
+
+    def _forward(self, x, residual=None, out=None, training=True, x_absmax=None):
         self.out_absmax = None
         w = self.store.w[self.name + '/kernel']
         b = self.store.w[self.name + '/bias'] if self.use_bias else None
@@ -225,6 +239,8 @@ class ConvUnit:
     def backward(self, dy, need_dx=True, inplace=False, add_to=None):
         """add_to: optional tensor added to the returned input gradient inside the data-gradient kernel's epilogue (a skip connection's
         gradient); it may be overwritten."""
+        if self.stride > 1:
+            dy, inplace = ops.subsample_bwd(dy, self._full_hw, self.stride), True
         x, a, bn_stats, x_absmax = self.saved
         self.saved = None
         s, g = self.store, self.store.g
@@ -310,40 +326,72 @@ class resnet:
 
 # ----------------------------------------------------------------------------- bottleneck blocks
 class _bottleneck_base:
-    """blocks/bottleneck_block.py:9-66 for downsampling_method='pool' + use_resnet=True (the shipped configuration)."""
+    """blocks/bottleneck_block.py:9-66: down-sampling (pool, or a strided convolution), n_convs convolution stages (plain convolutions,
+    each followed by a BatchNormalization layer when use_batchnorm - which the reference counts as a stage of its own, :52-55 - or resnet
+    blocks), then the up-sampling of the subclass."""
 
     def __init__(self, store, ctx, name, cin, *, downsampling_factor, filters, conv_kernel_size, n_convs=1, upsampling_factor=None,
                  padding_mode='constant', constant_padding_value=0.0, conv_activation='linear', conv_use_bias=True, use_resnet=False,
-                 downsampling_method='conv', pool_downsampling_method='max', use_batchnorm=False, **unused):
-        if downsampling_method.lower() != 'pool' or not use_resnet:
-            raise NotImplementedError('only downsampling_method="pool" with use_resnet=True (the shipped hpnn configs) is implemented')
+                 downsampling_method='conv', conv_downsampling_kernel_size=None, pool_downsampling_method='max', use_batchnorm=False, **unused):
         self.name, self.f = name, int(downsampling_factor)
         self.up = int(upsampling_factor) if upsampling_factor is not None else self.f
         self.downsampling_factor = self.f
         self.filters = filters
+        self.method = downsampling_method.lower()
         self.pool = pool_downsampling_method.lower()
-        self.conv0 = ConvUnit(store, ctx, name + '/conv0', conv_kernel_size, cin, filters, padding_mode=padding_mode,
-                              pad_value=constant_padding_value, activation=conv_activation, use_bias=conv_use_bias)
-        self.res = [resnet(store, ctx, '%s/res%d' % (name, i), filters, conv_kernel_size, use_batchnorm=use_batchnorm, padding_mode=padding_mode,
-                           constant_padding_value=constant_padding_value, activation=conv_activation, use_bias=conv_use_bias)
-                    for i in range(n_convs - 1)]
+        kw = dict(padding_mode=padding_mode, pad_value=constant_padding_value, activation=conv_activation, use_bias=conv_use_bias)
+        self.down_conv = None
+        self.stages = []                                                # ConvUnit / resnet objects in call order (a conv's BN is fused into it)
+        n_layers = 0                                                    # the reference's len(self.conv_layers): BN layers count
+        if self.method == 'conv':
+            if conv_downsampling_kernel_size is None:
+                raise ValueError('conv_downsampling_kernel_size is required for downsampling_method="conv"')
+            self.down_conv = ConvUnit(store, ctx, name + '/downsample', conv_downsampling_kernel_size, cin, filters, stride=self.f, **kw)
+            c = filters
+        elif self.method == 'pool':
+            c = cin
+            if use_resnet:
+                self.stages.append(ConvUnit(store, ctx, name + '/conv0', conv_kernel_size, cin, filters, **kw))
+                n_layers, c = 1, filters
+        else:
+            raise ValueError('Downsampling method can only be conv or pool')
+        i = 0
+        while n_layers < n_convs:
+            if use_resnet:
+                self.stages.append(resnet(store, ctx, '%s/res%d' % (name, i), filters, conv_kernel_size, use_batchnorm=use_batchnorm, padding_mode=padding_mode,
+                                          constant_padding_value=constant_padding_value, activation=conv_activation, use_bias=conv_use_bias))
+                n_layers += 1
+            else:
+                self.stages.append(ConvUnit(store, ctx, '%s/conv%d' % (name, i), conv_kernel_size, c, filters,
+                                            bn_name=('%s/bn%d' % (name, i)) if use_batchnorm else None, **kw))
+                n_layers += 2 if use_batchnorm else 1
+                c = filters
+            i += 1
+        # names kept from round 1 for the shipped (pool + resnet) configuration: conv0, res0, res1, ...
+        self.conv0 = self.stages[0] if (self.method == 'pool' and use_resnet) else None
+        self.res = [st for st in self.stages if isinstance(st, resnet)]
 
     def _down_and_convs(self, x, training):
         self.x = x if training else None
-        o = ops.pool2d_fwd(x, self.f, self.pool)
-        o = self.conv0.forward(o, training=training)
-        hint = self.conv0.out_absmax
-        for r in self.res:
-            o = r.forward(o, training=training, x_absmax=hint)
-            hint = r.out_absmax
+        hint = None
+        if self.down_conv is not None:
+            o = self.down_conv.forward(x, training=training)
+        else:
+            o = ops.pool2d_fwd(x, self.f, self.pool)
+        for st in self.stages:
+            o = st.forward(o, training=training, x_absmax=hint)
+            hint = st.out_absmax
         return o
 
     def _backward_convs_and_down(self, dcoarse, d_in):
         d = dcoarse
-        for r in reversed(self.res):
-            d = r.backward(d, inplace=True)
-        d = self.conv0.backward(d, inplace=True)
-        ops.pool2d_bwd(self.x, d, self.f, self.pool, dx=d_in, accumulate=True)
+        for st in reversed(self.stages):
+            d = st.backward(d, inplace=True)
+        if self.down_conv is not None:
+            dx = self.down_conv.backward(d, inplace=True)
+            ops.axpby(1.0, dx, 1.0, d_in)
+        else:
+            ops.pool2d_bwd(self.x, d, self.f, self.pool, dx=d_in, accumulate=True)
         self.x = None
 
     def out_hw(self, H, W):

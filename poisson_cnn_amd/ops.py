@@ -424,6 +424,23 @@ def axpby(alpha, x, beta, y):
     return y
 
 
+def subsample(x, stride):
+    """x[:, ::s, ::s, :] (the strided form of the fused pad+conv keeps every s-th output of the stride-1 result)."""
+    N, H, W, C = x.shape
+    y = empty((N, -(-H // stride), -(-W // stride), C), x.device)
+    handle().call('pcnn_subsample', c_int(N), c_int(H), c_int(W), c_int(C), c_int(stride), _p(x), c_int(_ld(x)), _p(y), c_int(_ld(y)), c_int(0))
+    return y
+
+
+def subsample_bwd(dy, full_hw, stride):
+    """Adjoint of subsample: the coarse gradient scattered into a zero full-resolution tensor."""
+    N, Ho, Wo, C = dy.shape
+    H, W = full_hw
+    dx = empty((N, H, W, C), dy.device)
+    handle().call('pcnn_subsample', c_int(N), c_int(H), c_int(W), c_int(C), c_int(stride), _p(dy), c_int(_ld(dy)), _p(dx), c_int(_ld(dx)), c_int(1))
+    return dx
+
+
 def axpby_flat(alpha, x, beta, y):
     n = x.numel()
     handle().call('pcnn_axpby', c_int64(1), c_int(n), c_float(alpha), _p(x), c_int(n), c_float(beta), _p(y), c_int(n))

@@ -61,14 +61,20 @@ def test_hpnn_forward_matches_oracle(bc):
     assert rel(y, ref) < TOL_FWD
 
 
-def _train_reference(cfg, p, rhs, dx, target, lossp, gbs):
-    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in p.items()}
-    pred = ohpnn.forward(torch_twin, cfg, pt, torch.tensor(rhs), torch.tensor(dx))
-    L = oloss.loss_wrapper(global_batch_size=gbs, **lossp)
-    loss = L(target, pred, torch.tensor(rhs), np.concatenate([dx, dx], 1))
-    loss.backward()
-    grads = {k: v.grad.numpy() for k, v in pt.items() if v.requires_grad}
-    return float(loss.detach()), pred.detach().numpy(), grads
+def _train_reference(cfg, p, rhs, dx, target, lossp, gbs, dtype=torch.float64):
+    """fp64 (default): the oracle.  fp32: the same graph in PyTorch-CPU single precision - an independent fp32 implementation whose distance
+    from the fp64 oracle shows what fp32 arithmetic alone costs."""
+    torch_twin.set_dtype(dtype)
+    try:
+        pt = {k: torch.tensor(v, dtype=dtype, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in p.items()}
+        pred = ohpnn.forward(torch_twin, cfg, pt, torch.tensor(rhs, dtype=dtype), torch.tensor(dx, dtype=dtype))
+        L = oloss.loss_wrapper(global_batch_size=gbs, **lossp)
+        loss = L(target.astype(np.float32 if dtype == torch.float32 else np.float64), pred, torch.tensor(rhs, dtype=dtype), np.concatenate([dx, dx], 1))
+        loss.backward()
+        grads = {k: v.grad.double().numpy() for k, v in pt.items() if v.requires_grad}
+        return float(loss.detach()), pred.detach().double().numpy(), grads
+    finally:
+        torch_twin.set_dtype(torch.float64)
 
 
 @pytest.mark.parametrize('bc,pi_w', [('dirichlet', 0.0), ('neumann', 6e-4)])
@@ -157,6 +163,17 @@ def test_hpnn_train_step_gradients(activation, tol):
     print('flat rel', rel(flat, flat_ref), 'worst tensors', worst, 'last layer', errs['final/out1/kernel'])
     assert errs['final/out1/kernel'] < 2e-5 and errs['scaling/dense2/kernel'] < 2e-5
     assert rel(flat, flat_ref) < tol
+    if 'leaky' in activation:
+        # The 8e-3 is not kernel error: the SAME graph evaluated by PyTorch-CPU in fp32 (oneDNN convolutions, no code shared with
+        # libpcnn) sits as far from the fp64 oracle, because fp32 and fp64 pick different leaky-ReLU slopes at activations that
+        # round to opposite signs.  The HIP gradient must be no farther from the oracle than ~2x that independent fp32 run, and the
+        # effect must be visible in it (otherwise the tolerance above would be hiding something else).
+        _, _, g32 = _train_reference(cfg, p, rhs, dx, target, lossp, 2, dtype=torch.float32)
+        flat32 = np.concatenate([g32[n].ravel() for n in names])
+        d_cpu32, d_hip = rel(flat32, flat_ref), rel(flat, flat_ref)
+        print('fp32 torch-CPU twin vs fp64 oracle', d_cpu32, 'HIP vs fp64 oracle', d_hip)
+        assert d_cpu32 > 1e-4
+        assert d_hip < 2.5 * d_cpu32 + 1e-4
 
 
 def test_forward_matches_committed_golden_vectors():
