@@ -273,6 +273,12 @@ int pcnn_set_max_magnitude(pcnn_handle h, int N, int64_t per, const float* targe
 /* x[n,:] *= s[n] */
 int pcnn_scale_samples(pcnn_handle h, int N, int64_t per, const float* s, float* x);
 
+/* tf.keras.layers.LayerNormalization() over the last axis of an (N, F) matrix (epsilon 1e-3 in Keras): the optional final layer of the
+ * metalearning hyper-networks (layers/metalearning_conv.py:128-129).  fwd also returns the per-row mean and 1/sqrt(var + eps) for bwd. */
+int pcnn_layernorm_fwd(pcnn_handle h, int N, int F, const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd);
+int pcnn_layernorm_bwd(pcnn_handle h, int N, int F, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                       float* dx, float* dgamma, float* dbeta);
+
 /* ---- Dirichlet_BC_NN_Legacy_2 / Poisson_CNN_Legacy (kernels in csrc/dbcnn.hip) ------------------------------ */
 /* out[n,y,0:3] = {bc[n,y], 1, cos(pi y/(L-1))}: the boundary input with its positional embeddings
  * (models/Dirichlet_BC_NN_Legacy.py:113-124,136-139); 1-D tensors are NHWC with H = 1 */

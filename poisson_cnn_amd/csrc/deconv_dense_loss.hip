@@ -428,3 +428,83 @@ extern "C" int pcnn_loss_coefficients(pcnn_handle h, int N, int64_t hw, const fl
   PCNN_CHECK_LAUNCH(h, "pcnn_loss_coefficients");
   return 0;
 }
+
+// ---------------------------------------------------------------- LayerNormalization over the feature axis of an (N, F) matrix
+// tf.keras.layers.LayerNormalization() (axis -1, epsilon 1e-3, gamma / beta of length F): the optional last layer of the metalearning
+// hyper-networks (layers/metalearning_conv.py:128-129).  One workgroup per row.
+namespace {
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(int F, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ double red[2][256];
+  const int n = blockIdx.x;
+  const float* xr = x + (int64_t)n * F;
+  double s = 0.0, s2 = 0.0;
+  for (int f = threadIdx.x; f < F; f += 256) { const double v = xr[f]; s += v; s2 += v * v; }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  const double m = red[0][0] / F;
+  double var = red[1][0] / F - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+  for (int f = threadIdx.x; f < F; f += 256) y[(int64_t)n * F + f] = (xr[f] - mu) * rs * gamma[f] + beta[f];
+  if (threadIdx.x == 0) { mean[n] = mu; rstd[n] = rs; }
+}
+
+// dx[n,f] = rstd (g - mean_f(g) - xhat mean_f(g xhat)), g = dy gamma
+__global__ __launch_bounds__(256) void layernorm_bwd_x_kernel(int F, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ dy, float* __restrict__ dx) {
+  __shared__ double red[2][256];
+  const int n = blockIdx.x;
+  const float mu = mean[n], rs = rstd[n];
+  double s = 0.0, s2 = 0.0;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const double g = (double)dy[(int64_t)n * F + f] * gamma[f], xh = ((double)x[(int64_t)n * F + f] - mu) * rs;
+    s += g; s2 += g * xh;
+  }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  const float mg = (float)(red[0][0] / F), mgx = (float)(red[1][0] / F);
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const float g = dy[(int64_t)n * F + f] * gamma[f], xh = (x[(int64_t)n * F + f] - mu) * rs;
+    dx[(int64_t)n * F + f] = rs * (g - mg - xh * mgx);
+  }
+}
+
+__global__ void layernorm_bwd_params_kernel(int N, int F, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                            const float* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  float sg = 0.f, sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float d = dy[(int64_t)n * F + f];
+    sg += d * (x[(int64_t)n * F + f] - mean[n]) * rstd[n];
+    sb += d;
+  }
+  dgamma[f] = sg; dbeta[f] = sb;
+}
+}  // namespace
+
+extern "C" int pcnn_layernorm_fwd(pcnn_handle h, int N, int F, const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
+                                  float* rstd) {
+  PCNN_REQUIRE(h, h && x && gamma && beta && y && mean && rstd && N >= 1 && F >= 1, "pcnn_layernorm_fwd: bad argument");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(N), dim3(256), 0, h->stream, F, x, gamma, beta, eps, y, mean, rstd);
+  PCNN_CHECK_LAUNCH(h, "pcnn_layernorm_fwd");
+  return 0;
+}
+
+extern "C" int pcnn_layernorm_bwd(pcnn_handle h, int N, int F, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                                  float* dx, float* dgamma, float* dbeta) {
+  PCNN_REQUIRE(h, h && x && gamma && mean && rstd && dy && dx && dgamma && dbeta && N >= 1 && F >= 1, "pcnn_layernorm_bwd: bad argument");
+  hipLaunchKernelGGL(layernorm_bwd_x_kernel, dim3(N), dim3(256), 0, h->stream, F, x, gamma, mean, rstd, dy, dx);
+  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3((F + 255) / 256), dim3(256), 0, h->stream, N, F, x, mean, rstd, dy, dgamma, dbeta);
+  PCNN_CHECK_LAUNCH(h, "pcnn_layernorm_bwd");
+  return 0;
+}

@@ -391,6 +391,22 @@ def dense_bwd(x, w, y, dy, act, dw, db, need_dx=True):
     return dx
 
 
+def layernorm_fwd(x, gamma, beta, eps=1e-3):
+    """tf.keras.layers.LayerNormalization() on (N, F): returns (y, (mean, rstd))."""
+    N, F = x.shape
+    y = empty((N, F), x.device)
+    st = empty((2, N), x.device)
+    handle().call('pcnn_layernorm_fwd', c_int(N), c_int(F), _p(x), _p(gamma), _p(beta), c_float(eps), _p(y), _p(st[0]), _p(st[1]))
+    return y, st
+
+
+def layernorm_bwd(x, gamma, stats, dy, dgamma, dbeta):
+    N, F = x.shape
+    dx = empty((N, F), x.device)
+    handle().call('pcnn_layernorm_bwd', c_int(N), c_int(F), _p(x), _p(gamma), _p(stats[0]), _p(stats[1]), _p(dy), _p(dx), _p(dgamma), _p(dbeta))
+    return dx
+
+
 def spp_max_fwd(x, bins):
     N, H, W, C = x.shape
     assert x.is_contiguous()

@@ -277,3 +277,96 @@ def test_metalearning_conv_forward_backward(padding, mode):
     assert rel(nchw(dx), xt.grad.numpy()) < 5e-6 and rel(ddi.cpu().numpy(), dit.grad.numpy()) < 2e-5
     for n in names:
         assert rel(lay.store.g[n].cpu().numpy(), wt[n].grad.numpy()) < 2e-5, n
+
+
+def _ml_setup(layer, rng):
+    """Random hyper-network weights (biases, layer-norm and BN parameters too) -> fp64 dict, loaded into the layer's store."""
+    w = {}
+    for n in layer.store.names:
+        t = layer.store.w[n].cpu().numpy()
+        if n.endswith(('moving_variance', 'gamma')):
+            v = rng.uniform(0.6, 1.4, t.shape)
+        elif n.endswith('kernel'):
+            v = t * 1.3
+        else:
+            v = rng.standard_normal(t.shape) * 0.2
+        w[n] = f32(v)
+        layer.store.w[n].copy_(torch.tensor(w[n], dtype=torch.float32))
+    return w
+
+
+def _ml_check(layer, w, ref_fn, x, di, run_fwd):
+    pt = {k: torch.tensor(v, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in w.items()}
+    xt, dit = torch.tensor(x, requires_grad=True), torch.tensor(di, requires_grad=True)
+    yt = ref_fn(pt, xt, dit)
+    y = run_fwd()
+    assert tuple(y.shape) == tuple(yt.shape) and rel(y.cpu().numpy(), yt.detach().numpy()) < 5e-6
+    dy = f32(np.random.default_rng(5).standard_normal(tuple(yt.shape)))
+    (yt * torch.tensor(dy)).sum().backward()
+    dx, ddi = layer.backward(nhwc(dy))
+    assert rel(nchw(dx), xt.grad.numpy()) < 1e-5 and rel(ddi.cpu().numpy(), dit.grad.numpy()) < 3e-5
+    for n in layer.store.trainable_names():
+        assert rel(layer.store.g[n].cpu().numpy(), pt[n].grad.numpy()) < 3e-5, n
+
+
+def test_metalearning_conv_layernorm_and_stride():
+    """use_layernorm (layers/metalearning_conv.py:128-129) and the strided 'same' form (metalearning_bottleneck_block.py:60-62), lazy build."""
+    from oracle import metalearning as oml
+    from poisson_cnn_amd.metalearning import metalearning_conv
+    rng = np.random.default_rng(31)
+    N, H, W, Cin, Cout, k, F = 2, 20, 23, 6, 5, 3, 4
+    x, di = f32(rng.standard_normal((N, Cin, H, W))), f32(rng.standard_normal((N, F)))
+    lay = metalearning_conv(Cout, k, strides=2, padding='same', padding_mode='SYMMETRIC', conv_activation='tf.nn.leaky_relu', dense_activations='tf.nn.tanh',
+                            pre_output_dense_units=[8, 16], use_layernorm=True, seed=2)
+    lay([dev(x), dev(di)])                                   # reference call convention, builds lazily
+    w = _ml_setup(lay, rng)
+    fn = lambda p, xt, dt: oml.mconv(p, 'metalearning_conv', xt, dt, k, Cin, Cout, ['tanh'] * 3, same=True, mode='SYMMETRIC', act='leaky_relu', stride=2, use_layernorm=True)
+    _ml_check(lay, w, fn, x, di, lambda: lay([dev(x), dev(di)], training=True))
+
+
+def test_metalearning_deconvupscale_and_resnet():
+    from oracle import metalearning as oml
+    from poisson_cnn_amd.metalearning import metalearning_deconvupscale, metalearning_resnet
+    rng = np.random.default_rng(32)
+    N, Cin, F = 2, 5, 3
+    x, di = f32(rng.standard_normal((N, Cin, 7, 9))), f32(rng.standard_normal((N, F)))
+    up = metalearning_deconvupscale(3, 4, 3, dense_activations='tf.nn.tanh', pre_output_dense_units=[6, 8], seed=1)
+    shp = np.array([N, 4, 20, 26], dtype=np.int32)
+    up([dev(x), dev(di), shp])
+    w = _ml_setup(up, rng)
+    _ml_check(up, w, lambda p, xt, dt: oml.mdeconv(p, 'metalearning_deconvupscale', xt, dt, 3, Cin, 4, ['tanh'] * 3, (20, 26)), x, di,
+              lambda: up([dev(x), dev(di), shp], training=True))
+    for use_bn in (False, True):
+        x2 = f32(rng.standard_normal((N, 6, 15, 17)))
+        blk = metalearning_resnet(6, 3, use_batchnorm=use_bn, padding_mode='SYMMETRIC', conv_activation='tf.nn.leaky_relu', dense_activations='tf.nn.tanh',
+                                  pre_output_dense_units=[6, 8], seed=3)
+        blk([dev(x2), dev(di)])
+        w = _ml_setup(blk, rng)
+        fn = lambda p, xt, dt: oml.mresnet(p, 'metalearning_resnet', xt, dt, 3, 6, ['tanh'] * 3, use_bn, same=True, mode='SYMMETRIC', act='leaky_relu')
+        _ml_check(blk, w, fn, x2, di, lambda: blk([dev(x2), dev(di)], training=True))
+
+
+@pytest.mark.parametrize('kind,method,use_resnet,use_bn', [('deconv', 'pool', True, True), ('deconv', 'conv', False, True), ('multilinear', 'conv', True, False),
+                                                            ('multilinear', 'pool', False, True)])
+def test_metalearning_bottleneck_blocks(kind, method, use_resnet, use_bn):
+    from oracle import metalearning as oml
+    from poisson_cnn_amd.metalearning import metalearning_bottleneck_block_deconvupsample, metalearning_bottleneck_block_multilinearupsample
+    rng = np.random.default_rng(33)
+    N, Cin, F = 2, 4, 3
+    x, di = f32(rng.standard_normal((N, Cin, 18, 24))), f32(rng.standard_normal((N, F)))
+    common = dict(ndims=2, downsampling_factor=3, filters=5, conv_kernel_size=3, n_convs=3, conv_padding_mode='SYMMETRIC', conv_conv_activation='tf.nn.leaky_relu',
+                  conv_dense_activation='tf.nn.tanh', conv_pre_output_dense_units=[6, 8], use_resnet=use_resnet, downsampling_method=method,
+                  conv_downsampling_kernel_size=5, pool_downsampling_method='average', use_batchnorm=use_bn, seed=4)
+    if kind == 'deconv':
+        blk = metalearning_bottleneck_block_deconvupsample(deconv_kernel_size=3, deconv_dense_activation='tf.nn.tanh', deconv_pre_output_dense_units=[6, 8], **common)
+        call = lambda training=False: blk([dev(x), dev(di)], training=training)
+        name = 'metalearning_bottleneck_deconv'
+    else:
+        blk = metalearning_bottleneck_block_multilinearupsample(**common)
+        call = lambda training=False: blk([dev(x), dev(di), None], training=training)
+        name = 'metalearning_bottleneck_multilinear'
+    call()
+    w = _ml_setup(blk, rng)
+    okw = dict(kind=kind, f=3, up=3, filters=5, k=3, n_convs=3, acts=['tanh'] * 3, mode='SYMMETRIC', value=0.0, act='leaky_relu', method=method, pool='average',
+               use_resnet=use_resnet, use_bn=use_bn, kdown=5, kdeconv=3, dacts=['tanh'] * 3)
+    _ml_check(blk, w, lambda p, xt, dt: oml.mbottleneck(p, name, xt, dt, **okw), x, di, lambda: call(training=True))
