@@ -13,6 +13,9 @@
 
 int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw);   // spectral_conv.hip
 bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad);
+int pcnn_conv_small_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes);   // conv_small.hip
+bool pcnn_conv_small_wgrad_eligible(const pcnn_conv_desc* d);
+size_t pcnn_conv_small_wgrad_workspace(const pcnn_conv_desc* d);
 
 namespace {
 
@@ -720,7 +723,7 @@ extern "C" size_t pcnn_conv2d_wgrad_workspace(const pcnn_conv_desc* d) {
   const WgradPlan pls = make_split_plan(&pd);
   const size_t plain = partials_bytes(d, pl);
   const size_t split = split_eligible(&pd, pls) ? partials_bytes(&pd, pls) + 256 + plane_bytes(&pd) : 0;
-  return plain > split ? plain : split;
+  return std::max(std::max(plain, split), pcnn_conv_small_wgrad_workspace(d));
 }
 
 extern "C" int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
@@ -734,6 +737,7 @@ extern "C" int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, co
   PCNN_REQUIRE(h, d->Cin >= 1 && d->Cin <= 128 && d->Cout >= 1 && d->Cout <= 64, "pcnn_conv2d_wgrad: channels %d->%d unsupported (<=64)", d->Cin, d->Cout);
   PCNN_REQUIRE(h, d->ldx >= d->Cin && d->ldy >= d->Cout, "pcnn_conv2d_wgrad: channel stride smaller than channel count");
   PCNN_REQUIRE(h, workspace_bytes >= pcnn_conv2d_wgrad_workspace(d), "pcnn_conv2d_wgrad: workspace too small");
+  if (pcnn_conv_small_wgrad_eligible(d)) return pcnn_conv_small_wgrad(h, d, x, dz, dw, workspace, workspace_bytes);
   if (pcnn_spectral_eligible(h, d, true)) return pcnn_spectral_conv_wgrad(h, d, x, dz, dw);
   const pcnn_conv_desc pd = padded_desc(d);
   const WgradPlan pls = make_split_plan(&pd);

@@ -1,0 +1,112 @@
+"""The narrow-convolution kernels (csrc/conv_small.hip: <= 16 channels, 3x3 / 5x5, exact fp32 FMA on the vector ALUs, built for the HBM
+roofline): forward with every epilogue option and ragged channel counts, data gradient and weight gradient vs the fp64 oracle - in BOTH
+math modes (the kernels do not depend on the mode) - and that the route is really taken."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops, torch_twin
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def nhwc(a):
+    return torch.tensor(np.ascontiguousarray(np.asarray(a).transpose(0, 2, 3, 1)), dtype=torch.float32, device='cuda')
+
+
+def nchw(t):
+    return t.detach().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+SHAPES = [(3, 8, 8), (3, 16, 12), (3, 12, 12), (3, 12, 8), (3, 8, 4), (3, 4, 1), (3, 2, 4), (3, 4, 4), (3, 3, 5), (3, 1, 16), (3, 16, 16), (3, 7, 11),
+          (5, 16, 16), (5, 8, 12), (5, 3, 1), (5, 12, 16)]
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'split_f16'])
+@pytest.mark.parametrize('k,Cin,Cout', SHAPES)
+def test_forward_backward(mode, k, Cin, Cout):
+    from poisson_cnn_amd import ops
+    prev = ops.get_math_mode()
+    ops.set_math_mode(mode)
+    try:
+        rng = np.random.default_rng(k * 1000 + Cin * 17 + Cout)
+        N, H, W = 2, 37, 45
+        pad_mode = ['CONSTANT', 'SYMMETRIC', 'REFLECT'][(Cin + Cout) % 3]
+        x = rng.standard_normal((N, Cin, H, W)).astype(np.float32).astype(np.float64)
+        w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32).astype(np.float64)
+        b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+        dy = rng.standard_normal((N, Cout, H, W)).astype(np.float32).astype(np.float64)
+        xt, wt, bt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True), torch.tensor(b, requires_grad=True)
+        yt = torch_twin.padded_conv2d(xt, wt, bt, pad_mode, 0.3, 'linear')
+        (yt * torch.tensor(dy)).sum().backward()
+        p = k // 2
+        xd, wd = nhwc(x), torch.tensor(w, dtype=torch.float32, device='cuda')
+        y = ops.conv2d_fwd(xd, wd, torch.tensor(b, dtype=torch.float32, device='cuda'), pad_top=p, pad_left=p, pad_mode=pad_mode, pad_value=0.3)
+        assert rel(nchw(y), np_ops.padded_conv2d(x, w, b, pad_mode, 0.3, 'linear')) < 2e-6
+        dw = ops.conv2d_wgrad(xd, nhwc(dy), w.shape, pad_top=p, pad_left=p, pad_mode=pad_mode, pad_value=0.3)
+        assert rel(dw.cpu().numpy(), wt.grad.numpy()) < 5e-6
+        wf = ops.flip_transpose_weights(wd)
+        if pad_mode == 'CONSTANT':
+            dx = ops.conv2d_fwd(nhwc(dy), wf, None, pad_top=k - 1 - p, pad_left=k - 1 - p)
+        else:
+            gp = ops.conv2d_fwd(nhwc(dy), wf, None, pad_top=k - 1, pad_left=k - 1, out_hw=(H + k - 1, W + k - 1))
+            dx = ops.pad_fold_bwd(gp, (H, W), ((p, p), (p, p)), pad_mode)
+        assert rel(nchw(dx), xt.grad.numpy()) < 2e-6
+    finally:
+        ops.set_math_mode(prev)
+
+
+def test_epilogue_options_and_channel_slices():
+    """bias + leaky-ReLU + BN affine + residual + act_out, input and output as channel slices of wider buffers (vector and scalar paths)."""
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(3)
+    for Cin, Cout, ldx_extra, ldy_extra in ((8, 8, 8, 8), (12, 8, 4, 0), (6, 5, 1, 3)):
+        N, H, W = 2, 19, 40
+        xb = torch.tensor(rng.standard_normal((N, H, W, Cin + ldx_extra)), dtype=torch.float32, device='cuda')
+        x = xb[..., ldx_extra:]
+        w = torch.tensor(rng.standard_normal((3, 3, Cin, Cout)) / 8, dtype=torch.float32, device='cuda')
+        b = torch.tensor(rng.standard_normal(Cout), dtype=torch.float32, device='cuda')
+        sc = torch.tensor(rng.uniform(0.5, 1.5, Cout), dtype=torch.float32, device='cuda')
+        sh = torch.tensor(rng.standard_normal(Cout), dtype=torch.float32, device='cuda')
+        res = torch.tensor(rng.standard_normal((N, H, W, Cout)), dtype=torch.float32, device='cuda')
+        outb = torch.zeros((N, H, W, Cout + ldy_extra), dtype=torch.float32, device='cuda')
+        a_out = torch.empty((N, H, W, Cout), dtype=torch.float32, device='cuda')
+        amax = torch.zeros(1, device='cuda')
+        ops.conv2d_fwd(x, w, b, pad_top=1, pad_left=1, pad_mode='SYMMETRIC', act='leaky_relu', bn_scale=sc, bn_shift=sh, residual=res,
+                       out=outb[..., :Cout], act_out=a_out, y_absmax=amax)
+        xn = x.cpu().numpy().transpose(0, 3, 1, 2).astype(np.float64)
+        a = np_ops.padded_conv2d(xn, w.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64), 'SYMMETRIC', 0.0, 'leaky_relu')
+        ref = a * sc.cpu().numpy()[None, :, None, None] + sh.cpu().numpy()[None, :, None, None] + res.cpu().numpy().transpose(0, 3, 1, 2)
+        assert rel(nchw(a_out), a) < 2e-6 and rel(nchw(outb[..., :Cout]), ref) < 2e-6
+        if ldy_extra:
+            assert float(outb[..., Cout:].abs().max()) == 0.0
+        assert abs(float(amax) - np.abs(ref).max()) < 1e-5 * np.abs(ref).max()
+
+
+def test_small_route_beats_the_mfma_route_at_full_size():
+    """8 x 1024^2, 3x3 8->8: same numbers as the MFMA implicit GEMM (to rounding), and this is the north star's "conv forward vs HBM
+    roofline" layer: 537 MB of tensors per launch."""
+    import os
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(8, 1024, 1024, 8, device='cuda', generator=g)
+    w = torch.randn(3, 3, 8, 8, device='cuda', generator=g) * 0.1
+    y = ops.conv2d_fwd(x, w, None, pad_top=1, pad_left=1)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10):
+        ops.conv2d_fwd(x, w, None, pad_top=1, pad_left=1, out=y)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 10
+    gbs = 2 * x.numel() * 4 / ms / 1e6
+    print('3x3 8->8 at 8x1024^2: %.3f ms, %.0f GB/s algorithmic (%.0f %% of 8 TB/s)' % (ms, gbs, gbs / 80))
+    ref = torch.nn.functional.conv2d(x[:1, :64, :64].permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1)
+    assert float((y[:1, 1:63, 1:63].permute(0, 3, 1, 2).double() - ref[:, :, 1:63, 1:63]).norm() / ref[:, :, 1:63, 1:63].norm()) < 2e-6
+    assert gbs > 2400          # >= 30 % of the 8 TB/s peak on any device of the pool (the MFMA route: ~10 %)
