@@ -282,19 +282,26 @@ def run(args):
         peak = PEAK_FP32_MFMA_TFLOPS if mode == 'fp32' else PEAK_SPLIT_TFLOPS
         flops, secs, calls = prof.totals('conv_fwd')
         wf, ws_, wc = prof.totals('conv_wgrad')
-        traffic, tsrc = traffic_from_profiles(mode, args.workload, 'conv_fwd')
-        wtraffic, _ = traffic_from_profiles(mode, args.workload, 'wgrad')
+        bf, bs, bc = prof.totals('conv_bwd_fused')
+        af, as_, ac = flops + wf + bf, secs + ws_ + bs, calls + wc + bc
+        traffic, tsrc = traffic_from_profiles(mode, args.workload, 'conv')
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
         hf, hb, hs, hc = prof.select(lambda k, f, b: k == 'conv_fwd' and b > 0 and f / b < ridge)
         df, db, ds, dc = prof.select(lambda k, f, b: k == 'deconv_fwd')
         rf, rb, rs, rc = prof.select(lambda k, f, b: k == 'resize_fwd')
-        return {'bound': 'mfma', 'kernel': ('conv_fwd_kernel' if mode == 'fp32' else 'conv_fwd_split_kernel') + ' (fused pad+conv fwd and data-gradient; all launches of the timed steps)',
-                'achieved': flops / secs / 1e12 if secs else None, 'peak': peak, 'unit': 'TFLOP/s (algorithmic fp32 FLOP)',
-                'frac': flops / secs / 1e12 / peak if secs else None, 'traffic': traffic, 'traffic_source': tsrc,
-                'algorithmic_bytes_per_launch': prof.total_bytes('conv_fwd') / calls if calls else None, 'launches': calls,
-                'avg_launch_ms': 1e3 * secs / calls if calls else None,
-                'wgrad_kernel': {'achieved': wf / ws_ / 1e12 if ws_ else None, 'frac': wf / ws_ / 1e12 / peak if ws_ else None, 'launches': wc,
-                                 'avg_launch_ms': 1e3 * ws_ / wc if wc else None, 'traffic': wtraffic},
+
+        def blk(f, s_, c):
+            return {'achieved': f / s_ / 1e12 if s_ else None, 'frac': f / s_ / 1e12 / peak if s_ else None, 'launches': c, 'avg_launch_ms': 1e3 * s_ / c if c else None}
+        return {'bound': 'mfma',
+                'kernel': 'all convolution launches of the timed steps (forward, data gradient, weight gradient): fp32-MFMA implicit GEMM (%s), tiled spectral '
+                          'route (spec_fwd / spec_mix / spec_inv / spec_wmix: DFT as fp32 MFMA GEMM) for the wide filters, vector-ALU kernels for <= 16 channels'
+                          % ('conv_fwd_kernel / wgrad_kernel' if mode == 'fp32' else 'conv_fwd_split_kernel / wgrad_split_kernel'),
+                'achieved': af / as_ / 1e12 if as_ else None, 'peak': peak, 'unit': 'TFLOP/s (ALGORITHMIC direct-convolution fp32 FLOP, 2 N Ho Wo kh kw Cin Cout per launch)',
+                'frac': af / as_ / 1e12 / peak if as_ else None,
+                'note': 'frac > 1 is possible: the spectral route needs ~k^2/25 times fewer multiply-adds than the direct convolution the numerator counts',
+                'traffic': traffic, 'traffic_source': tsrc, 'launches': ac, 'avg_launch_ms': 1e3 * as_ / ac if ac else None,
+                'algorithmic_bytes_per_launch': (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused')) / max(calls + bc, 1),
+                'forward_and_data_gradient': blk(flops, secs, calls), 'wgrad_kernel': blk(wf, ws_, wc), 'backward_fused': blk(bf, bs, bc),
                 'hbm_bound': {'what': 'conv forward / data-gradient launches below the fp32 ridge (%.1f FLOP/B: the 3x3 tail with <= 8 channels and the Scaling convs)' % ridge,
                               'bound': 'hbm', 'achieved': hb / hs / 1e9 if hs else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s (algorithmic bytes)',
                               'frac': hb / hs / 1e9 / PEAK_HBM_GBS if hs else None, 'launches': hc, 'avg_launch_ms': 1e3 * hs / hc if hc else None,

@@ -99,6 +99,16 @@ int pcnn_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, co
 int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw,
                            void* workspace, size_t workspace_bytes, const float* x_absmax, const float* dz_absmax);
 
+/* Both gradients of a wide-filter layer in one call on the spectral route (csrc/spectral_conv.hip): the spectrum of dz's tile windows is
+ * computed once and serves the data gradient (d/dx of the same tf.nn.conv2d) AND the filter gradient, which is formed input-partitioned.
+ * d: the FORWARD convolution; dg: its data-gradient convolution (input dz with channel stride dg->ldx, filter w_flipped = the output of
+ * pcnn_conv2d_flip_transpose_weights, output dx (N,dg->Ho,dg->Wo,Cin) with stride dg->ldy - for SYMMETRIC / REFLECT layers the gradient on
+ * the padded domain, Ho = H + kh - 1; residual (stride dg->ld_res) is added to dx if given).  Eligibility (cost model, Cout <= 32, zero
+ * constant padding) must be asked first; an ineligible layer uses pcnn_conv2d_wgrad + pcnn_conv2d_fwd as before. */
+int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg);
+int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
+                             const float* residual, float* dx, float* dw);
+
 /* Backward of the fused epilogue: given dy (gradient at y) and the saved activation a = act(z),
  *   dz = dy * bn_scale[c] * act'(z)      (act' recovered from a: leaky -> a>0 ? 1 : alpha, tanh -> 1-a^2)
  * and the per-channel sums  dbias[c] = sum dz,  dgamma_hat[c] = sum dy*a,  dbeta[c] = sum dy  (the caller turns

@@ -27,6 +27,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
                            const float* bn_shift, const float* residual, float* y, float* act_out);
 int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw);
 bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad);
+bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d);   // conv_small.hip
 
 namespace {
 
@@ -54,7 +55,8 @@ struct FwdParams {
   int H, W, C, ld, groups, cstride, cvalid;
   int tiles_x, tiles_y, tile0, ntile;
   int Vy, Vx, oy, ox, pad_mode; float pad_value;
-  int ylim, xlim;
+  int ylim, xlim;        // the window holds values only in its first ylim x xlim entries (gradient / input tiles of the backward pass)
+  int ext_y, ext_x;      // ... and only where the tile grid coordinate (ty Vy + r, tx Vx + c) lies inside ext_y x ext_x
 };
 
 // one (tile, channel group) work item as the loader sees it: a wave-uniform image base plus 32-bit per-lane offsets (so the loads take
@@ -64,6 +66,7 @@ struct FwdItem {
   int wy0;               // uniform: window origin row
   unsigned off[16];      // lane: float offset of window column 2 xs + half (clamped into the image) + this lane's channel
   unsigned cmask, zmask; // bit xs: column is constant padding / lies beyond xlim (zero)
+  int ylim, xlim;        // uniform: rows / columns of this item's window that can be non-zero
   bool cok;              // this lane's channel exists
 };
 
@@ -78,20 +81,22 @@ __device__ __forceinline__ void fwd_item(const FwdParams& p, int item, int half,
   it.img = p.x + (int64_t)n * p.H * p.W * p.ld;
   it.wy0 = ty * p.Vy - p.oy;
   const int wx0 = tx * p.Vx - p.ox;
+  it.ylim = min(p.ylim, p.ext_y - ty * p.Vy);
+  it.xlim = min(p.xlim, p.ext_x - tx * p.Vx);
   it.cmask = 0u; it.zmask = 0u;
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) {
     const int xc = 2 * xs + half;
     const int sx = pcnn_pad_index(wx0 + xc, p.W, p.pad_mode);
     if (sx < 0) it.cmask |= 1u << xs;
-    if (xc >= p.xlim) it.zmask |= 1u << xs;
+    if (xc >= it.xlim) it.zmask |= 1u << xs;
     it.off[xs] = (unsigned)((sx < 0 ? 0 : sx) * p.ld + (it.cok ? chan : 0));
   }
 }
 // issues the 16 loads of window row y (always-valid addresses; padding is applied when the values are consumed).  y is wave-uniform.
 template <bool MASKED>
 __device__ __forceinline__ void fwd_load_row(const FwdParams& p, const FwdItem& it, int y, float (&v)[16]) {
-  if (MASKED && y >= p.ylim) return;                                             // zero row (gradient windows hold Vy x Vx values): nothing to fetch
+  if (MASKED && y >= it.ylim) return;                                            // zero row (gradient windows hold Vy x Vx values): nothing to fetch
   const int sy = pcnn_pad_index(it.wy0 + y, p.H, p.pad_mode);
   const float* row = it.img + (int64_t)(sy < 0 ? 0 : sy) * p.W * p.ld;
 #pragma unroll
@@ -101,10 +106,10 @@ template <bool MASKED>
 __device__ __forceinline__ f32x16 fwd_row_mfma(const FwdParams& p, const FwdItem& it, int y, const float (&greg)[16], const float (&v)[16]) {
   const int sy = pcnn_pad_index(it.wy0 + y, p.H, p.pad_mode);
   f32x16 acc = zero16();
-  if (MASKED && y >= p.ylim) return acc;
+  if (MASKED && y >= it.ylim) return acc;
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) {
-    if (!MASKED || 2 * xs < p.xlim) {                                             // uniform: columns beyond xlim are zero, their K steps are skipped
+    if (!MASKED || 2 * xs < it.xlim) {                                             // uniform: columns beyond xlim are zero, their K steps are skipped
       float val = (sy < 0 || ((it.cmask >> xs) & 1u)) ? p.pad_value : v[xs];
       if (!it.cok || (MASKED && ((it.zmask >> xs) & 1u))) val = 0.f;
       acc = mfma(greg[xs], val, acc);
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) U[(y * 32 + acc_row(r, half)) * 32 + c] = acc[r];
     };
+    const int ylim = cur.ylim;                                       // `cur` will describe the NEXT item by the time the y axis runs
     fwd_load_row<MASKED>(p, cur, wave + 8, v1);
     store_u(wave, fwd_row_mfma<MASKED>(p, cur, wave, greg, v0));
     fwd_load_row<MASKED>(p, cur, wave + 16, v0);
@@ -163,13 +169,13 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) {
         const int yk = (2 * ks + half) & 31, s = ks < 16 ? fx : 16 + fx;
-        if (!MASKED || 2 * (ks & 15) < p.ylim) bu[ks] = U[(yk * 32 + s) * 32 + c];      // rows beyond ylim are zero: K steps skipped (uniform)
+        if (!MASKED || 2 * (ks & 15) < ylim) bu[ks] = U[(yk * 32 + s) * 32 + c];      // rows beyond ylim are zero: K steps skipped (uniform)
       }
       if (FENCE) lds_fence();
       f32x16 acc = zero16();
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks)
-        if (!MASKED || 2 * (ks & 15) < p.ylim) acc = mfma(fcreg[ks], bu[ks], acc);
+        if (!MASKED || 2 * (ks & 15) < ylim) acc = mfma(fcreg[ks], bu[ks], acc);
       float* o = out + (64 + 64 * (fx - 1) + 32 * h) * 32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
@@ -179,12 +185,12 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
       float bu[16];
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
-        if (!MASKED || 2 * ks < p.ylim) bu[ks] = U[((2 * ks + half) * 32 + col) * 32 + c];
+        if (!MASKED || 2 * ks < ylim) bu[ks] = U[((2 * ks + half) * 32 + col) * 32 + c];
       if (FENCE) lds_fence();
       f32x16 acc = zero16();
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
-        if (!MASKED || 2 * ks < p.ylim) acc = mfma(greg[ks], bu[ks], acc);
+        if (!MASKED || 2 * ks < ylim) acc = mfma(greg[ks], bu[ks], acc);
       float* o = out + (h ? 32 : 0) * 32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
@@ -201,6 +207,7 @@ struct InvParams {
   float* y; const float* bias; const float* bn_scale; const float* bn_shift; const float* res; float* act_out; unsigned* absmax;
   int Ho, Wo, C, ldy, ld_res, ld_act, groups, cstride, cvalid, act; float alpha;
   int tiles_x, tiles_y, tile0, ntile, Vy, Vx;
+  int flip;              // store output pixel (y, x) at (Ho-1-y, Wo-1-x): the input-partitioned weight gradient comes out tap-reversed
 };
 
 // unit u of wave (q, h): complex column fx = 1 + q + 4u (32 K steps), or - q == 3, u == 3 - the real column 0 / 16 (16 K steps).
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
         f32x16 acc = zero16();
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], bu[ks], acc);
-        const int64_t rowpix = ((int64_t)n * p.Ho + y0 + yy) * p.Wo + x0;
+        const int64_t rowpix = p.flip ? ((int64_t)n * p.Ho + (p.Ho - 1 - y0 - yy)) * p.Wo + (p.Wo - 1 - x0) : ((int64_t)n * p.Ho + y0 + yy) * p.Wo + x0;
+        const int xsgn = p.flip ? -1 : 1;
         float* yrow = p.y + rowpix * p.ldy;
         float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
         const float* rrow = p.res ? p.res + rowpix * p.ld_res : nullptr;
@@ -298,10 +306,10 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
             if (xx < vx) {
               float v = acc[r] + bias;
               v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
-              if (arow) arow[(unsigned)(xx * p.ld_act) + chv] = v;
+              if (arow) arow[(int)(xsgn * xx * p.ld_act) + (int)chv] = v;
               v = v * sc + sh;
-              if (rrow) v += rrow[(unsigned)(xx * p.ld_res) + chv];
-              yrow[(unsigned)(xx * p.ldy) + chv] = v;
+              if (rrow) v += rrow[(int)(xsgn * xx * p.ld_res) + (int)chv];
+              yrow[(int)(xsgn * xx * p.ldy) + (int)chv] = v;
               ymax = fmaxf(ymax, fabsf(v));
             }
           }
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
 
 // C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
 // Output: spectrum of a one-tile image with Cin*Cout channels, group = ci, lane = co.
-__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin) {
+__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin, float isign) {
   const int64_t total = (int64_t)NSLOT * gin * 1024;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = i & 1023; int64_t r = i >> 10; const int gi = r % gin; const int slot = r / gin;
@@ -468,7 +476,7 @@ __global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4*
     }
     const int4 sl = slots[slot];
     // P[0] = Xr^T Dr, P[1] = Xi^T Dr, P[2] = Xr^T Di, P[3] = Xi^T Di
-    const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : P[1] - P[2];
+    const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : isign * (P[1] - P[2]);     // isign = -1: conj(X^) D^ instead of X^ conj(D^)
     csp[((int64_t)ci * ROWS + sl.x) * 32 + co] = cr;
     csp[((int64_t)ci * ROWS + sl.y) * 32 + co] = cim;
   }
@@ -620,19 +628,19 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   fw.x = w; fw.sp = ws.wsp; fw.tab = ws.tab; fw.H = d->kh; fw.W = d->kw; fw.C = d->Cin * d->Cout; fw.ld = d->Cin * d->Cout; fw.groups = d->Cin * gout;
   fw.cstride = gout > 1 ? 32 : d->Cout; fw.cvalid = gout > 1 ? 32 : d->Cout;     // group ci * gout + go holds output channels 32 go .. 32 go + 31
   fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
-  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T;
+  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
   launch_fwd(h, fw, 1);
   hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, ws.wsp, ws.slots, ws.M, d->Cin, gin, gout);
   PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
   FwdParams fx;
   fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
   fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
-  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T;
+  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
   InvParams iv;
   iv.sp = ws.ys; iv.tab = ws.tab; iv.y = y; iv.bias = bias; iv.bn_scale = bn_scale; iv.bn_shift = bn_shift; iv.res = residual; iv.act_out = act_out;
   iv.absmax = reinterpret_cast<unsigned*>(h->y_absmax);
   iv.Ho = d->Ho; iv.Wo = d->Wo; iv.C = d->Cout; iv.ldy = d->ldy; iv.ld_res = d->ld_res; iv.ld_act = d->ld_act_out; iv.groups = gout; iv.cstride = 32; iv.cvalid = 32;
-  iv.act = d->act; iv.alpha = d->act_alpha; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx;
+  iv.act = d->act; iv.alpha = d->act_alpha; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx; iv.flip = 0;
   MixParams mx;
   mx.xs = ws.xs; mx.ys = ws.ys; mx.M = ws.M; mx.slots = ws.slots; mx.gin = gin; mx.gout = gout;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
@@ -661,7 +669,7 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
   FwdParams fx;
   fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
   fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
-  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T;
+  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
   FwdParams fz = fx;                                    // dz: the tile's own Vy x Vx outputs, zero elsewhere in the window
   fz.x = dz; fz.sp = ws.ys; fz.H = d->Ho; fz.W = d->Wo; fz.C = d->Cout; fz.ld = d->ldy; fz.groups = 1; fz.oy = 0; fz.ox = 0;
   fz.pad_mode = PCNN_PAD_CONSTANT; fz.pad_value = 0.f; fz.ylim = Vy; fz.xlim = Vx;
@@ -674,13 +682,101 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
     launch_fwd(h, fz, nt);
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S / 4, gin), dim3(256), 0, h->stream, wm);
   }
-  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, ws.part, ws.slots, ws.csp, S, gin, d->Cin);
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, ws.part, ws.slots, ws.csp, S, gin, d->Cin, 1.0f);
   InvParams iv;
   iv.sp = ws.csp; iv.tab = ws.tab; iv.y = dw; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = nullptr; iv.act_out = nullptr;
   iv.absmax = nullptr; iv.Ho = d->kh; iv.Wo = d->kw; iv.C = d->Cin * d->Cout; iv.ldy = d->Cin * d->Cout; iv.ld_res = 0; iv.ld_act = 0;
   iv.groups = d->Cin; iv.cstride = d->Cout; iv.cvalid = d->Cout; iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f;
-  iv.tiles_x = 1; iv.tiles_y = 1; iv.tile0 = 0; iv.Vy = T; iv.Vx = T;
+  iv.tiles_x = 1; iv.tiles_y = 1; iv.tile0 = 0; iv.Vy = T; iv.Vx = T; iv.flip = 0;
   launch_inv(h, iv, 1);
   PCNN_CHECK_LAUNCH(h, "spectral weight gradient");
+  return 0;
+}
+
+// Both gradients of one layer in one pass over the tile grid of the DATA gradient: the spectrum of dz's windows (with halo) is computed once
+// and serves the data gradient (channel mixing with the flipped filter, inverse transform -> dx) AND the weight gradient, which is formed
+// input-partitioned - dw[t] = sum over x tiles (their own Vy x Vx values, zero elsewhere: a cheap masked transform) of
+// corr(x tile, dz window)[k-1-t] - so that neither x's windows nor a second, masked copy of dz have to be transformed.
+// d: the forward convolution; dg: its data-gradient convolution (input dz, filter w_flipped (kh,kw,Cout,Cin), output dx or, for
+// SYMMETRIC / REFLECT layers, the gradient on the padded domain).
+extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg) {
+  if (!h || !d || !dg) return 0;
+  if (d->Cout > 32 || d->Cin > 64) return 0;
+  if (d->pad_mode == PCNN_PAD_CONSTANT && d->pad_value != 0.f) return 0;
+  if (pcnn_conv_small_fwd_eligible(dg)) return 0;
+  return pcnn_spectral_eligible(h, dg, false) && pcnn_spectral_eligible(h, d, true) ? 1 : 0;
+}
+
+extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
+                                        const float* residual, float* dx, float* dw) {
+  PCNN_REQUIRE(h, h && d && dg && x && dz && w_flipped && dx && dw, "pcnn_conv2d_bwd_spectral: null argument");
+  PCNN_REQUIRE(h, pcnn_conv2d_bwd_spectral_eligible(h, d, dg), "pcnn_conv2d_bwd_spectral: layer is not eligible (ask pcnn_conv2d_bwd_spectral_eligible first)");
+  PCNN_REQUIRE(h, dg->Cin == d->Cout && dg->Cout == d->Cin && dg->kh == d->kh && dg->kw == d->kw && dg->N == d->N, "pcnn_conv2d_bwd_spectral: descriptors do not match");
+  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const int tiles_y = pcnn_cdiv(dg->Ho, Vy), tiles_x = pcnn_cdiv(dg->Wo, Vx);
+  const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
+  PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
+  const int gz = 1, gx = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();       // channel groups of dz (<= 32 channels) and of x / dx
+  const int chunk = (int)std::min<int64_t>(chunk_tiles() / gx, ntile);
+  // workspace: [filter spectrum | M | dz spectra (gz) | dx spectra (gx) | x-tile spectra (gx) | partial sums]; C^ reuses the filter-spectrum slot
+  const size_t wsp_b = align256((size_t)std::max(dg->Cin * gx, d->Cin) * ROWS * 32 * 4), M_b = align256((size_t)NSLOT * gz * gx * 64 * 64 * 4);
+  const size_t zs_b = align256((size_t)chunk * gz * ROWS * 32 * 4), ys_b = align256((size_t)chunk * gx * ROWS * 32 * 4);
+  const size_t part_b = align256((size_t)S * NSLOT * gx * 4 * 1024 * 4);
+  Workspace ws;
+  if (int rc = ensure_workspace(h, wsp_b + M_b + zs_b + 2 * ys_b + part_b + 4096, ws, 1, 1, 1, 1)) return rc;
+  char* r = reinterpret_cast<char*>(ws.wsp);
+  float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
+  float* Mm = reinterpret_cast<float*>(r); r += M_b;
+  float* zs = reinterpret_cast<float*>(r); r += zs_b;
+  float* ys = reinterpret_cast<float*>(r); r += ys_b;
+  float* xs = reinterpret_cast<float*>(r); r += ys_b;
+  float* part = reinterpret_cast<float*>(r);
+  // flipped filter spectrum -> mixing matrices of the data gradient (input groups: dz's, output groups: dx's)
+  FwdParams fw;
+  fw.x = w_flipped; fw.sp = wsp; fw.tab = ws.tab; fw.H = d->kh; fw.W = d->kw; fw.C = dg->Cin * dg->Cout; fw.ld = dg->Cin * dg->Cout; fw.groups = dg->Cin * gx;
+  fw.cstride = gx > 1 ? 32 : dg->Cout; fw.cvalid = gx > 1 ? 32 : dg->Cout;
+  fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
+  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
+  PCNN_REQUIRE(h, gx == 1 || dg->Cout == 64, "pcnn_conv2d_bwd_spectral: %d input channels unsupported (<= 32 or 64)", d->Cin);
+  launch_fwd(h, fw, 1);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, ws.slots, Mm, dg->Cin, gz, gx);
+  PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral (filter spectrum)");
+  FwdParams fz;                                          // dz windows with halo: the data gradient's input transform
+  fz.x = dz; fz.sp = zs; fz.tab = ws.tab; fz.H = dg->H; fz.W = dg->W; fz.C = dg->Cin; fz.ld = dg->ldx; fz.groups = gz; fz.cstride = 32; fz.cvalid = 32;
+  fz.tiles_x = tiles_x; fz.tiles_y = tiles_y; fz.Vy = Vy; fz.Vx = Vx; fz.oy = dg->pad_top; fz.ox = dg->pad_left; fz.pad_mode = dg->pad_mode;
+  fz.pad_value = dg->pad_value; fz.ylim = T; fz.xlim = T; fz.ext_y = 1 << 30; fz.ext_x = 1 << 30;
+  FwdParams fxm = fz;                                    // x tiles: own Vy x Vx values (boundary-condition padded where the grid is the padded domain)
+  const bool padded_domain = d->pad_mode != PCNN_PAD_CONSTANT;
+  fxm.x = x; fxm.sp = xs; fxm.H = d->H; fxm.W = d->W; fxm.C = d->Cin; fxm.ld = d->ldx; fxm.groups = gx;
+  fxm.oy = padded_domain ? d->pad_top : 0; fxm.ox = padded_domain ? d->pad_left : 0; fxm.pad_mode = d->pad_mode; fxm.pad_value = 0.f;
+  fxm.ylim = Vy; fxm.xlim = Vx; fxm.ext_y = dg->Ho; fxm.ext_x = dg->Wo;
+  InvParams iv;
+  iv.sp = ys; iv.tab = ws.tab; iv.y = dx; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = residual; iv.act_out = nullptr; iv.absmax = nullptr;
+  iv.Ho = dg->Ho; iv.Wo = dg->Wo; iv.C = dg->Cout; iv.ldy = dg->ldy; iv.ld_res = dg->ld_res; iv.ld_act = 0; iv.groups = gx; iv.cstride = 32; iv.cvalid = 32;
+  iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx; iv.flip = 0;
+  MixParams mx;
+  mx.xs = zs; mx.ys = ys; mx.M = Mm; mx.slots = ws.slots; mx.gin = gz; mx.gout = gx;
+  WMixParams wm;
+  wm.xs = xs; wm.ds = zs; wm.part = part; wm.slots = ws.slots; wm.gin = gx; wm.S = S / 4;
+  for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
+    const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
+    fz.tile0 = (int)t0; fxm.tile0 = (int)t0; iv.tile0 = (int)t0; mx.ntile = nt; wm.ntile = nt; wm.accumulate = t0 > 0;
+    launch_fwd(h, fz, nt);
+    const int nMt = pcnn_cdiv(nt, 32);
+    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 4));
+    hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy, gx), dim3(256), 0, h->stream, mx);
+    launch_inv(h, iv, nt);
+    launch_fwd(h, fxm, nt);
+    hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S / 4, gx), dim3(256), 0, h->stream, wm);
+  }
+  float* csp = wsp;                                      // the filter spectrum is no longer needed
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, ws.slots, csp, S, gx, d->Cin, -1.0f);
+  InvParams iw;
+  iw.sp = csp; iw.tab = ws.tab; iw.y = dw; iw.bias = nullptr; iw.bn_scale = nullptr; iw.bn_shift = nullptr; iw.res = nullptr; iw.act_out = nullptr;
+  iw.absmax = nullptr; iw.Ho = d->kh; iw.Wo = d->kw; iw.C = d->Cin * d->Cout; iw.ldy = d->Cin * d->Cout; iw.ld_res = 0; iw.ld_act = 0;
+  iw.groups = d->Cin; iw.cstride = d->Cout; iw.cvalid = d->Cout; iw.act = PCNN_ACT_LINEAR; iw.alpha = 0.f;
+  iw.tiles_x = 1; iw.tiles_y = 1; iw.tile0 = 0; iw.Vy = T; iw.Vx = T; iw.flip = 1;
+  launch_inv(h, iw, 1);
+  PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral");
   return 0;
 }

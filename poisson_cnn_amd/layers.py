@@ -265,6 +265,21 @@ class ConvUnit:
             if trivial:
                 dz = dy
         w = s.w[self.name + '/kernel']
+        kh, kw = self.kh, self.kw
+        if need_dx:
+            # wide filters: both gradients in one call on the spectral route (the spectrum of dz is shared); None = not eligible
+            wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
+            res = add_to if (self.mode == 'CONSTANT') else None
+            out = ops.conv2d_bwd_fused(x, dz, w.shape, wf, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
+                                       dw=g[self.name + '/kernel'], residual=res)
+            if out is not None:
+                if self.mode == 'CONSTANT':
+                    return out
+                if add_to is not None and add_to.is_contiguous():
+                    self.ctx.before_inplace_write(add_to)
+                    return ops.pad_fold_bwd(out, (H, W), (self.pads_y, self.pads_x), self.mode, out=add_to, accumulate=True)
+                dx = ops.pad_fold_bwd(out, (H, W), (self.pads_y, self.pads_x), self.mode)
+                return dx if add_to is None else ops.axpby(1.0, add_to, 1.0, dx)
         side = self.ctx.side_stream()
         if side is None:
             ops.conv2d_wgrad(x, dz, w.shape, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
@@ -284,7 +299,6 @@ class ConvUnit:
             self.ctx.side_reads[dz.data_ptr()] = done          # see Context.before_inplace_write
         if not need_dx:
             return None
-        kh, kw = self.kh, self.kw
         wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
         if self.mode == 'CONSTANT':
             return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to)

@@ -210,6 +210,33 @@ def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_
     return dw
 
 
+def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, dw, residual=None):
+    """Both gradients of the fused pad+conv in one call when the layer takes the spectral route (pcnn_conv2d_bwd_spectral: dz's spectrum is
+    computed once for the data gradient and the weight gradient).  wf: the flipped / transposed filter (kh,kw,Cout,Cin).  Fills dw and returns
+    the data-gradient convolution's output - dx for CONSTANT padding (+ `residual` if given), the gradient on the padded domain otherwise
+    (fold it with pad_fold_bwd) - or None when the layer is not eligible (the caller then uses conv2d_wgrad / conv2d_fwd)."""
+    N, H, W, Cin = x.shape
+    kh, kw, _, Cout = w_shape
+    mode = pad_mode.upper()
+    d = conv_desc(x.shape, _ld(x), w_shape, (dz.shape[1], dz.shape[2]), _ld(dz), pad_top, pad_left, mode, pad_value)
+    if mode == 'CONSTANT':
+        out_hw, dpt, dpl = (H, W), kh - 1 - pad_top, kw - 1 - pad_left
+    else:
+        out_hw, dpt, dpl = (H + kh - 1, W + kw - 1), kh - 1, kw - 1
+        residual = None
+    ldo = Cin
+    dg = conv_desc(dz.shape, _ld(dz), (kh, kw, Cout, Cin), out_hw, ldo, dpt, dpl, 'CONSTANT', 0.0, 'linear', _ld(residual) if residual is not None else 0, 0)
+    h = handle()
+    if not h.lib.pcnn_conv2d_bwd_spectral_eligible(h._h, byref(d), byref(dg)):
+        return None
+    out = empty((N, out_hw[0], out_hw[1], Cin), x.device)
+    flops = 2.0 * N * dz.shape[1] * dz.shape[2] * kh * kw * Cin * Cout
+    _launch('conv_bwd_fused', 2.0 * flops,
+            lambda: h.call('pcnn_conv2d_bwd_spectral', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw)),
+            4.0 * (2 * N * H * W * Cin + N * dz.shape[1] * dz.shape[2] * Cout + 2 * kh * kw * Cin * Cout))
+    return out
+
+
 def epilogue_bwd(dy, a, *, act='linear', bn_scale=None, dz=None, dbias=None, s_dy_a=None, s_dy=None, ws=None, dz_absmax=None):
     """dz_absmax: optional 1-element device tensor that receives max|dz| (a free by-product; conv2d_wgrad takes it as a hint)."""
     N, H, W, C = dy.shape
