@@ -194,7 +194,7 @@ def traffic_from_profiles(math, workload, kernel_prefix):
         summ = json.load(f)
     if summ.get('source_hash') != _lib.source_hash():
         return None, 'profiles/%s was measured on other kernel sources (stamp %s, this tree %s): re-run tools/collect_pmc.sh' % (name, summ.get('source_hash'), _lib.source_hash())
-    ks = [v for k, v in summ['kernels'].items() if k.startswith(kernel_prefix)]
+    ks = [v for k, v in summ['kernels'].items() if k.startswith(kernel_prefix + ' (')] or [v for k, v in summ['kernels'].items() if k.startswith(kernel_prefix)]
     if not ks:
         return None, 'no %s* rows in profiles/%s' % (kernel_prefix, name)
     return (sum(v['traffic_bytes_per_launch'] * v['launches'] for v in ks) / max(sum(v['launches'] for v in ks), 1),
@@ -299,8 +299,8 @@ def run(args):
                 'achieved': af / as_ / 1e12 if as_ else None, 'peak': peak, 'unit': 'TFLOP/s (ALGORITHMIC direct-convolution fp32 FLOP, 2 N Ho Wo kh kw Cin Cout per launch)',
                 'frac': af / as_ / 1e12 / peak if as_ else None,
                 'note': 'frac > 1 is possible: the spectral route needs ~k^2/25 times fewer multiply-adds than the direct convolution the numerator counts',
-                'traffic': traffic, 'traffic_source': tsrc, 'launches': ac, 'avg_launch_ms': 1e3 * as_ / ac if ac else None,
-                'algorithmic_bytes_per_launch': (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused')) / max(calls + bc, 1),
+                'traffic': traffic, 'traffic_unit': 'bytes per training step over all convolution kernels (2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': tsrc, 'launches': ac, 'avg_launch_ms': 1e3 * as_ / ac if ac else None,
+                'algorithmic_bytes_per_step': (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad')) / max(args.steps, 1),
                 'forward_and_data_gradient': blk(flops, secs, calls), 'wgrad_kernel': blk(wf, ws_, wc), 'backward_fused': blk(bf, bs, bc),
                 'hbm_bound': {'what': 'conv forward / data-gradient launches below the fp32 ridge (%.1f FLOP/B: the 3x3 tail with <= 8 channels and the Scaling convs)' % ridge,
                               'bound': 'hbm', 'achieved': hb / hs / 1e9 if hs else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s (algorithmic bytes)',

@@ -206,7 +206,8 @@ def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_
     dw = out if out is not None else empty(tuple(w_shape), x.device)
     assert dw.is_contiguous()
     _launch('conv_wgrad', 2.0 * N * Ho * Wo * w_shape[0] * w_shape[1] * w_shape[2] * w_shape[3],
-            lambda: handle().call('pcnn_conv2d_wgrad_hint', byref(d), _p(x), _p(dz), _p(dw), _p(wsb), c_size_t(wsb.numel() * 4), _p(x_absmax), _p(dz_absmax)))
+            lambda: handle().call('pcnn_conv2d_wgrad_hint', byref(d), _p(x), _p(dz), _p(dw), _p(wsb), c_size_t(wsb.numel() * 4), _p(x_absmax), _p(dz_absmax)),
+            4.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + N * Ho * Wo * Cout + w_shape[0] * w_shape[1] * w_shape[2] * w_shape[3]))
     return dw
 
 

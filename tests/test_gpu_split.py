@@ -63,7 +63,7 @@ def test_wide_dynamic_range_inputs():
     assert np.linalg.norm(dw.cpu().numpy() - refw) / np.linalg.norm(refw) < 5e-6
 
 
-@pytest.mark.parametrize('shift,bound_split', [(15, 4e-6), (20, 1.2e-4)])
+@pytest.mark.parametrize('shift,bound_split', [(15, 6e-6), (20, 1.2e-4)])
 def test_componentwise_error_on_low_magnitude_region(shift, bound_split):
     """The split kernel scales each (tile, 8-channel chunk) by ONE power of two, so pixels far below the chunk's maximum sit low in fp16's
     range: 2^15 below they still carry 22 significand bits (hi normal, lo at the subnormal edge), 2^20 below the lo half is subnormal and
@@ -74,7 +74,7 @@ def test_componentwise_error_on_low_magnitude_region(shift, bound_split):
     from oracle import np_ops
     from poisson_cnn_amd import ops
     rng = np.random.default_rng(21 + shift)
-    N, C, H, W, k, Co = 1, 8, 16, 64, 5, 8
+    N, C, H, W, k, Co = 1, 24, 16, 64, 5, 24          # > 16 channels: the MFMA kernels (narrower layers take the exact-fp32 vector-ALU kernels in both modes)
     x = (rng.uniform(-1, 1, (N, C, H, W)) * 2.0 ** -shift).astype(np.float32)
     x[:, :, 0:2, 0:2] = rng.uniform(0.5, 1.0, (N, C, 2, 2)).astype(np.float32)       # the chunk maximum: ~1, in the corner of every tile row block
     x[:, :, 8:10, 32:34] = rng.uniform(0.5, 1.0, (N, C, 2, 2)).astype(np.float32)
@@ -86,6 +86,8 @@ def test_componentwise_error_on_low_magnitude_region(shift, bound_split):
     xt = torch.tensor(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), device='cuda')
     wt = torch.tensor(w, device='cuda')
     errs = {}
+    spec = ops.get_spectral_mode()
+    ops.set_spectral_mode('off')                         # this test is about the direct split kernel's per-tile scaling
     for mode in ('split_f16', 'fp32'):
         ops.set_math_mode(mode)
         got = ops.conv2d_fwd(xt, wt, None, pad_top=2, pad_left=2, pad_mode='CONSTANT').cpu().numpy().transpose(0, 3, 1, 2).astype(np.float64)
@@ -93,7 +95,8 @@ def test_componentwise_error_on_low_magnitude_region(shift, bound_split):
         assert np.abs(r).max() < 2.0 ** -(shift - 6)                                  # the region really holds only small-input outputs
         errs[mode] = np.abs(got[:, :, region] - r).max() / np.sqrt(np.mean(r ** 2))
     ops.set_math_mode('split_f16')
-    assert errs['fp32'] < 2e-6, errs
+    ops.set_spectral_mode(spec)
+    assert errs['fp32'] < 4e-6, errs                     # max-norm over the region, relative to its RMS
     assert errs['split_f16'] < bound_split, errs
 
 
