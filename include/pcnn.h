@@ -37,6 +37,9 @@ int pcnn_set_stream(pcnn_handle h, void* hip_stream);
 int pcnn_sync(pcnn_handle h);
 const char* pcnn_last_error(pcnn_handle h);
 int pcnn_version(void);
+/* CRC-32C of a host buffer (continue from `crc`, 0 to start): the checksum of TensorFlow TensorBundle checkpoints
+ * (train/utils.py:10-29 loads them; poisson_cnn_amd/tf_checkpoint.py reads and writes the format).  Host only. */
+uint32_t pcnn_crc32c(const void* data, size_t n, uint32_t crc);
 
 /* Arithmetic of the convolution GEMMs.
  *   PCNN_MATH_FP32      (default): v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulate.

@@ -56,3 +56,22 @@ extern "C" int pcnn_set_spectral_mode(pcnn_handle h, int mode) {
 }
 
 extern "C" int pcnn_get_spectral_mode(pcnn_handle h) { return h ? h->spectral_mode : -2; }
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a HOST buffer: the checksum of TensorFlow's TensorBundle checkpoint files
+// (tensorflow/core/lib/hash/crc32c.h) that poisson_cnn_amd/tf_checkpoint.py reads and writes.  Host-only helper, no device work.
+extern "C" uint32_t pcnn_crc32c(const void* data, size_t n, uint32_t crc) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      table[i] = c;
+    }
+    init = true;
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  crc = ~crc;
+  for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+  return ~crc;
+}

@@ -7,6 +7,8 @@ experiments/hpnn.json loads unchanged), `model([rhs, dx]) -> (N,1,H,W)`, `compil
 """
 import copy
 
+import os
+
 import numpy as np
 import torch
 
@@ -73,11 +75,22 @@ class _ModelBase:
                 raise ValueError('shape mismatch for %s: %s vs %s' % (n, v.shape, tuple(self.store.w[n].shape)))
             self.store.w[n].copy_(torch.from_numpy(v))
 
-    def save_weights(self, path):
+    def save_weights(self, path, save_format=None):
+        """Flat .npz keyed by parameter name (every model), or - save_format='tf' - the TensorFlow checkpoint pair <path>.index +
+        <path>.data-00000-of-00001 that the reference's `model.save_weights(path)` writes (tf_checkpoint.py)."""
+        if save_format in ('tf', 'tensorflow'):
+            from .tf_checkpoint import save_tf_checkpoint
+            return save_tf_checkpoint(self, str(path))
+        if save_format not in (None, 'npz'):
+            raise ValueError('save_format must be None / "npz" / "tf" (HDF5 is not supported)')
         np.savez(path, **{n.replace('/', '.'): w for n, w in zip(self.store.names, self.get_weights())})
 
     def load_weights(self, path):
-        with np.load(path if str(path).endswith('.npz') else str(path) + '.npz') as z:
+        path = str(path)
+        if os.path.exists(path + '.index'):
+            from .tf_checkpoint import load_tf_checkpoint
+            return load_tf_checkpoint(self, path)
+        with np.load(path if path.endswith('.npz') else path + '.npz') as z:
             self.set_weights({n: z[n.replace('/', '.')] for n in self.store.names})
 
     def count_params(self):

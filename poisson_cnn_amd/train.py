@@ -96,15 +96,16 @@ class Callback:
 
 
 class ModelCheckpoint(Callback):
-    def __init__(self, filepath, save_weights_only=True, save_best_only=True, monitor='loss'):
+    def __init__(self, filepath, save_weights_only=True, save_best_only=True, monitor='loss', save_format=None):
         self.filepath, self.best, self.monitor, self.save_best_only = filepath, math.inf, monitor, save_best_only
+        self.save_format = save_format                       # None: flat .npz; 'tf': TensorFlow checkpoint files (tf_checkpoint.py)
 
     def on_epoch_end(self, epoch, logs):
         v = logs[self.monitor]
         if not self.save_best_only or v < self.best:
             self.best = min(self.best, v)
             if int(os.environ.get('RANK', '0')) == 0:
-                self.model.save_weights(self.filepath)
+                self.model.save_weights(self.filepath, **({'save_format': self.save_format} if self.save_format else {}))
 
 
 class ReduceLROnPlateau(Callback):
@@ -147,12 +148,24 @@ class TerminateOnNaN(Callback):
             self.model.stop_training = True
 
 
+def latest_checkpoint(checkpoint_dir):
+    """tf.train.latest_checkpoint: the prefix named by `model_checkpoint_path` in <dir>/checkpoint, or None."""
+    state = os.path.join(checkpoint_dir, 'checkpoint')
+    if os.path.exists(state):
+        for line in open(state):
+            if line.startswith('model_checkpoint_path:'):
+                name = line.split(':', 1)[1].strip().strip('"')
+                return name if os.path.isabs(name) else os.path.join(checkpoint_dir, name)
+    return None
+
+
 def load_model_checkpoint(model, checkpoint_path, **unused):
-    """train/utils.py:10-29 (checkpoints are flat .npz in get_weights() order)."""
+    """train/utils.py:10-29.  A directory holding TensorFlow checkpoint files (a `checkpoint` state file naming the prefix, as Keras'
+    ModelCheckpoint leaves it) is read through tf_checkpoint.py; otherwise the flat .npz this package writes by default."""
     if checkpoint_path is not None:
         path = checkpoint_path
         if os.path.isdir(path):
-            path = os.path.join(path, 'chkpt.checkpoint.npz')
+            path = latest_checkpoint(path) or os.path.join(path, 'chkpt.checkpoint.npz')
         print('Attempting to load checkpoint from ' + path)
         model.load_weights(path)
 

@@ -1,0 +1,146 @@
+"""TensorFlow checkpoint (TensorBundle V2) interchange, tf_checkpoint.py: the format's fixed points and the round trip.  No TensorFlow exists
+here, so cross-reading with TensorFlow itself is NOT covered (the module header says "parity unpinned")."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from poisson_cnn_amd import tf_checkpoint as T
+
+
+def test_crc32c_known_answers_and_mask():
+    # RFC 3720 B.4 vectors
+    assert T.crc32c(b'123456789') == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA
+    assert T.crc32c(bytes([0xff] * 32)) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    # running form: Extend(Extend(0, a), b) == Value(a + b)
+    assert T.crc32c(b'6789', T.crc32c(b'12345')) == 0xE3069283
+    for v in (0, 1, 0xE3069283, 0xffffffff):
+        assert T.unmask(T.mask(v)) == v
+    assert T.mask(0xE3069283) == (((0xE3069283 >> 15) | (0xE3069283 << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def test_bundle_round_trip_and_layout(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {'a/b/kernel' + T.SUFFIX: rng.standard_normal((3, 3, 2, 4)).astype(np.float32),
+               'a/b/bias' + T.SUFFIX: rng.standard_normal(4).astype(np.float32),
+               'a/c/0/gamma' + T.SUFFIX: rng.standard_normal(7).astype(np.float64),
+               'step' + T.SUFFIX: np.array(12345, dtype=np.int64)}
+    prefix = str(tmp_path / 'chkpt.checkpoint')
+    T.write_bundle(prefix, tensors)
+    assert sorted(os.listdir(tmp_path)) == ['checkpoint', 'chkpt.checkpoint.data-00000-of-00001', 'chkpt.checkpoint.index']
+    idx = open(prefix + '.index', 'rb').read()
+    assert struct.unpack('<Q', idx[-8:])[0] == 0xdb4775248b80fb57                     # table magic
+    got = T.read_bundle(prefix)
+    assert sorted(got) == sorted(tensors)
+    for k in tensors:
+        assert got[k].dtype == tensors[k].dtype and got[k].shape == tensors[k].shape
+        np.testing.assert_array_equal(got[k], tensors[k])
+    # the data shard is the raw little-endian bytes back to back in key order (object graph included)
+    keys = sorted(list(tensors) + [T.OBJECT_GRAPH_KEY])
+    data = open(prefix + '.data-00000-of-00001', 'rb').read()
+    off = 0
+    for k in keys:
+        if k != T.OBJECT_GRAPH_KEY:
+            raw = tensors[k].tobytes()
+            assert data[off:off + len(raw)] == raw
+            off += len(raw)
+        else:
+            n, p = T._read_varint(data, off)
+            off = p + 4 + n
+    assert off == len(data)
+    # header entry: key "", num_shards 1, version.producer 1
+    items = T._read_table(prefix + '.index')
+    assert items[0][0] == b'' and [k for k, _ in items] == sorted(k for k, _ in items)
+    hdr = {n: v for n, _, v in T._parse(items[0][1])}
+    assert hdr[1] == 1 and T._parse(hdr[3]) == [(1, 0, 1)]
+    # state file
+    assert 'model_checkpoint_path: "chkpt.checkpoint"' in open(tmp_path / 'checkpoint').read()
+
+
+def test_corruption_is_detected(tmp_path):
+    prefix = str(tmp_path / 'c')
+    T.write_bundle(prefix, {'w' + T.SUFFIX: np.arange(100, dtype=np.float32)})
+    raw = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    raw[-17] ^= 0x40                                                # inside the float tensor (the object graph sorts first)
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='checksum mismatch'):
+        T.read_bundle(prefix)
+    assert T.read_bundle(prefix, verify=False)['w' + T.SUFFIX].shape == (100,)
+    idx = bytearray(open(prefix + '.index', 'rb').read())
+    idx[3] ^= 0x01
+    open(prefix + '.index', 'wb').write(bytes(idx))
+    with pytest.raises(ValueError, match='block checksum'):
+        T.read_bundle(prefix)
+    open(prefix + '.index', 'wb').write(b'not a table' * 10)
+    with pytest.raises(ValueError, match='bad magic'):
+        T.read_bundle(prefix)
+
+
+def test_many_keys_span_several_table_blocks(tmp_path):
+    tensors = {'layer/%04d/kernel%s' % (i, T.SUFFIX): np.full((i % 5 + 1,), i, dtype=np.float32) for i in range(700)}
+    prefix = str(tmp_path / 'big')
+    T.write_bundle(prefix, tensors)
+    # force small blocks as well: restart points + prefix compression + several data blocks
+    items = [(k.encode(), b'v' * 10) for k in sorted(tensors)]
+    T._write_table(str(tmp_path / 't.index'), items, block_size=512)
+    assert T._read_table(str(tmp_path / 't.index')) == items
+    got = T.read_bundle(prefix)
+    assert len(got) == 700 and all(np.array_equal(got[k], tensors[k]) for k in tensors)
+
+
+def test_object_graph_names_every_variable():
+    keys = ['a/b/kernel' + T.SUFFIX, 'a/b/bias' + T.SUFFIX, 'a/c/0/gamma' + T.SUFFIX]
+    g = T._object_graph(keys)
+    nodes = [v for n, _, v in T._parse(g) if n == 1]
+    # root -> a -> {b -> {kernel, bias}, c -> 0 -> gamma}: 1 + 1 + 2 + 2 + 1 + 1 nodes
+    assert len(nodes) == 8
+    root_children = [dict((n, v) for n, _, v in T._parse(c))[2] for n, _, c in T._parse(nodes[0]) if n == 1]
+    assert root_children == [b'a']
+    found = []
+    for nd in nodes:
+        for n, _, v in T._parse(nd):
+            if n == 2:
+                a = {k: val for k, _, val in T._parse(v)}
+                assert a[1] == b'VARIABLE_VALUE'
+                found.append(a[3].decode())
+    assert sorted(found) == sorted(keys)
+
+
+def test_hpnn_checkpoint_uses_the_reference_object_paths(tmp_path):
+    """Variables land at the attribute paths of models/Homogeneous_Poisson_NN_Legacy.py:41-115 and come back bit-exact through
+    save_weights(save_format='tf') / load_weights / load_model_checkpoint(directory)."""
+    from poisson_cnn_amd import configs, train
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    cfg = configs.hpnn()['model']
+    m = Homogeneous_Poisson_NN_Legacy(**cfg, device='cpu', seed=1)
+    paths = T.keras_object_paths(m)
+    assert paths['pre/conv1/kernel'] == 'pre_bottleneck_convolutions/2/kernel'          # conv, BN, conv, BN, ... in one list
+    assert paths['pre/bn1/moving_variance'] == 'pre_bottleneck_convolutions/3/moving_variance'
+    assert paths['deconv_f16/res1/bn0/gamma'] == 'bottleneck_deconv_blocks/0/conv_layers/2/batchnorm0/gamma'
+    assert paths['deconv_f2/deconv/kernel'] == 'bottleneck_deconv_blocks/4/upsample_layer/kernel'
+    assert paths['multilinear_f32/conv0/bias'] == 'bottleneck_multilinear_blocks/2/conv_layers/0/bias'
+    assert paths['post_merge_resnet/conv2/kernel'] == 'post_merge_resnet/conv_layers/2/kernel'
+    assert paths['final/stage3/res/conv1/bias'] == 'final_convolutions/7/conv_layers/1/bias'
+    assert paths['final/out1/kernel'] == 'final_convolutions/15/kernel'
+    assert paths['dx_dense2/kernel'] == 'dx_dense_layers/2/kernel'
+    assert paths['scaling/conv2/bias'] == 'scaling/stages/4/bias' and paths['scaling/dense1/kernel'] == 'scaling/dense_1/kernel'
+    d = tmp_path / 'ck'
+    d.mkdir()
+    m.save_weights(str(d / 'chkpt.checkpoint'), save_format='tf')
+    m2 = Homogeneous_Poisson_NN_Legacy(**cfg, device='cpu', seed=2)
+    assert any(not np.array_equal(a, b) for a, b in zip(m.get_weights(), m2.get_weights()))
+    train.load_model_checkpoint(m2, str(d))
+    for a, b in zip(m.get_weights(), m2.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    # a checkpoint lacking a variable is an error, extra variables (optimizer slots) are ignored
+    t = T.read_bundle(str(d / 'chkpt.checkpoint'))
+    t['optimizer/iter' + T.SUFFIX] = np.array(3, dtype=np.int64)
+    T.write_bundle(str(d / 'extra'), t)
+    m2.load_weights(str(d / 'extra'))
+    del t['post_merge_conv/kernel' + T.SUFFIX]
+    T.write_bundle(str(d / 'short'), t)
+    with pytest.raises(ValueError, match='post_merge_conv/kernel'):
+        m2.load_weights(str(d / 'short'))
