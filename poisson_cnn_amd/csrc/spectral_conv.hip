@@ -32,7 +32,9 @@ bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d);   // conv_small.hip
 namespace {
 
 constexpr int T = 32, ROWS = 1024, NSLOT = 512;
-constexpr int TAB_G = 0, TAB_GI = 1024, TAB_FC = 2048, TAB_FI = 2048 + 4096, TAB_FLOATS = 2048 + 8192;
+// tables (all stored [k][m], 32 x 32): G / GI the real <-> half-complex 32-point transforms; F2[parity] / FI2[parity] the two 16-point complex
+// transforms of one radix-2 step of the 32-point complex DFT (see build_tables); GI2 the real-column inverse split into its two parities
+constexpr int TAB_G = 0, TAB_GI = 1024, TAB_F2 = 2048, TAB_FI2 = 4096, TAB_GI2 = 6144, TAB_FLOATS = 7168;
 constexpr size_t LDS_U = (size_t)T * T * 32 * sizeof(float);   // 128 KB
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -118,9 +120,10 @@ __device__ __forceinline__ f32x16 fwd_row_mfma(const FwdParams& p, const FwdItem
   return acc;
 }
 
-// Persistent: one workgroup (8 waves) per CU walks the (tile, group) items; the first window row of the next item is requested before
-// the y-axis phase of the current one, every other row one row ahead (two register sets, ping-pong), so the global-load latency sits
-// under MFMAs.
+// Persistent: one workgroup (8 waves) per CU walks the (tile, group) items.  A wave's four window rows of the NEXT item are requested
+// before the y-axis phase of the current one (four register sets), so the global-load latency sits under that phase's MFMAs.
+// y axis: one radix-2 decimation-in-frequency step on the vector ALU (u[y] +- u[y + 16], in-lane), then the even / odd output frequencies
+// are two 16-point complex DFTs = two real 32 x 32 products (F2[0], F2[1]) - half the matrix-core work of the 64 x 64 real form.
 // MASKED: the window holds values only in its first ylim x xlim entries (gradient tiles): their zero rows / columns are skipped.
 // FENCE: fetch a unit's LDS operands as one burst before its MFMA chain (see lds_fence).
 template <bool MASKED, bool FENCE>
@@ -132,53 +135,55 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
   const int total = p.ntile * p.groups;
   int item = blockIdx.x;
   if (item >= total) return;
-  float greg[16], fcreg[32];
+  float greg[16], freg[16];
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) greg[xs] = p.tab[TAB_G + (2 * xs + half) * 32 + c];
 #pragma unroll
-  for (int ks = 0; ks < 32; ++ks) fcreg[ks] = p.tab[TAB_FC + (2 * ks + half) * 64 + 32 * h + c];
+  for (int ks = 0; ks < 16; ++ks) freg[ks] = p.tab[TAB_F2 + h * 1024 + (2 * ks + half) * 32 + c];
   FwdItem cur;
   fwd_item(p, item, half, c, cur);
-  float v0[16], v1[16];
-  fwd_load_row<MASKED>(p, cur, wave, v0);
+  float v[4][16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fwd_load_row<MASKED>(p, cur, wave + 8 * j, v[j]);
   for (;;) {
     const int next = item + gridDim.x;
     // ---- x axis: D_y[s][c] = sum_x G[s][x] xw[y][x][c]; A = G (lane = s), B = the pixel's channel row (lane = c), two x per MFMA
-    auto store_u = [&](int y, const f32x16& acc) {
+    const int ylim = cur.ylim;                                       // `cur` will describe the NEXT item by the time the y axis runs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = wave + 8 * j;
+      const f32x16 acc = fwd_row_mfma<MASKED>(p, cur, y, greg, v[j]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) U[(y * 32 + acc_row(r, half)) * 32 + c] = acc[r];
-    };
-    const int ylim = cur.ylim;                                       // `cur` will describe the NEXT item by the time the y axis runs
-    fwd_load_row<MASKED>(p, cur, wave + 8, v1);
-    store_u(wave, fwd_row_mfma<MASKED>(p, cur, wave, greg, v0));
-    fwd_load_row<MASKED>(p, cur, wave + 16, v0);
-    store_u(wave + 8, fwd_row_mfma<MASKED>(p, cur, wave + 8, greg, v1));
-    fwd_load_row<MASKED>(p, cur, wave + 24, v1);
-    store_u(wave + 16, fwd_row_mfma<MASKED>(p, cur, wave + 16, greg, v0));
-    {
-      const f32x16 acc = fwd_row_mfma<MASKED>(p, cur, wave + 24, greg, v1);
-      if (next < total) { fwd_item(p, next, half, c, cur); fwd_load_row<MASKED>(p, cur, wave, v0); }   // `cur` now describes the next item
-      store_u(wave + 24, acc);
+    }
+    if (next < total) {                                              // `cur` now describes the next item
+      fwd_item(p, next, half, c, cur);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fwd_load_row<MASKED>(p, cur, wave + 8 * j, v[j]);
     }
     __syncthreads();
-    // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = 0 -> real part rows, h = 1 -> imaginary part rows.
+    // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = parity of the output frequencies fy it produces.
     float* out = p.sp + (int64_t)item * ROWS * 32;
 #pragma unroll 1
     for (int fx = 1 + q; fx <= 15; fx += 4) {
-      float bu[32];
+      float bu[16];
 #pragma unroll
-      for (int ks = 0; ks < 32; ++ks) {
-        const int yk = (2 * ks + half) & 31, s = ks < 16 ? fx : 16 + fx;
-        if (!MASKED || 2 * (ks & 15) < ylim) bu[ks] = U[(yk * 32 + s) * 32 + c];      // rows beyond ylim are zero: K steps skipped (uniform)
+      for (int ks = 0; ks < 16; ++ks) {                              // K step ks: k = 2 ks + half = 16 part + y, y < 16
+        const int y = 2 * (ks & 7) + half, sc = ks < 8 ? fx : 16 + fx;
+        const float lo = U[(y * 32 + sc) * 32 + c];
+        const float hi = (!MASKED || 16 + 2 * (ks & 7) < ylim) ? U[((y + 16) * 32 + sc) * 32 + c] : 0.f;     // rows beyond ylim are zero (uniform test)
+        bu[ks] = h ? lo - hi : lo + hi;
       }
       if (FENCE) lds_fence();
       f32x16 acc = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 32; ++ks)
-        if (!MASKED || 2 * (ks & 15) < ylim) acc = mfma(fcreg[ks], bu[ks], acc);
-      float* o = out + (64 + 64 * (fx - 1) + 32 * h) * 32;
+      for (int ks = 0; ks < 16; ++ks) acc = mfma(freg[ks], bu[ks], acc);
+      float* o = out + (64 + 64 * (fx - 1) + h) * 32;                // accumulator row 16 part + m  ->  spectrum row 32 part + 2 m + h
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, half);
+        o[(unsigned)((32 * (row >> 4) + 2 * (row & 15)) * 32 + c)] = acc[r];
+      }
     }
     if (q == 3) {                                                        // the two real columns: fx = 0 (wave 6), fx = 16 (wave 7)
       const int col = h ? 16 : 0;
@@ -210,16 +215,24 @@ struct InvParams {
   int flip;              // store output pixel (y, x) at (Ho-1-y, Wo-1-x): the input-partitioned weight gradient comes out tap-reversed
 };
 
-// unit u of wave (q, h): complex column fx = 1 + q + 4u (32 K steps), or - q == 3, u == 3 - the real column 0 / 16 (16 K steps).
-// `in` is the item's uniform base, `loff` = 32 half + c the lane's offset.
-__device__ __forceinline__ void inv_load_unit(const float* in, int q, int h, unsigned loff, int u, float (&b)[32]) {
+// unit u of wave (q, h): complex column fx = 1 + q + 4u, input frequencies fy of parity h (K = (part, m), fy = 2 m + h), or - q == 3, u == 3 -
+// the real column 0 / 16 (all 32 half-complex entries).  `in` is the item's uniform base, `loff` = 32 half + c the lane's offset.
+__device__ __forceinline__ void inv_load_unit(const float* in, int q, int h, unsigned loff, int u, float (&b)[16]) {
   const bool realcol = q == 3 && u == 3;
-  const float* src = in + (realcol ? (h ? 32 : 0) : 64 + 64 * (q + 4 * u)) * 32;
+  if (realcol) {
+    const float* src = in + (h ? 32 : 0) * 32;
 #pragma unroll
-  for (int ks = 0; ks < 32; ++ks)
-    if (ks < 16 || !realcol) b[ks] = src[loff + 64u * ks];
+    for (int ks = 0; ks < 16; ++ks) b[ks] = src[loff + 64u * ks];                                   // row 2 ks + half
+  } else {
+    const float* src = in + (64 + 64 * (q + 4 * u) + h) * 32;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) b[ks] = src[2u * loff - (loff & 31u) + 32u * (32 * (ks >> 3) + 4 * (ks & 7))];   // row 32 part + 2 (2 (ks & 7) + half) + h
+  }
 }
 
+// y axis: one radix-2 decimation-in-time step - wave (q, h) produces E (h = 0) or O (h = 1) for rows y < 16 of its columns, two real
+// 32 x 32 products (FI2) instead of the 64 x 64 real form; the x-axis phase forms u[y] = E + O (y < 16) or E - O (y >= 16) while it
+// reads its operands.  LDS: E[(y*32 + s)*32 + c] in the first 64 KB, O in the second.
 // TANH = false: linear / relu / leaky-relu as one select with the negative-side slope in p.alpha (1 / 0 / alpha) - sixteen inlined
 // tanhf bodies would otherwise cost every layer ~90 registers and spills
 template <bool TANH>
@@ -232,41 +245,50 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   const int total = p.ntile * p.groups;
   int item = blockIdx.x;
   if (item >= total) return;
-  float fireg[32], gireg[16];
+  float fireg[16], gireg[16], gi2reg[16];
 #pragma unroll
-  for (int ks = 0; ks < 32; ++ks) fireg[ks] = p.tab[TAB_FI + (2 * ks + half) * 64 + 32 * h + c];
+  for (int ks = 0; ks < 16; ++ks) {
+    fireg[ks] = p.tab[TAB_FI2 + h * 1024 + (2 * ks + half) * 32 + c];
+    gireg[ks] = p.tab[TAB_GI + (2 * ks + half) * 32 + c];
+    gi2reg[ks] = q == 3 ? p.tab[TAB_GI2 + (2 * ks + half) * 32 + c] : 0.f;
+  }
+  float* const Uh = U + h * (16 * 32 * 32);
+  float b[4][16];
+  {
+    const float* in = p.sp + (int64_t)item * ROWS * 32;
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) gireg[ks] = p.tab[TAB_GI + (2 * ks + half) * 32 + c];
-  float b0[32], b1[32];
-  inv_load_unit(p.sp + (int64_t)item * ROWS * 32, q, h, loff, 0, b0);
+    for (int u = 0; u < 4; ++u) inv_load_unit(in, q, h, loff, u, b[u]);
+  }
   float ymax = 0.f;
   for (;;) {
     const int next = item + gridDim.x;
-    const float* in = p.sp + (int64_t)item * ROWS * 32;
-    // ---- y axis inverse: complex columns -> U[y][fx] (h = 0) / U[y][16 + fx] (h = 1); real columns -> U[y][0], U[y][16]
-    auto unit = [&](int u, const float (&b)[32]) {
+    const float* nin = p.sp + (int64_t)next * ROWS * 32;
+    // ---- y axis inverse: complex columns -> E / O [y][fx] (real part) and [y][16 + fx] (imaginary part); real columns -> [y][0], [y][16]
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
       const bool realcol = q == 3 && u == 3;
       f32x16 acc = zero16();
       if (!realcol) {
 #pragma unroll
-        for (int ks = 0; ks < 32; ++ks) acc = mfma(fireg[ks], b[ks], acc);
-      } else {
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(fireg[ks], b[u][ks], acc);
+        if (next < total) inv_load_unit(nin, q, h, loff, u, b[u]);  // the next item's unit u: lands under the rest of this item
+        const int fx = 1 + q + 4 * u;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], b[ks], acc);
+        for (int r = 0; r < 16; ++r) {
+          const int row = acc_row(r, half);                          // 16 part + y
+          Uh[((row & 15) * 32 + 16 * (row >> 4) + fx) * 32 + c] = acc[r];
+        }
+      } else {                                                       // rows 16 par + y: both parities from this one wave
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(gi2reg[ks], b[u][ks], acc);
+        if (next < total) inv_load_unit(nin, q, h, loff, u, b[u]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = acc_row(r, half);
+          U[(row >> 4) * (16 * 32 * 32) + ((row & 15) * 32 + (h ? 16 : 0)) * 32 + c] = acc[r];
+        }
       }
-      const int fx = 1 + q + 4 * u;
-      const int s = realcol ? (h ? 16 : 0) : (h ? 16 + fx : fx);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) U[(acc_row(r, half) * 32 + s) * 32 + c] = acc[r];
-    };
-    inv_load_unit(in, q, h, loff, 1, b1);
-    unit(0, b0);
-    inv_load_unit(in, q, h, loff, 2, b0);
-    unit(1, b1);
-    inv_load_unit(in, q, h, loff, 3, b1);
-    unit(2, b0);
-    if (next < total) inv_load_unit(p.sp + (int64_t)next * ROWS * 32, q, h, loff, 0, b0);
-    unit(3, b1);
+    }
     __syncthreads();
     // ---- x axis inverse on the valid rows + epilogue (lane = channel: per-channel constants are per-lane scalars)
     {
@@ -284,9 +306,12 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
 #pragma unroll 1
       for (int yy = wave; yy < vy; yy += 8) {
         float bu[16];
+        const float osign = yy < 16 ? 1.f : -1.f;                    // u[y] = E[y & 15] +- O[y & 15]
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) bu[ks] = U[(yy * 32 + 2 * ks + half) * 32 + c];
-        lds_fence();
+        for (int ks = 0; ks < 16; ++ks) {
+          const int e = ((yy & 15) * 32 + 2 * ks + half) * 32 + c;
+          bu[ks] = U[e] + osign * U[16 * 32 * 32 + e];
+        }
         f32x16 acc = zero16();
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) acc = mfma(gireg[ks], bu[ks], acc);
@@ -492,15 +517,30 @@ void build_tables(std::vector<float>& tab, std::vector<int>& slots) {
     if (s == 16) return ((n & 1) ? -1.0 : 1.0) / T;
     return s < 16 ? 2.0 * cos(tp * s * n) / T : -2.0 * sin(tp * (s - 16) * n) / T;
   };
-  auto Fc = [&](int m, int k) {                      // [[C, S], [-S, C]]
-    const int a = m & 31, b = k & 31;
-    const double cs = cos(tp * ((a * b) & 31)), sn = sin(tp * ((a * b) & 31));
-    return (m < 32) == (k < 32) ? cs : (m < 32 ? sn : -sn);
+  // one radix-2 step of the 32-point complex DFT along y.  Forward (decimation in frequency): Z[2m + par] = sum_{y<16} (u[y] +- u[y+16])
+  // e^{-i th}, th = 2 pi (2m + par) y / 32, as a real product with rows (part_out, m) and K (part_in, y): [[cos, sin], [-sin, cos]].
+  // Inverse (decimation in time): E / O[y] = sum_m Z[2m + par] e^{+i th} / 32, u[y] = E + O, u[y + 16] = E - O.
+  auto F2 = [&](int par, int row, int k) {
+    const int po = row >> 4, m = row & 15, pi = k >> 4, y = k & 15;
+    const double th = tp * (((2 * m + par) * y) & 31);
+    return po == pi ? cos(th) : (po == 0 ? sin(th) : -sin(th));
+  };
+  auto FI2 = [&](int par, int row, int k) {
+    const int po = row >> 4, y = row & 15, pi = k >> 4, m = k & 15;
+    const double th = tp * (((2 * m + par) * y) & 31);
+    return (po == pi ? cos(th) : (po == 0 ? -sin(th) : sin(th))) / T;
   };
   for (int k = 0; k < 32; ++k)
-    for (int m = 0; m < 32; ++m) { tab[TAB_G + k * 32 + m] = (float)G(m, k); tab[TAB_GI + k * 32 + m] = (float)Gi(m, k); }
-  for (int k = 0; k < 64; ++k)
-    for (int m = 0; m < 64; ++m) { tab[TAB_FC + k * 64 + m] = (float)Fc(m, k); tab[TAB_FI + k * 64 + m] = (float)(Fc(k, m) / T); }
+    for (int m = 0; m < 32; ++m) {
+      tab[TAB_G + k * 32 + m] = (float)G(m, k); tab[TAB_GI + k * 32 + m] = (float)Gi(m, k);
+      for (int par = 0; par < 2; ++par) {
+        tab[TAB_F2 + par * 1024 + k * 32 + m] = (float)F2(par, m, k);
+        tab[TAB_FI2 + par * 1024 + k * 32 + m] = (float)FI2(par, m, k);
+      }
+      // real columns of the inverse: row (par, y < 16) gathers the half-complex entries k whose frequency has parity par
+      const int fk = k <= 16 ? k : k - 16;
+      tab[TAB_GI2 + k * 32 + m] = (fk & 1) == (m >> 4) ? (float)Gi(m & 15, k) : 0.f;
+    }
   slots.clear();
   for (int b = 0; b < 2; ++b) {
     const int base = b ? 32 : 0;
