@@ -7,9 +7,9 @@
 //                           zero-padded filter is read through the scalar cache (uniform addresses -> s_load, the FMAs take the weight
 //                           as their SGPR operand), and the fused epilogue stores 16 bytes per lane.  Exact fp32 FMA chain in both math
 //                           modes.  Also the data gradient (flipped / transposed filter).
-//   conv_small_wgrad_kernel lane = pixel, wave = a group of filter taps whose Cin x Cout partial sums stay in registers while the
-//                           workgroup streams its tiles; one cross-lane reduction per workgroup at the very end, partials summed in a
-//                           fixed order (deterministic).  x and dz are each read once from HBM.
+//   conv_small_wgrad_kernel the one place where the matrix cores do pay: K = pixels is long, so v_mfma_f32_16x16x4_f32 tiles (M = ci, N = co) run at
+//                           full rate whatever the channel counts; wave = one filter row, operands straight from the staged NHWC tile,
+//                           partials summed in a fixed order (deterministic).  x and dz are each read once from HBM.
 #include "pcnn_internal.h"
 #include "conv_epilogue.h"
 
@@ -33,10 +33,10 @@ struct SmallParams {
 };
 
 // stages the (STH + K - 1) x (STW + K - 1) halo tile of image n as [pixel][CI (stride CIS)] floats, padding applied
-template <int K, int CI>
+template <int K, int CI, int CIS = lds_stride(CI)>
 __device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float* __restrict__ xin, int H, int W, int Cin, int ldx, int y0, int x0, int pt, int pl,
                                            int pad_mode, float pad_value, int vec) {
-  constexpr int TR = STH + K - 1, TC = STW + K - 1, Q = CI / 4, CIS = lds_stride(CI);
+  constexpr int TR = STH + K - 1, TC = STW + K - 1, Q = CI / 4;
   for (int u = threadIdx.x; u < TR * TC * Q; u += blockDim.x) {
     const int q = u % Q, pix = u / Q, r = pix / TC, c = pix - r * TC;
     const int sy = pcnn_pad_index(y0 + r - pt, H, pad_mode), sx = pcnn_pad_index(x0 + c - pl, W, pad_mode);
@@ -184,126 +184,174 @@ bool dispatch_ci(pcnn_handle h, const SmallParams& p, int64_t nblk, int CI, int 
   return false;
 }
 
-// ---------------------------------------------------------------------------------------------------------------- weight gradient (3x3)
+// ---------------------------------------------------------------------------------------------------------------- weight gradient (3x3, 5x5)
 struct SmallWgradParams {
   const float* x; const float* dz; float* part;
   int N, H, W, Cin, ldx, Ho, Wo, Cout, lddz, pt, pl, pad_mode; float pad_value;
   int tiles_x, tiles_y, ntiles, S, vec_in, vec_dz;
 };
 
-// Workgroup = 3 waves; wave w of tap-group block yi owns taps (3 yi + w) TPW ... + TPW - 1 (< 9).  The ny workgroups that sweep the same
-// tiles for different taps are decoded from blockIdx.x so that they sit on one XCD, adjacent in dispatch order: x and dz then come from
-// HBM once and from that XCD's L2 for the siblings.
-template <int CI, int CO, int TPW>
-__global__ __launch_bounds__(192) void conv_small_wgrad_kernel(SmallWgradParams p) {
-  constexpr int K = 3, TC = STW + K - 1, CIS = lds_stride(CI), COS = lds_stride(CO);
+// dw[tap][ci][co] = sum over pixels of x[pixel + tap][ci] dz[pixel][co] on the matrix cores: v_mfma_f32_16x16x4_f32 with M = ci, N = co and
+// K = four consecutive pixels of a tile row (exact fp32 products and accumulation, the arithmetic class of every other convolution kernel
+// here).  One workgroup = K waves, wave i owns filter row i (its K tap accumulators are 4 registers each) and walks the staged tile:
+// per K step one dz operand and K input operands, each ONE ds_read_b32 (lane = (pixel l / 16, channel l % 16) is exactly the NHWC order).
+// Workgroups are persistent over tiles (tile += S); partial sums go to part[split][tap][ci][co] and are reduced in a fixed order.
+template <int K, int CI, int CO>
+__global__ __launch_bounds__(64 * K) void conv_small_wgrad_kernel(SmallWgradParams p) {
+  constexpr int TR = STH + K - 1, TC = STW + K - 1, CIS = CI, COS = CO;      // unpadded: the operand reads are 4-byte, 16 consecutive channels per pixel
+  constexpr int NT = 64 * K, QX = CI / 4, QZ = CO / 4, NX = (TR * TC * QX + NT - 1) / NT, NZ = (STH * STW * QZ + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;
-  float* zs = lds + (STH + K - 1) * TC * CIS;
-  const int tid = threadIdx.x, lane = tid & 63;
+  float* zs = lds + TR * TC * CIS + 16;                     // + slack: lanes of channels >= CI read (and discard) up to 15 floats past a pixel
+  const int tid = threadIdx.x, lane = tid & 63, ch = lane & 15, kk = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int NY = (9 + 3 * TPW - 1) / (3 * TPW);
-  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3, yi = qq % NY, split = (qq / NY) * 8 + xcd;
-  if (split >= p.S) return;
-  const int tap0 = (yi * 3 + wave) * TPW;
-  float acc[TPW][CI][CO];
+  const int split = blockIdx.x;
+  // <= 8 (<= 4) input channels: two (four) taps of the filter row share one MFMA - rows 16 / GP * js + ci of the A tile hold tap g GP + js
+  constexpr int GP = CI <= 4 ? 4 : (CI <= 8 ? 2 : 1), CPT = 16 / GP, NM = (K + GP - 1) / GP;
+  const int js = ch / CPT, cc = ch % CPT;
+  f32x4 acc[NM];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int a = 0; a < CI; ++a)
-#pragma unroll
-      for (int b = 0; b < CO; ++b) acc[t][a][b] = 0.f;
-  for (int tile = split; tile < p.ntiles; tile += p.S) {
+  for (int g = 0; g < NM; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool b_ok = ch < CO;
+  // this thread's staging items: NX 16-byte pieces of the input halo tile, NZ of the dz tile (tile-independent coordinates)
+  f32x4 xr[NX], zr[NZ];
+  auto fetch = [&](int tile) {                              // global -> registers; the loads stay in flight under the previous tile's MFMAs
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
     const int ty = tt % p.tiles_y;
     const int n = tt / p.tiles_y;
     const int y0 = ty * STH, x0 = tx * STW;
-    __syncthreads();
-    stage_tile<K, CI>(xs, p.x + (int64_t)n * p.H * p.W * p.ldx, p.H, p.W, p.Cin, p.ldx, y0, x0, p.pt, p.pl, p.pad_mode, p.pad_value, p.vec_in);
-    {   // dz tile (zero outside the image)
-      const float* zin = p.dz + (int64_t)n * p.Ho * p.Wo * p.lddz;
-      constexpr int Q = CO / 4;
-      for (int u = tid; u < STH * STW * Q; u += 192) {
-        const int q = u % Q, pix = u / Q, r = pix / STW, c = pix - r * STW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (y0 + r < p.Ho && x0 + c < p.Wo) {
-          const float* src = zin + ((int64_t)(y0 + r) * p.Wo + x0 + c) * p.lddz + 4 * q;
-          if (p.vec_dz && 4 * q + 3 < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
+    const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
+    const float* zin = p.dz + (int64_t)n * p.Ho * p.Wo * p.lddz;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int u = tid + i * NT, q = u % QX, pix = u / QX, r = pix / TC, c = pix - r * TC;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (u < TR * TC * QX) {
+        const int sy = pcnn_pad_index(y0 + r - p.pt, p.H, p.pad_mode), sx = pcnn_pad_index(x0 + c - p.pl, p.W, p.pad_mode);
+        if (sy < 0 || sx < 0) v = (f32x4){p.pad_value, p.pad_value, p.pad_value, p.pad_value};
+        else {
+          const float* src = xin + ((int64_t)sy * p.W + sx) * p.ldx + 4 * q;
+          if (p.vec_in && 4 * q + 3 < p.Cin) v = *reinterpret_cast<const f32x4*>(src);
           else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = 4 * q + j < p.Cout ? src[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = 4 * q + j < p.Cin ? src[j] : 0.f;
           }
         }
-        *reinterpret_cast<f32x4*>(zs + pix * COS + 4 * q) = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * q + j >= p.Cin) v[j] = 0.f;               // channels beyond Cin (also under constant padding): zero
       }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      const int u = tid + i * NT, q = u % QZ, pix = u / QZ, r = pix / STW, c = pix - r * STW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (u < STH * STW * QZ && y0 + r < p.Ho && x0 + c < p.Wo) {               // zero outside the image
+        const float* src = zin + ((int64_t)(y0 + r) * p.Wo + x0 + c) * p.lddz + 4 * q;
+        if (p.vec_dz && 4 * q + 3 < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = 4 * q + j < p.Cout ? src[j] : 0.f;
+        }
+      }
+      zr[i] = v;
+    }
+  };
+  int tile = split;
+  if (tile < p.ntiles) fetch(tile);
+  for (; tile < p.ntiles; tile += p.S) {
+    __syncthreads();                                        // the previous tile's operands are no longer read
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int u = tid + i * NT;
+      if (u < TR * TC * QX) *reinterpret_cast<f32x4*>(xs + (u / QX) * CIS + 4 * (u % QX)) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      const int u = tid + i * NT;
+      if (u < STH * STW * QZ) *reinterpret_cast<f32x4*>(zs + (u / QZ) * COS + 4 * (u % QZ)) = zr[i];
     }
     __syncthreads();
-    if (tap0 < 9) {
+    if (tile + p.S < p.ntiles) fetch(tile + p.S);
 #pragma unroll 1
-      for (int b = 0; b < 4; ++b) {                      // 4 batches of 64 pixels: lane = pixel
-        const int pix = b * 64 + lane, r = pix >> 5, c = pix & 31;
-        float zv[CO];
+    for (int r = 0; r < STH; ++r) {
+      const float* zrow = zs + (r * STW + kk) * COS + ch;
+      const float* xrow = xs + ((r + wave) * TC + kk + js) * CIS + cc;
 #pragma unroll
-        for (int q = 0; q < CO / 4; ++q) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(zs + pix * COS + 4 * q);
-          zv[4 * q] = v[0]; zv[4 * q + 1] = v[1]; zv[4 * q + 2] = v[2]; zv[4 * q + 3] = v[3];
-        }
+      for (int c0 = 0; c0 < STW; c0 += 4) {
+        float bv = zrow[c0 * COS];
+        bv = b_ok ? bv : 0.f;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          const int tap = tap0 + t;
-          if (tap < 9) {
-            const int i = tap / 3, j = tap - 3 * i;
-            const float* px = xs + ((r + i) * TC + (c + j)) * CIS;
-#pragma unroll
-            for (int q = 0; q < CI / 4; ++q) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(px + 4 * q);
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int o = 0; o < CO; ++o) acc[t][4 * q + jj][o] = fmaf(v[jj], zv[o], acc[t][4 * q + jj][o]);
-            }
-          }
+        for (int g = 0; g < NM; ++g) {
+          float av = xrow[(c0 + g * GP) * CIS];
+          av = (cc < CI && g * GP + js < K) ? av : 0.f;
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[g], 0, 0, 0);
         }
       }
     }
   }
-  // ---- one reduction over the 64 lanes per accumulator, then partial[split][tap][ci][co]
-  if (tap0 < 9) {
+  // accumulator register r of lane l: row (= ci) 4 (l / 16) + r, column (= co) l % 16
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int tap = tap0 + t;
+  for (int g = 0; g < NM; ++g)
 #pragma unroll
-      for (int a = 0; a < CI; ++a)
-#pragma unroll
-        for (int b = 0; b < CO; ++b) {
-          float v = acc[t][a][b];
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-          if (lane == 0 && tap < 9 && a < p.Cin && b < p.Cout) p.part[(((int64_t)split * 9 + tap) * p.Cin + a) * p.Cout + b] = v;
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * kk + r, j = g * GP + row / CPT, ci = row % CPT;
+      if (j < K && ci < p.Cin && ch < p.Cout) p.part[(((int64_t)split * K * K + wave * K + j) * p.Cin + ci) * p.Cout + ch] = acc[g][r];
     }
+}
+
+// dw[e] = sum over splits, sixteen interleaved partial sums per element combined in a fixed order
+__global__ __launch_bounds__(256) void small_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nel, int S) {
+  __shared__ float red[16][16];
+  const int el = threadIdx.x & 15, q = threadIdx.x >> 4, e = blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (e < nel)
+    for (int k = q; k < S; k += 16) s += part[(int64_t)k * nel + e];
+  red[q][el] = s;
+  __syncthreads();
+  if (q == 0 && e < nel) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][el];
+    dw[e] = t;
   }
 }
 
-__global__ void small_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nel, int S) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nel) return;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += part[(int64_t)k * nel + e];
-  dw[e] = s;
-}
+size_t wgrad_lds_bytes(int K, int CI, int CO) { return ((size_t)(STH + K - 1) * (STW + K - 1) * CI + 16 + (size_t)STH * STW * CO + 16) * sizeof(float); }
 
+// one persistent workgroup per slot the chip can hold at once (LDS-limited, at most 8 per CU): every workgroup is resident from the start
+// and walks the same number of tiles (+-1)
 int wgrad_splits(const pcnn_conv_desc* d) {
   const int64_t ntiles = (int64_t)d->N * pcnn_cdiv(d->Ho, STH) * pcnn_cdiv(d->Wo, STW);
-  return (int)std::min<int64_t>(ntiles, 1024);
+  const int per_cu = (int)std::min<size_t>(8, (160u << 10) / wgrad_lds_bytes(d->kh, (d->Cin + 3) & ~3, (d->Cout + 3) & ~3));
+  return (int)std::min<int64_t>(ntiles, 256 * per_cu);
 }
 
-template <int CI, int CO, int TPW>
+template <int K, int CI, int CO>
 void launch_small_wgrad(pcnn_handle h, const SmallWgradParams& p) {
-  constexpr size_t lds = ((size_t)(STH + 2) * (STW + 2) * lds_stride(CI) + (size_t)STH * STW * lds_stride(CO)) * sizeof(float);
-  constexpr int NY = (9 + 3 * TPW - 1) / (3 * TPW);        // workgroups per split: 3 tap groups (waves) each
-  hipLaunchKernelGGL((conv_small_wgrad_kernel<CI, CO, TPW>), dim3((unsigned)(8 * pcnn_cdiv(p.S, 8) * NY)), dim3(192), lds, h->stream, p);
+  hipLaunchKernelGGL((conv_small_wgrad_kernel<K, CI, CO>), dim3((unsigned)p.S), dim3(64 * K), wgrad_lds_bytes(K, CI, CO), h->stream, p);
+}
+template <int K, int CI>
+bool wgrad_dispatch_co(pcnn_handle h, const SmallWgradParams& p, int CO) {
+  switch (CO) {
+    case 4: launch_small_wgrad<K, CI, 4>(h, p); return true;
+    case 8: launch_small_wgrad<K, CI, 8>(h, p); return true;
+    case 12: launch_small_wgrad<K, CI, 12>(h, p); return true;
+    case 16: launch_small_wgrad<K, CI, 16>(h, p); return true;
+  }
+  return false;
+}
+template <int K>
+bool wgrad_dispatch_ci(pcnn_handle h, const SmallWgradParams& p, int CI, int CO) {
+  switch (CI) {
+    case 4: return wgrad_dispatch_co<K, 4>(h, p, CO);
+    case 8: return wgrad_dispatch_co<K, 8>(h, p, CO);
+    case 12: return wgrad_dispatch_co<K, 12>(h, p, CO);
+    case 16: return wgrad_dispatch_co<K, 16>(h, p, CO);
+  }
+  return false;
 }
 
 }  // namespace
@@ -319,11 +367,11 @@ bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d) {
 
 bool pcnn_conv_small_wgrad_eligible(const pcnn_conv_desc* d) {
   static const int on = getenv("PCNN_SMALL_CONV") ? atoi(getenv("PCNN_SMALL_CONV")) : 1;
-  return on && d->kh == 3 && d->kw == 3 && d->Cin <= 16 && d->Cout <= 16 && pad4(d->Cin) * pad4(d->Cout) <= 192;
+  return on && d->kh == d->kw && (d->kh == 3 || d->kh == 5) && d->Cin <= 16 && d->Cout <= 16;
 }
 
 size_t pcnn_conv_small_wgrad_workspace(const pcnn_conv_desc* d) {
-  return pcnn_conv_small_wgrad_eligible(d) ? (size_t)wgrad_splits(d) * 9 * d->Cin * d->Cout * sizeof(float) : 0;
+  return pcnn_conv_small_wgrad_eligible(d) ? (size_t)wgrad_splits(d) * d->kh * d->kw * d->Cin * d->Cout * sizeof(float) : 0;
 }
 
 int pcnn_conv_small_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
@@ -365,14 +413,11 @@ int pcnn_conv_small_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x
   p.tiles_x = pcnn_cdiv(d->Wo, STW); p.tiles_y = pcnn_cdiv(d->Ho, STH); p.ntiles = d->N * p.tiles_x * p.tiles_y; p.S = wgrad_splits(d);
   p.vec_in = (d->ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   p.vec_dz = (d->ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
-#define PCNN_SW(A, B, T) if (CI == A && CO == B) launch_small_wgrad<A, B, T>(h, p); else
-  PCNN_SW(4, 4, 3) PCNN_SW(4, 8, 3) PCNN_SW(8, 4, 3) PCNN_SW(8, 8, 3) PCNN_SW(4, 12, 3) PCNN_SW(12, 4, 3) PCNN_SW(4, 16, 3) PCNN_SW(16, 4, 3)
-  PCNN_SW(8, 12, 2) PCNN_SW(12, 8, 2) PCNN_SW(8, 16, 1) PCNN_SW(16, 8, 1) PCNN_SW(12, 12, 1) PCNN_SW(12, 16, 1) PCNN_SW(16, 12, 1)
-  { PCNN_FAIL(h, "pcnn_conv2d_wgrad(small): no kernel for %d->%d", d->Cin, d->Cout); }
-#undef PCNN_SW
+  const bool ok = d->kh == 3 ? wgrad_dispatch_ci<3>(h, p, CI, CO) : wgrad_dispatch_ci<5>(h, p, CI, CO);
+  PCNN_REQUIRE(h, ok, "pcnn_conv2d_wgrad(small): no kernel for %d->%d", d->Cin, d->Cout);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(small)");
-  const int nel = 9 * d->Cin * d->Cout;
-  hipLaunchKernelGGL(small_wgrad_reduce_kernel, dim3(pcnn_cdiv(nel, 256)), dim3(256), 0, h->stream, p.part, dw, nel, p.S);
+  const int nel = d->kh * d->kw * d->Cin * d->Cout;
+  hipLaunchKernelGGL(small_wgrad_reduce_kernel, dim3(pcnn_cdiv(nel, 16)), dim3(256), 0, h->stream, p.part, dw, nel, p.S);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(small reduce)");
   return 0;
 }

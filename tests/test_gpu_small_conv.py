@@ -110,3 +110,22 @@ def test_small_route_beats_the_mfma_route_at_full_size():
     ref = torch.nn.functional.conv2d(x[:1, :64, :64].permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1)
     assert float((y[:1, 1:63, 1:63].permute(0, 3, 1, 2).double() - ref[:, :, 1:63, 1:63]).norm() / ref[:, :, 1:63, 1:63].norm()) < 2e-6
     assert gbs > 2400          # >= 30 % of the 8 TB/s peak on any device of the pool (the MFMA route: ~10 %)
+
+
+@pytest.mark.parametrize('k,Cin,Cout', [(3, 12, 8), (5, 16, 16), (5, 7, 3)])
+def test_weight_gradient_with_more_tiles_than_workgroups(k, Cin, Cout):
+    """The MFMA weight-gradient kernel is persistent (tile += splits): 1250 tiles over at most 768 workgroups, channel-sliced operands."""
+    import torch.nn.functional as F
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(k + Cin)
+    N, H, W = 2, 200, 800
+    xb = torch.randn(N, H, W, Cin + 4, device='cuda', generator=g)
+    zb = torch.randn(N, H, W, Cout + 1, device='cuda', generator=g)
+    x, dz = xb[..., 4:], zb[..., :Cout]
+    p = k // 2
+    dw = ops.conv2d_wgrad(x, dz, (k, k, Cin, Cout), pad_top=p, pad_left=p)
+    xt = x.permute(0, 3, 1, 2).double().cpu()
+    wt = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xt, wt, padding=p) * dz.permute(0, 3, 1, 2).double().cpu()).sum().backward()
+    ref = wt.grad.permute(2, 3, 1, 0).numpy()
+    assert rel(dw.cpu().numpy(), ref) < 5e-6
