@@ -24,7 +24,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
 bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad);
 int pcnn_conv_small_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                         const float* bn_shift, const float* residual, float* y, float* act_out);              // conv_small.hip
-bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d);
+bool pcnn_conv_fwd_takes_narrow_route(pcnn_handle h, const pcnn_conv_desc* d);                            // spectral_conv.hip
 
 namespace {
 
@@ -236,7 +236,7 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
     PCNN_REQUIRE(h, d->pad_top <= lim_y && pb <= lim_y && d->pad_left <= lim_x && pr <= lim_x,
                  "pcnn_conv2d_fwd: padding exceeds what tf.pad allows for a %dx%d image", d->H, d->W);
   }
-  if (pcnn_conv_small_fwd_eligible(d)) return pcnn_conv_small_fwd(h, d, x, w, bias, bn_scale, bn_shift, residual, y, act_out);
+  if (pcnn_conv_fwd_takes_narrow_route(h, d)) return pcnn_conv_small_fwd(h, d, x, w, bias, bn_scale, bn_shift, residual, y, act_out);
   if (pcnn_spectral_eligible(h, d, false)) return pcnn_spectral_conv_fwd(h, d, x, w, bias, bn_scale, bn_shift, residual, y, act_out);
   if (h->math_mode == PCNN_MATH_SPLIT_F16) {
     const int rc = pcnn_conv2d_fwd_split(h, d, x, w, bias, bn_scale, bn_shift, residual, y, act_out);

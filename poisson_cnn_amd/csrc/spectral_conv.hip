@@ -28,6 +28,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
 int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw);
 bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad);
 bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d);   // conv_small.hip
+bool pcnn_conv_fwd_takes_narrow_route(pcnn_handle h, const pcnn_conv_desc* d);
 
 namespace {
 
@@ -59,6 +60,8 @@ struct FwdParams {
   int Vy, Vx, oy, ox, pad_mode; float pad_value;
   int ylim, xlim;        // the window holds values only in its first ylim x xlim entries (gradient / input tiles of the backward pass)
   int ext_y, ext_x;      // ... and only where the tile grid coordinate (ty Vy + r, tx Vx + c) lies inside ext_y x ext_x
+  int pack, cpt, tgx;    // layers of <= 16 channels: `pack` x-adjacent tiles share the 32 lanes (lane = cpt * tile + channel, cpt = 32 / pack);
+                         // tgx = tile groups per tile row; an "item" is then a tile GROUP and tile0 / ntile count groups
 };
 
 // one (tile, channel group) work item as the loader sees it: a wave-uniform image base plus 32-bit per-lane offsets (so the loads take
@@ -75,23 +78,26 @@ struct FwdItem {
 __device__ __forceinline__ void fwd_item(const FwdParams& p, int item, int half, int c, FwdItem& it) {
   const int g = item % p.groups;
   int t = p.tile0 + item / p.groups;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int txg = t % p.tgx; t /= p.tgx;
   const int ty = t % p.tiles_y;
   const int n = t / p.tiles_y;
-  const int chan = g * p.cstride + c;
-  it.cok = c < p.cvalid && chan < p.C;
+  const int sub = p.pack > 1 ? c / p.cpt : 0, cc = c - sub * p.cpt;            // this lane's tile of the group, and its channel
+  const int tx = txg * p.pack + sub;
+  const int chan = g * p.cstride + cc;
+  it.cok = cc < p.cvalid && chan < p.C && tx < p.tiles_x;
   it.img = p.x + (int64_t)n * p.H * p.W * p.ld;
   it.wy0 = ty * p.Vy - p.oy;
   const int wx0 = tx * p.Vx - p.ox;
   it.ylim = min(p.ylim, p.ext_y - ty * p.Vy);
-  it.xlim = min(p.xlim, p.ext_x - tx * p.Vx);
+  it.xlim = min(p.xlim, p.ext_x - txg * p.pack * p.Vx);                       // uniform bound (the group's first tile); per lane: zmask
+  const int xlim_lane = min(p.xlim, p.ext_x - tx * p.Vx);
   it.cmask = 0u; it.zmask = 0u;
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) {
     const int xc = 2 * xs + half;
     const int sx = pcnn_pad_index(wx0 + xc, p.W, p.pad_mode);
     if (sx < 0) it.cmask |= 1u << xs;
-    if (xc >= it.xlim) it.zmask |= 1u << xs;
+    if (xc >= xlim_lane) it.zmask |= 1u << xs;
     it.off[xs] = (unsigned)((sx < 0 ? 0 : sx) * p.ld + (it.cok ? chan : 0));
   }
 }
@@ -213,6 +219,7 @@ struct InvParams {
   int Ho, Wo, C, ldy, ld_res, ld_act, groups, cstride, cvalid, act; float alpha;
   int tiles_x, tiles_y, tile0, ntile, Vy, Vx;
   int flip;              // store output pixel (y, x) at (Ho-1-y, Wo-1-x): the input-partitioned weight gradient comes out tap-reversed
+  int pack, cpt, tgx;    // tile packing, as in FwdParams (flip requires pack == 1)
 };
 
 // unit u of wave (q, h): complex column fx = 1 + q + 4u, input frequencies fy of parity h (K = (part, m), fy = 2 m + h), or - q == 3, u == 3 -
@@ -294,13 +301,15 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
     {
       const int g = item % p.groups;
       int t = p.tile0 + item / p.groups;
-      const int tx = t % p.tiles_x; t /= p.tiles_x;
+      const int txg = t % p.tgx; t /= p.tgx;
       const int ty = t % p.tiles_y;
       const int n = t / p.tiles_y;
-      const int y0 = ty * p.Vy, x0 = tx * p.Vx;
-      const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0);
-      const int chan = g * p.cstride + c;
-      const bool cok = c < p.cvalid && chan < p.C;
+      const int sub = p.pack > 1 ? c / p.cpt : 0, cc = c - sub * p.cpt;      // this lane's tile of the group, and its channel
+      const int subx = sub * p.Vx;                                            // ... and that tile's x offset from the group's first tile
+      const int y0 = ty * p.Vy, x0 = txg * p.pack * p.Vx;
+      const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0 - subx);
+      const int chan = g * p.cstride + cc;
+      const bool cok = cc < p.cvalid && chan < p.C;
       const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
       const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
 #pragma unroll 1
@@ -331,10 +340,11 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
             if (xx < vx) {
               float v = acc[r] + bias;
               v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
-              if (arow) arow[(int)(xsgn * xx * p.ld_act) + (int)chv] = v;
+              const int xo = xsgn * xx + subx;
+              if (arow) arow[(int)(xo * p.ld_act) + (int)chv] = v;
               v = v * sc + sh;
-              if (rrow) v += rrow[(int)(xsgn * xx * p.ld_res) + (int)chv];
-              yrow[(int)(xsgn * xx * p.ldy) + (int)chv] = v;
+              if (rrow) v += rrow[(int)(xo * p.ld_res) + (int)chv];
+              yrow[(int)(xo * p.ldy) + (int)chv] = v;
               ymax = fmaxf(ymax, fabsf(v));
             }
           }
@@ -421,15 +431,18 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
 
 // M_f from the filter spectrum Wsp[ci * gout + go][row][co % 32] (conj: correlation).
 // M[slot][go][gi][k = 32 part_in + ci % 32][n = 32 part_out + co % 32]
-__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout) {
+// cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and M_f is block diagonal - a tile's channels mix only among themselves.
+__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout, int cpt) {
   const int64_t total = (int64_t)NSLOT * gout * gin * 64 * 64;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int nn = i & 63; int64_t r = i >> 6; const int k = r & 63; r >>= 6; const int gi = r % gin; r /= gin; const int go = r % gout; const int slot = r / gout;
-    const int pin = k >> 5, cil = k & 31, pout = nn >> 5, co = nn & 31;
+    const int pin = k >> 5, pout = nn >> 5;
+    const int cil = (k & 31) % cpt, co = (nn & 31) % cpt;
+    const bool same_tile = (k & 31) / cpt == (nn & 31) / cpt;
     const int ci = gi * 32 + cil;
     const int4 sl = slots[slot];
     float v = 0.f;
-    if (ci < Cin) {
+    if (ci < Cin && same_tile) {
       const float* wg = wsp + ((int64_t)(ci * gout + go) * ROWS) * 32 + co;
       const float wr = wg[sl.x * 32], wi = wg[sl.y * 32];
       if (sl.z == 1) v = (pin == 0 && pout == 0) ? wr : ((pin == 1 && pout == 1) ? wi : 0.f);     // two real frequencies packed in one slot
@@ -487,18 +500,20 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
 
 // C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
 // Output: spectrum of a one-tile image with Cin*Cout channels, group = ci, lane = co.
-__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin, float isign) {
+// cpt < 32 (tile packing): the wanted products are the 32 / cpt diagonal blocks (tile with itself); they are summed here.
+__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin, float isign, int cpt) {
   const int64_t total = (int64_t)NSLOT * gin * 1024;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = i & 1023; int64_t r = i >> 10; const int gi = r % gin; const int slot = r / gin;
     const int cil = e >> 5, co = e & 31, ci = gi * 32 + cil;
-    if (ci >= Cin) continue;
+    if (ci >= Cin || cil >= cpt || co >= cpt) continue;
     float P[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) {
-      const float* b = part + (((int64_t)s * NSLOT + slot) * gin + gi) * 4 * 1024 + e;
+    for (int s = 0; s < S; ++s)
+      for (int sub = 0; sub < 32 / cpt; ++sub) {
+        const float* b = part + (((int64_t)s * NSLOT + slot) * gin + gi) * 4 * 1024 + (sub * cpt + cil) * 32 + sub * cpt + co;
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) P[qd] += b[qd * 1024];
-    }
+        for (int qd = 0; qd < 4; ++qd) P[qd] += b[qd * 1024];
+      }
     const int4 sl = slots[slot];
     // P[0] = Xr^T Dr, P[1] = Xi^T Dr, P[2] = Xr^T Di, P[3] = Xi^T Di
     const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : isign * (P[1] - P[2]);     // isign = -1: conj(X^) D^ instead of X^ conj(D^)
@@ -629,6 +644,14 @@ void launch_inv(pcnn_handle h, InvParams p, int ntile) {
   }
 }
 
+// tiles per lane group for a layer of Cin -> Cout channels: both sides must fit `cpt` lanes (a power of two >= 4)
+int pack_for(int Cin, int Cout) {
+  static const int on = getenv("PCNN_SPEC_PACK") ? atoi(getenv("PCNN_SPEC_PACK")) : 1;
+  const int c = std::max(Cin, Cout);
+  if (!on || c > 16) return 1;
+  return c <= 4 ? 8 : (c <= 8 ? 4 : 2);
+}
+
 }  // namespace
 
 // Route choice.  Both estimates are calibrated on MI355X measurements at 8 x 1024^2 (tools/probe_spectral.py, profiles/r02_probe_spectral.txt):
@@ -643,9 +666,14 @@ bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad) 
   // decided on ONE image, so that a sample's arithmetic never depends on its batch neighbours (the model's per-sample results are
   // bit-identical for any batch size); images of fewer than 4 tiles stay on the direct route (launch overheads dominate there)
   const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
-  const double tiles = (double)((d->Ho + Vy - 1) / Vy) * ((d->Wo + Vx - 1) / Vx);
+  const int pack = pack_for(d->Cin, d->Cout);
+  const double tiles = (double)((d->Ho + Vy - 1) / Vy) * (((d->Wo + Vx - 1) / Vx + pack - 1) / pack);        // tile groups
   if (tiles < 4) return false;
-  const double t_spec = tiles * ((d->Cin > 32 || d->Cout > 32) ? 0.33e-6 : 0.21e-6);
+  const double t_spec = tiles * ((d->Cin > 32 || d->Cout > 32) ? 0.33e-6 : 0.19e-6);
+  if (!wgrad && pcnn_conv_small_fwd_eligible(d)) {         // the alternative is the vector-ALU narrow kernel: ~17 T multiply-adds/s on its padded channels
+    const double fma = (double)d->Ho * d->Wo * d->kh * d->kw * ((d->Cin + 3) & ~3) * ((d->Cout + 3) & ~3);
+    return t_spec < 0.8 * fma / 17e12;
+  }
   const int cin8 = (d->Cin + 7) & ~7, co32 = (d->Cout + 31) & ~31;
   const double flop = 2.0 * d->Ho * d->Wo * d->kh * d->kw * cin8 * co32;
   const bool split = h->math_mode == PCNN_MATH_SPLIT_F16;
@@ -653,11 +681,18 @@ bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad) 
   return t_spec < 0.9 * flop / rate;
 }
 
+// forward / data-gradient route of a layer the narrow kernels could also take: they keep every 3x3 layer; a 5x5 layer goes spectral when
+// that is the faster of the two
+bool pcnn_conv_fwd_takes_narrow_route(pcnn_handle h, const pcnn_conv_desc* d) {
+  return pcnn_conv_small_fwd_eligible(d) && !(d->kh == 5 && pcnn_spectral_eligible(h, d, false));
+}
+
 int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                            const float* bn_shift, const float* residual, float* y, float* act_out) {
   const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
   const int tiles_y = pcnn_cdiv(d->Ho, Vy), tiles_x = pcnn_cdiv(d->Wo, Vx);
-  const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
+  const int pack = pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
+  const int64_t ntile = (int64_t)d->N * tiles_y * tgx;                       // tile groups (= tiles when pack == 1)
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gin = pcnn_cdiv(d->Cin, 32), gout = pcnn_cdiv(d->Cout, 32);
   const int chunk = (int)std::min<int64_t>(chunk_tiles() / (gin > gout ? gin : gout), ntile);
@@ -669,18 +704,23 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   fw.cstride = gout > 1 ? 32 : d->Cout; fw.cvalid = gout > 1 ? 32 : d->Cout;     // group ci * gout + go holds output channels 32 go .. 32 go + 31
   fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
   fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
+  fw.pack = 1; fw.cpt = 32; fw.tgx = 1;
   launch_fwd(h, fw, 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, ws.wsp, ws.slots, ws.M, d->Cin, gin, gout);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, ws.wsp, ws.slots, ws.M, d->Cin, gin, gout, cpt);
   PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
   FwdParams fx;
   fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
   fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
   fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
+  fx.pack = pack; fx.cpt = cpt; fx.tgx = tgx;
+  if (pack > 1) { fx.cstride = cpt; fx.cvalid = cpt; }
   InvParams iv;
   iv.sp = ws.ys; iv.tab = ws.tab; iv.y = y; iv.bias = bias; iv.bn_scale = bn_scale; iv.bn_shift = bn_shift; iv.res = residual; iv.act_out = act_out;
   iv.absmax = reinterpret_cast<unsigned*>(h->y_absmax);
   iv.Ho = d->Ho; iv.Wo = d->Wo; iv.C = d->Cout; iv.ldy = d->ldy; iv.ld_res = d->ld_res; iv.ld_act = d->ld_act_out; iv.groups = gout; iv.cstride = 32; iv.cvalid = 32;
   iv.act = d->act; iv.alpha = d->act_alpha; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx; iv.flip = 0;
+  iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
+  if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
   MixParams mx;
   mx.xs = ws.xs; mx.ys = ws.ys; mx.M = ws.M; mx.slots = ws.slots; mx.gin = gin; mx.gout = gout;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
@@ -700,7 +740,8 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
 int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw) {
   const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
   const int tiles_y = pcnn_cdiv(d->Ho, Vy), tiles_x = pcnn_cdiv(d->Wo, Vx);
-  const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
+  const int pack = pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
+  const int64_t ntile = (int64_t)d->N * tiles_y * tgx;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gin = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();
   const int chunk = (int)std::min<int64_t>(chunk_tiles() / gin, ntile);
@@ -710,6 +751,8 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
   fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
   fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
   fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
+  fx.pack = pack; fx.cpt = cpt; fx.tgx = tgx;
+  if (pack > 1) { fx.cstride = cpt; fx.cvalid = cpt; }
   FwdParams fz = fx;                                    // dz: the tile's own Vy x Vx outputs, zero elsewhere in the window
   fz.x = dz; fz.sp = ws.ys; fz.H = d->Ho; fz.W = d->Wo; fz.C = d->Cout; fz.ld = d->ldy; fz.groups = 1; fz.oy = 0; fz.ox = 0;
   fz.pad_mode = PCNN_PAD_CONSTANT; fz.pad_value = 0.f; fz.ylim = Vy; fz.xlim = Vx;
@@ -722,12 +765,12 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
     launch_fwd(h, fz, nt);
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S / 4, gin), dim3(256), 0, h->stream, wm);
   }
-  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, ws.part, ws.slots, ws.csp, S, gin, d->Cin, 1.0f);
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, ws.part, ws.slots, ws.csp, S, gin, d->Cin, 1.0f, cpt);
   InvParams iv;
   iv.sp = ws.csp; iv.tab = ws.tab; iv.y = dw; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = nullptr; iv.act_out = nullptr;
   iv.absmax = nullptr; iv.Ho = d->kh; iv.Wo = d->kw; iv.C = d->Cin * d->Cout; iv.ldy = d->Cin * d->Cout; iv.ld_res = 0; iv.ld_act = 0;
   iv.groups = d->Cin; iv.cstride = d->Cout; iv.cvalid = d->Cout; iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f;
-  iv.tiles_x = 1; iv.tiles_y = 1; iv.tile0 = 0; iv.Vy = T; iv.Vx = T; iv.flip = 0;
+  iv.tiles_x = 1; iv.tiles_y = 1; iv.tile0 = 0; iv.Vy = T; iv.Vx = T; iv.flip = 0; iv.pack = 1; iv.cpt = 32; iv.tgx = 1;
   launch_inv(h, iv, 1);
   PCNN_CHECK_LAUNCH(h, "spectral weight gradient");
   return 0;
@@ -743,7 +786,7 @@ extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_
   if (!h || !d || !dg) return 0;
   if (d->Cout > 32 || d->Cin > 64) return 0;
   if (d->pad_mode == PCNN_PAD_CONSTANT && d->pad_value != 0.f) return 0;
-  if (pcnn_conv_small_fwd_eligible(dg)) return 0;
+  if (pcnn_conv_fwd_takes_narrow_route(h, dg)) return 0;
   return pcnn_spectral_eligible(h, dg, false) && pcnn_spectral_eligible(h, d, true) ? 1 : 0;
 }
 
@@ -754,7 +797,8 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   PCNN_REQUIRE(h, dg->Cin == d->Cout && dg->Cout == d->Cin && dg->kh == d->kh && dg->kw == d->kw && dg->N == d->N, "pcnn_conv2d_bwd_spectral: descriptors do not match");
   const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
   const int tiles_y = pcnn_cdiv(dg->Ho, Vy), tiles_x = pcnn_cdiv(dg->Wo, Vx);
-  const int64_t ntile = (int64_t)d->N * tiles_y * tiles_x;
+  const int pack = pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
+  const int64_t ntile = (int64_t)d->N * tiles_y * tgx;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gz = 1, gx = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();       // channel groups of dz (<= 32 channels) and of x / dx
   const int chunk = (int)std::min<int64_t>(chunk_tiles() / gx, ntile);
@@ -777,14 +821,17 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   fw.cstride = gx > 1 ? 32 : dg->Cout; fw.cvalid = gx > 1 ? 32 : dg->Cout;
   fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
   fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
+  fw.pack = 1; fw.cpt = 32; fw.tgx = 1;
   PCNN_REQUIRE(h, gx == 1 || dg->Cout == 64, "pcnn_conv2d_bwd_spectral: %d input channels unsupported (<= 32 or 64)", d->Cin);
   launch_fwd(h, fw, 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, ws.slots, Mm, dg->Cin, gz, gx);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, ws.slots, Mm, dg->Cin, gz, gx, cpt);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral (filter spectrum)");
   FwdParams fz;                                          // dz windows with halo: the data gradient's input transform
   fz.x = dz; fz.sp = zs; fz.tab = ws.tab; fz.H = dg->H; fz.W = dg->W; fz.C = dg->Cin; fz.ld = dg->ldx; fz.groups = gz; fz.cstride = 32; fz.cvalid = 32;
   fz.tiles_x = tiles_x; fz.tiles_y = tiles_y; fz.Vy = Vy; fz.Vx = Vx; fz.oy = dg->pad_top; fz.ox = dg->pad_left; fz.pad_mode = dg->pad_mode;
   fz.pad_value = dg->pad_value; fz.ylim = T; fz.xlim = T; fz.ext_y = 1 << 30; fz.ext_x = 1 << 30;
+  fz.pack = pack; fz.cpt = cpt; fz.tgx = tgx;
+  if (pack > 1) { fz.cstride = cpt; fz.cvalid = cpt; }
   FwdParams fxm = fz;                                    // x tiles: own Vy x Vx values (boundary-condition padded where the grid is the padded domain)
   const bool padded_domain = d->pad_mode != PCNN_PAD_CONSTANT;
   fxm.x = x; fxm.sp = xs; fxm.H = d->H; fxm.W = d->W; fxm.C = d->Cin; fxm.ld = d->ldx; fxm.groups = gx;
@@ -794,6 +841,8 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   iv.sp = ys; iv.tab = ws.tab; iv.y = dx; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = residual; iv.act_out = nullptr; iv.absmax = nullptr;
   iv.Ho = dg->Ho; iv.Wo = dg->Wo; iv.C = dg->Cout; iv.ldy = dg->ldy; iv.ld_res = dg->ld_res; iv.ld_act = 0; iv.groups = gx; iv.cstride = 32; iv.cvalid = 32;
   iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx; iv.flip = 0;
+  iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
+  if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
   MixParams mx;
   mx.xs = zs; mx.ys = ys; mx.M = Mm; mx.slots = ws.slots; mx.gin = gz; mx.gout = gx;
   WMixParams wm;
@@ -810,12 +859,12 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S / 4, gx), dim3(256), 0, h->stream, wm);
   }
   float* csp = wsp;                                      // the filter spectrum is no longer needed
-  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, ws.slots, csp, S, gx, d->Cin, -1.0f);
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, ws.slots, csp, S, gx, d->Cin, -1.0f, cpt);
   InvParams iw;
   iw.sp = csp; iw.tab = ws.tab; iw.y = dw; iw.bias = nullptr; iw.bn_scale = nullptr; iw.bn_shift = nullptr; iw.res = nullptr; iw.act_out = nullptr;
   iw.absmax = nullptr; iw.Ho = d->kh; iw.Wo = d->kw; iw.C = d->Cin * d->Cout; iw.ldy = d->Cin * d->Cout; iw.ld_res = 0; iw.ld_act = 0;
   iw.groups = d->Cin; iw.cstride = d->Cout; iw.cvalid = d->Cout; iw.act = PCNN_ACT_LINEAR; iw.alpha = 0.f;
-  iw.tiles_x = 1; iw.tiles_y = 1; iw.tile0 = 0; iw.Vy = T; iw.Vx = T; iw.flip = 1;
+  iw.tiles_x = 1; iw.tiles_y = 1; iw.tile0 = 0; iw.Vy = T; iw.Vx = T; iw.flip = 1; iw.pack = 1; iw.cpt = 32; iw.tgx = 1;
   launch_inv(h, iw, 1);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral");
   return 0;

@@ -48,7 +48,9 @@ def test_backward_cases():
         t.test_conv_backward_matches_autograd(*case)
 
 
-@pytest.mark.parametrize('k,Cin,Cout,H,W', [(15, 32, 32, 120, 101), (13, 28, 28, 75, 140), (7, 64, 32, 90, 90), (5, 20, 16, 64, 64)])
+@pytest.mark.parametrize('k,Cin,Cout,H,W', [(15, 32, 32, 120, 101), (13, 28, 28, 75, 140), (7, 64, 32, 90, 90), (5, 20, 16, 64, 64),
+                                         # <= 16 channels: 2 / 4 / 8 x-adjacent tiles share the 32 lanes (ragged last groups included)
+                                         (15, 3, 4, 100, 171), (13, 4, 16, 75, 140), (7, 16, 16, 90, 95), (7, 8, 5, 64, 230), (9, 2, 7, 40, 33)])
 def test_many_tiles_forward_and_weight_gradient(k, Cin, Cout, H, W):
     """Several tiles per image in both directions (interior tiles, overhanging last tiles, N > 1) against torch-CPU fp64."""
     import torch.nn.functional as F
@@ -90,7 +92,7 @@ def test_adjoint_identities_at_full_size():
 
 
 @pytest.mark.parametrize('k,Cin,Cout,mode', [(15, 32, 32, 'CONSTANT'), (13, 28, 28, 'CONSTANT'), (7, 64, 32, 'CONSTANT'), (11, 16, 32, 'SYMMETRIC'), (9, 24, 20, 'REFLECT'),
-                                             (6, 20, 16, 'SYMMETRIC')])
+                                             (6, 20, 16, 'SYMMETRIC'), (15, 3, 4, 'SYMMETRIC'), (7, 16, 12, 'CONSTANT'), (9, 8, 8, 'REFLECT'), (13, 4, 16, 'CONSTANT')])
 def test_fused_backward_shares_the_gradient_spectrum(k, Cin, Cout, mode):
     """pcnn_conv2d_bwd_spectral: data gradient and (input-partitioned, tap-reversed) weight gradient from ONE transform of dz, against
     autograd of the fp64 twin - all padding modes (the padded-domain form for SYMMETRIC / REFLECT), even and odd filters, 64 input channels,
