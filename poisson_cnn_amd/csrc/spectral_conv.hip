@@ -37,6 +37,14 @@ constexpr int T = 32, ROWS = 1024, NSLOT = 512;
 // transforms of one radix-2 step of the 32-point complex DFT (see build_tables); GI2 the real-column inverse split into its two parities
 constexpr int TAB_G = 0, TAB_GI = 1024, TAB_F2 = 2048, TAB_FI2 = 4096, TAB_GI2 = 6144, TAB_FLOATS = 7168;
 constexpr size_t LDS_U = (size_t)T * T * 32 * sizeof(float);   // 128 KB
+// Spectrum storage: items (tile x channel group) in blocks of SPB, rows outermost inside a block (row r of the block's SPB items is one
+// contiguous SPB x 128 B run).  SPB = 1 is the plain item-major layout.  Measured at 8 x 1024^2, 15x15, 32 -> 32 (8192-tile launches):
+// SPB = 32 makes the per-frequency kernels stream whole DRAM pages but gains them nothing (mix 0.59 -> 0.61 ms, wmix 0.56 -> 0.58 ms)
+// and costs the inverse transform its sequential rows (0.45 -> 0.52 ms) - the page pattern is not what bounds them.
+constexpr int SPB = 1, RS = SPB * 32;
+                          // items per block, floats between consecutive rows of an item
+__host__ __device__ __forceinline__ int64_t sp_item(int64_t item) { return (item / SPB) * ((int64_t)ROWS * RS) + (item % SPB) * 32; }
+__host__ __device__ __forceinline__ size_t sp_bytes(size_t items) { return ((items + SPB - 1) / SPB) * SPB * (size_t)ROWS * 32 * sizeof(float); }
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 zero16() {
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
     }
     __syncthreads();
     // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = parity of the output frequencies fy it produces.
-    float* out = p.sp + (int64_t)item * ROWS * 32;
+    float* out = p.sp + sp_item(item);
 #pragma unroll 1
     for (int fx = 1 + q; fx <= 15; fx += 4) {
       float bu[16];
@@ -184,11 +192,11 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
       f32x16 acc = zero16();
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) acc = mfma(freg[ks], bu[ks], acc);
-      float* o = out + (64 + 64 * (fx - 1) + h) * 32;                // accumulator row 16 part + m  ->  spectrum row 32 part + 2 m + h
+      float* o = out + (64 + 64 * (fx - 1) + h) * RS;                // accumulator row 16 part + m  ->  spectrum row 32 part + 2 m + h
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, half);
-        o[(unsigned)((32 * (row >> 4) + 2 * (row & 15)) * 32 + c)] = acc[r];
+        o[(unsigned)((32 * (row >> 4) + 2 * (row & 15)) * RS + c)] = acc[r];
       }
     }
     if (q == 3) {                                                        // the two real columns: fx = 0 (wave 6), fx = 16 (wave 7)
@@ -202,9 +210,9 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
         if (!MASKED || 2 * ks < ylim) acc = mfma(greg[ks], bu[ks], acc);
-      float* o = out + (h ? 32 : 0) * 32;
+      float* o = out + (h ? 32 : 0) * RS;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * 32 + c)] = acc[r];
+      for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * RS + c)] = acc[r];
     }
     if (next >= total) break;
     item = next;
@@ -223,17 +231,17 @@ struct InvParams {
 };
 
 // unit u of wave (q, h): complex column fx = 1 + q + 4u, input frequencies fy of parity h (K = (part, m), fy = 2 m + h), or - q == 3, u == 3 -
-// the real column 0 / 16 (all 32 half-complex entries).  `in` is the item's uniform base, `loff` = 32 half + c the lane's offset.
+// the real column 0 / 16 (all 32 half-complex entries).  `in` is the item's uniform base, `loff` = RS half + c the lane's offset.
 __device__ __forceinline__ void inv_load_unit(const float* in, int q, int h, unsigned loff, int u, float (&b)[16]) {
   const bool realcol = q == 3 && u == 3;
   if (realcol) {
-    const float* src = in + (h ? 32 : 0) * 32;
+    const float* src = in + (h ? 32 : 0) * RS;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) b[ks] = src[loff + 64u * ks];                                   // row 2 ks + half
+    for (int ks = 0; ks < 16; ++ks) b[ks] = src[loff + (unsigned)(2 * RS) * ks];                    // row 2 ks + half
   } else {
-    const float* src = in + (64 + 64 * (q + 4 * u) + h) * 32;
+    const float* src = in + (64 + 64 * (q + 4 * u) + h) * RS;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) b[ks] = src[2u * loff - (loff & 31u) + 32u * (32 * (ks >> 3) + 4 * (ks & 7))];   // row 32 part + 2 (2 (ks & 7) + half) + h
+    for (int ks = 0; ks < 16; ++ks) b[ks] = src[2u * loff - (loff & 31u) + (unsigned)RS * (32 * (ks >> 3) + 4 * (ks & 7))];   // row 32 part + 2 (2 (ks & 7) + half) + h
   }
 }
 
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = wave & 1, q = wave >> 1;
-  const unsigned loff = 32u * half + c;
+  const unsigned loff = (unsigned)RS * half + c;
   const int total = p.ntile * p.groups;
   int item = blockIdx.x;
   if (item >= total) return;
@@ -262,14 +270,14 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   float* const Uh = U + h * (16 * 32 * 32);
   float b[4][16];
   {
-    const float* in = p.sp + (int64_t)item * ROWS * 32;
+    const float* in = p.sp + sp_item(item);
 #pragma unroll
     for (int u = 0; u < 4; ++u) inv_load_unit(in, q, h, loff, u, b[u]);
   }
   float ymax = 0.f;
   for (;;) {
     const int next = item + gridDim.x;
-    const float* nin = p.sp + (int64_t)next * ROWS * 32;
+    const float* nin = p.sp + sp_item(next);
     // ---- y axis inverse: complex columns -> E / O [y][fx] (real part) and [y][16 + fx] (imaginary part); real columns -> [y][0], [y][16]
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -370,6 +378,7 @@ struct MixParams { const float* xs; float* ys; const float* M; const int4* slots
 
 // K order inside one 64-row block of M_f (one input channel group): step ks = 16 p + j pairs channel j (lanes 0-31) with channel 16 + j
 // (lanes 32-63) of part p (0: real row, 1: imaginary row) - so a lane's A operands are 16 CONSECUTIVE channels of its tile's row.
+// (3 workgroups per CU - 168 VGPRs - was measured: 7 % slower; the kernel is bound by the HBM read + write stream, not by latency)
 template <int GIN>
 __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
@@ -389,11 +398,11 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   const int mstride = gridDim.y * 4;
   auto load_a = [&](int mt, int gi, f32x4 (&a)[2][4]) {
     const int tile = min(mt * 32 + c, p.ntile - 1);
-    const float* base = p.xs + ((int64_t)tile * GIN + gi) * ROWS * 32 + 16 * half;
+    const float* base = p.xs + sp_item((int64_t)tile * GIN + gi) + 16 * half;
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
-      a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * 32 + 4 * j4);
-      a[1][j4] = *reinterpret_cast<const f32x4*>(base + ri * 32 + 4 * j4);
+      a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * RS + 4 * j4);
+      a[1][j4] = *reinterpret_cast<const f32x4*>(base + ri * RS + 4 * j4);
     }
   };
   f32x4 a[2][4], an[2][4];
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int trow = mt * 32 + acc_row(r, half);
-        if (trow < p.ntile) p.ys[(((int64_t)trow * p.gout + go) * ROWS + row) * 32 + c] = acc[nt][r];
+        if (trow < p.ntile) p.ys[sp_item((int64_t)trow * p.gout + go) + row * RS + c] = acc[nt][r];
       }
     }
   }
@@ -443,8 +452,8 @@ __global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4*
     const int4 sl = slots[slot];
     float v = 0.f;
     if (ci < Cin && same_tile) {
-      const float* wg = wsp + ((int64_t)(ci * gout + go) * ROWS) * 32 + co;
-      const float wr = wg[sl.x * 32], wi = wg[sl.y * 32];
+      const float* wg = wsp + sp_item(ci * gout + go) + co;
+      const float wr = wg[sl.x * RS], wi = wg[sl.y * RS];
       if (sl.z == 1) v = (pin == 0 && pout == 0) ? wr : ((pin == 1 && pout == 1) ? wi : 0.f);     // two real frequencies packed in one slot
       else v = pin == pout ? wr : (pin == 0 ? -wi : wi);                                          // [[Hr, Hi], [-Hi, Hr]], H = conj(W)
     }
@@ -466,9 +475,8 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
   const int4 sl = p.slots[slot];
   const int per = (((p.ntile + nparts - 1) / nparts) + 1) & ~1;
   const int t0 = part * per, t1 = min(t0 + per, p.ntile);
-  const float* xr = p.xs + ((int64_t)gi * ROWS + sl.x) * 32, *xi = p.xs + ((int64_t)gi * ROWS + sl.y) * 32;
-  const float* dr = p.ds + (int64_t)sl.x * 32, *di = p.ds + (int64_t)sl.y * 32;
-  const unsigned xstride = (unsigned)p.gin * ROWS * 32, dstride = (unsigned)ROWS * 32;
+  const float* xr = p.xs + sl.x * RS, *xi = p.xs + sl.y * RS;
+  const float* dr = p.ds + sl.x * RS, *di = p.ds + sl.y * RS;
   f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
   for (int tb = t0; tb < t1; tb += 8) {
     float ar[4], ai[4], br[4], bi[4];
@@ -476,7 +484,8 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
     for (int u = 0; u < 4; ++u) {
       const int tt = tb + 2 * u + half;
       const unsigned tc = (unsigned)(tt < t1 ? tt : t0);
-      ar[u] = xr[tc * xstride + c]; ai[u] = xi[tc * xstride + c]; br[u] = dr[tc * dstride + c]; bi[u] = di[tc * dstride + c];
+      const unsigned ix = (unsigned)sp_item((int64_t)tc * p.gin + gi) + c, id = (unsigned)sp_item(tc) + c;
+      ar[u] = xr[ix]; ai[u] = xi[ix]; br[u] = dr[id]; bi[u] = di[id];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -517,8 +526,8 @@ __global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4*
     const int4 sl = slots[slot];
     // P[0] = Xr^T Dr, P[1] = Xi^T Dr, P[2] = Xr^T Di, P[3] = Xi^T Di
     const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : isign * (P[1] - P[2]);     // isign = -1: conj(X^) D^ instead of X^ conj(D^)
-    csp[((int64_t)ci * ROWS + sl.x) * 32 + co] = cr;
-    csp[((int64_t)ci * ROWS + sl.y) * 32 + co] = cim;
+    csp[sp_item(ci) + sl.x * RS + co] = cr;
+    csp[sp_item(ci) + sl.y * RS + co] = cim;
   }
 }
 
@@ -597,8 +606,8 @@ int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, in
   ws.tab = reinterpret_cast<float*>(b + o_tab);
   ws.slots = reinterpret_cast<int4*>(b + o_slots);
   char* r = b + o_rest;
-  const size_t wsp_b = align256((size_t)cin * gout * ROWS * 32 * 4), M_b = align256((size_t)NSLOT * gin * gout * 64 * 64 * 4);
-  const size_t xs_b = align256((size_t)chunk * gin * ROWS * 32 * 4), ys_b = align256((size_t)chunk * gout * ROWS * 32 * 4);
+  const size_t wsp_b = align256(sp_bytes((size_t)cin * gout)), M_b = align256((size_t)NSLOT * gin * gout * 64 * 64 * 4);
+  const size_t xs_b = align256(sp_bytes((size_t)chunk * gin)), ys_b = align256(sp_bytes((size_t)chunk * gout));
   ws.wsp = reinterpret_cast<float*>(r); r += wsp_b;                        // filter spectrum (forward) / C^ (weight gradient)
   ws.M = reinterpret_cast<float*>(r); r += M_b;
   ws.xs = reinterpret_cast<float*>(r); r += xs_b;
@@ -609,8 +618,8 @@ int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, in
 }
 
 size_t workspace_bytes(int gin, int gout, int cin, int chunk, bool wgrad) {
-  size_t b = align256((size_t)cin * gout * ROWS * 32 * 4) + align256((size_t)NSLOT * gin * gout * 64 * 64 * 4) +
-             align256((size_t)chunk * gin * ROWS * 32 * 4) + align256((size_t)chunk * gout * ROWS * 32 * 4);
+  size_t b = align256(sp_bytes((size_t)cin * gout)) + align256((size_t)NSLOT * gin * gout * 64 * 64 * 4) +
+             align256(sp_bytes((size_t)chunk * gin)) + align256(sp_bytes((size_t)chunk * gout));
   if (wgrad) b += align256((size_t)wgrad_splits() * NSLOT * gin * 4 * 1024 * 4);
   return b;
 }
@@ -728,7 +737,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
     fx.tile0 = (int)t0; iv.tile0 = (int)t0; mx.ntile = nt;
     launch_fwd(h, fx, nt);
     const int nMt = pcnn_cdiv(nt, 32);
-    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 4));
+    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
     if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy, gout), dim3(256), 0, h->stream, mx);
     else hipLaunchKernelGGL(spec_mix_kernel<2>, dim3(NSLOT, gy, gout), dim3(256), 0, h->stream, mx);
     launch_inv(h, iv, nt);
@@ -803,8 +812,8 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   const int gz = 1, gx = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();       // channel groups of dz (<= 32 channels) and of x / dx
   const int chunk = (int)std::min<int64_t>(chunk_tiles() / gx, ntile);
   // workspace: [filter spectrum | M | dz spectra (gz) | dx spectra (gx) | x-tile spectra (gx) | partial sums]; C^ reuses the filter-spectrum slot
-  const size_t wsp_b = align256((size_t)std::max(dg->Cin * gx, d->Cin) * ROWS * 32 * 4), M_b = align256((size_t)NSLOT * gz * gx * 64 * 64 * 4);
-  const size_t zs_b = align256((size_t)chunk * gz * ROWS * 32 * 4), ys_b = align256((size_t)chunk * gx * ROWS * 32 * 4);
+  const size_t wsp_b = align256(sp_bytes((size_t)std::max(dg->Cin * gx, d->Cin))), M_b = align256((size_t)NSLOT * gz * gx * 64 * 64 * 4);
+  const size_t zs_b = align256(sp_bytes((size_t)chunk * gz)), ys_b = align256(sp_bytes((size_t)chunk * gx));
   const size_t part_b = align256((size_t)S * NSLOT * gx * 4 * 1024 * 4);
   Workspace ws;
   if (int rc = ensure_workspace(h, wsp_b + M_b + zs_b + 2 * ys_b + part_b + 4096, ws, 1, 1, 1, 1)) return rc;
@@ -852,7 +861,7 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
     fz.tile0 = (int)t0; fxm.tile0 = (int)t0; iv.tile0 = (int)t0; mx.ntile = nt; wm.ntile = nt; wm.accumulate = t0 > 0;
     launch_fwd(h, fz, nt);
     const int nMt = pcnn_cdiv(nt, 32);
-    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 4));
+    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
     hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy, gx), dim3(256), 0, h->stream, mx);
     launch_inv(h, iv, nt);
     launch_fwd(h, fxm, nt);
