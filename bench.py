@@ -294,7 +294,7 @@ def run(args):
             return {'achieved': f / s_ / 1e12 if s_ else None, 'frac': f / s_ / 1e12 / peak if s_ else None, 'launches': c, 'avg_launch_ms': 1e3 * s_ / c if c else None}
         return {'bound': 'mfma',
                 'kernel': 'all convolution launches of the timed steps (forward, data gradient, weight gradient): fp32-MFMA implicit GEMM (%s), tiled spectral '
-                          'route (spec_fwd / spec_mix / spec_inv / spec_wmix: DFT as fp32 MFMA GEMM) for the wide filters, vector-ALU kernels for <= 16 channels'
+                          'route (spec_fwd / spec_mix / spec_inv / spec_wmix: DFT as fp32 MFMA GEMM) for the wide filters (tile-packed below 17 channels), vector-ALU forward and 16x16x4-MFMA weight-gradient kernels for the 3x3 layers of <= 16 channels'
                           % ('conv_fwd_kernel / wgrad_kernel' if mode == 'fp32' else 'conv_fwd_split_kernel / wgrad_split_kernel'),
                 'achieved': af / as_ / 1e12 if as_ else None, 'peak': peak, 'unit': 'TFLOP/s (ALGORITHMIC direct-convolution fp32 FLOP, 2 N Ho Wo kh kw Cin Cout per launch)',
                 'frac': af / as_ / 1e12 / peak if as_ else None,

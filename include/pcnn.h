@@ -41,6 +41,18 @@ int pcnn_version(void);
  * (train/utils.py:10-29 loads them; poisson_cnn_amd/tf_checkpoint.py reads and writes the format).  Host only. */
 uint32_t pcnn_crc32c(const void* data, size_t n, uint32_t crc);
 
+/* Data-parallel collective: what tf.distribute.MirroredStrategy does under `with dist_strategy.scope()`
+ * (train/hpnn_legacy_train.py:37) - ONE sum all-reduce of the flat gradient bucket per optimizer step - over RCCL / xGMI, on the handle's
+ * stream.  RCCL is loaded at the first call (dlopen); rendezvous is the caller's: rank 0 obtains the 128-byte id and ships it to the
+ * other ranks over whatever channel the host program has, then every rank (one process per GPU, one handle) calls pcnn_comm_init.
+ * pcnn_allreduce / pcnn_broadcast are in place, asynchronous, fp32. */
+#define PCNN_UNIQUE_ID_BYTES 128
+int pcnn_comm_unique_id(pcnn_handle h, void* id_out);
+int pcnn_comm_init(pcnn_handle h, const void* id, int rank, int world_size);
+int pcnn_comm_destroy(pcnn_handle h);
+int pcnn_allreduce(pcnn_handle h, float* buf, size_t count);
+int pcnn_broadcast(pcnn_handle h, float* buf, size_t count, int root);
+
 /* Arithmetic of the convolution GEMMs.
  *   PCNN_MATH_FP32      (default): v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulate.
  *   PCNN_MATH_SPLIT_F16 : every fp32 operand is split into two fp16 halves (hi + lo, 22 significant bits, per-tile power-of-two

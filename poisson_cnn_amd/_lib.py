@@ -68,10 +68,11 @@ class Handle:
         rc = self.lib.pcnn_create(int(device), c_void_p(stream), byref(self._h))
         if rc != 0:
             raise RuntimeError('pcnn_create(device=%d) failed with code %d' % (device, rc))
-        self.device = device
+        self.device, self.stream_ptr = device, int(stream or 0)
 
     def set_stream(self, stream):
         self.check(self.lib.pcnn_set_stream(self._h, c_void_p(stream)), 'pcnn_set_stream')
+        self.stream_ptr = int(stream or 0)
 
     def check(self, rc, what):
         if rc != 0:

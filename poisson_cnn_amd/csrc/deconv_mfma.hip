@@ -45,13 +45,16 @@ __global__ void pack_deconv_bwd_kernel(const float* __restrict__ k, float* __res
 // ---------------------------------------------------------------- forward
 __global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
-  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);               // wave -> (n, yc, x tile)
-  const int total = p.N * p.hc * p.tiles_x;
+  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);               // wave -> (n, yc, x tile, filter row ty): one fine output row per wave, so
+  const int total = p.N * p.hc * p.tiles_x * p.f;               // that a 16x up-sampling of a 64^2 grid still fills the chip (16 384 waves)
   if (wid >= total) return;
+  const int ty = wid % p.f; wid /= p.f;
   const int tx0 = wid % p.tiles_x; wid /= p.tiles_x;
   const int yc = wid % p.hc, n = wid / p.hc;
   const int x0 = tx0 * 32;
   const int ng = (p.Cin + 7) >> 3;
+  const int Y = yc * p.f + ty - p.py;
+  if (Y < 0 || Y >= p.H) return;
   // A fragments: this lane's coarse pixel, 4 channels per 8-channel group (lane half selects which 4)
   f32x4 a[4];
   const int xc_l = x0 + col;
@@ -66,9 +69,7 @@ __global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
   }
   const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
   const f32x4* wl = reinterpret_cast<const f32x4*>(p.wp) + half * 32 + col;
-  for (int ty = 0; ty < p.f; ++ty) {
-    const int Y = yc * p.f + ty - p.py;
-    if (Y < 0 || Y >= p.H) continue;
+  {
     for (int tx = 0; tx < p.f; ++tx) {
       const int tap = ty * p.f + tx;
       f32x16 acc;
@@ -215,7 +216,7 @@ int pcnn_deconv_fwd_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, i
   p.N = N; p.hc = hc; p.wc = wc; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.f = f; p.py = (hc * f - H) / 2; p.px = (wc * f - W) / 2;
   p.x = x; p.ldx = ldx; p.wp = static_cast<const float*>(h->scratch); p.bias = bias; p.alpha = alpha; p.beta = beta; p.y = y; p.ldy = ldy;
   p.tiles_x = pcnn_cdiv(wc, 32);
-  const int64_t waves = (int64_t)N * hc * p.tiles_x;
+  const int64_t waves = (int64_t)N * hc * p.tiles_x * f;
   hipLaunchKernelGGL(deconv_fwd_mfma_kernel, dim3((unsigned)pcnn_cdiv64(waves, 4)), dim3(256), 0, h->stream, p);
   PCNN_CHECK_LAUNCH(h, "pcnn_deconv_fwd(mfma)");
   return 0;

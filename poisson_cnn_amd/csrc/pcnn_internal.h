@@ -17,7 +17,11 @@ struct pcnn_handle_s {
   void* spec_ws = nullptr;        // spectral-convolution workspace (tables, filter spectrum, tile spectra; grown on demand, owned by the handle)
   size_t spec_ws_bytes = 0;
   int spectral_mode = -1;         // PCNN_SPECTRAL_AUTO (cost model) / _OFF / _FORCE, see pcnn_set_spectral_mode
+  void* comm = nullptr;           // RCCL communicator (ncclComm_t) of pcnn_comm_init, see collective.hip
+  int comm_rank = 0, comm_size = 0;
 };
+
+void pcnn_comm_release(pcnn_handle_s* h);   // collective.hip
 
 #define PCNN_FAIL(h, ...)                                   \
   do {                                                      \

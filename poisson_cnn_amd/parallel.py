@@ -28,7 +28,10 @@ class DataParallel:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             dist.init_process_group(backend=backend, rank=rank, world_size=ws)
-        return cls(rank, ws, lr, backend)
+        self = cls(rank, ws, lr, backend)
+        if os.environ.get('PCNN_COLLECTIVE') == 'c_abi' and torch.cuda.is_available():
+            self.enable_c_abi_collective()
+        return self
 
     def local_batch(self, global_batch):
         """Even split by sample; the reference requires the same (H,W) on all replicas per step, and so do we."""
@@ -42,9 +45,39 @@ class DataParallel:
         return t[self.rank * n:(self.rank + 1) * n]
 
     def all_reduce_sum(self, flat):
-        if self.world_size > 1:
+        if getattr(self, '_c_abi', None) is not None:
+            import ctypes
+            h = self._c_abi
+            if torch.cuda.current_stream().cuda_stream != h.stream_ptr:
+                raise RuntimeError('the C-ABI collective was initialised on another stream than the one the gradients are produced on')
+            if flat.dtype != torch.float32 or not flat.is_contiguous():
+                raise ValueError('pcnn_allreduce takes a contiguous fp32 buffer')
+            h.call('pcnn_allreduce', ctypes.c_void_p(flat.data_ptr()), ctypes.c_size_t(flat.numel()))
+        elif self.world_size > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         return flat
+
+    def enable_c_abi_collective(self):
+        """Route the gradient all-reduce through the library's own entry point (pcnn_allreduce: RCCL bound inside libpcnn, issued on the
+        handle's stream) instead of torch.distributed - the path a non-torch host program uses.  torch.distributed, if
+        initialised, only ships the 128-byte rendezvous id from rank 0.  Also selected by PCNN_COLLECTIVE=c_abi in from_env()."""
+        import ctypes
+        from . import ops
+        h = ops.handle()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            h.call('pcnn_comm_unique_id', buf)
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if self.world_size > 1:
+            dev = 'cuda' if self.backend == 'nccl' else 'cpu'
+            ident = ident.to(dev)
+            dist.broadcast(ident, src=0)
+            ident = ident.cpu()
+        raw = (ctypes.c_ubyte * 128)(*ident.tolist())
+        h.call('pcnn_comm_init', raw, ctypes.c_int(self.rank), ctypes.c_int(self.world_size))
+        self._c_abi = h
+        return self
 
     def broadcast(self, flat, src=0):
         if self.world_size > 1:
@@ -71,6 +104,8 @@ class DataParallel:
 
     def collective_name(self):
         """The collective actually in use, for reports: backend "nccl" is RCCL on ROCm."""
+        if getattr(self, '_c_abi', None) is not None:
+            return 'RCCL all-reduce (pcnn_allreduce, C-ABI)'
         if self.world_size == 1:
             return 'none (single rank)'
         return {'nccl': 'RCCL all-reduce', 'gloo': 'gloo all-reduce (CPU)'}.get(self.backend, '%s all-reduce' % self.backend)

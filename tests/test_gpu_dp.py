@@ -127,3 +127,43 @@ def test_bench_two_ranks_bare_invocation_on_gpu():
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
     assert 'gloo' in out['config']['collective'] and out['dtype'] == 'f32'
     assert out['split_f16']['value'] > 0 and out['split_f16']['accuracy_vs_fp32']['forward_output']['rel_l2'] < 1e-5
+
+
+def test_c_abi_collective_single_rank():
+    """pcnn_comm_unique_id / pcnn_comm_init / pcnn_allreduce / pcnn_broadcast (RCCL bound inside libpcnn, include/pcnn.h) with world size 1:
+    RCCL loads, a communicator comes up on the handle's device, the 22.2 MB gradient bucket goes through ncclAllReduce on the handle's stream
+    and comes back unchanged; then the same through DataParallel.enable_c_abi_collective() and a model train step."""
+    import ctypes
+    from poisson_cnn_amd import ops
+    from poisson_cnn_amd.parallel import DataParallel
+    h = ops.handle()
+    probe = torch.zeros(4, device='cuda')
+    with pytest.raises(RuntimeError, match='no communicator'):
+        h.call('pcnn_allreduce', ctypes.c_void_p(probe.data_ptr()), ctypes.c_size_t(4))
+    ident = (ctypes.c_ubyte * 128)()
+    h.call('pcnn_comm_unique_id', ident)
+    assert any(ident)
+    with pytest.raises(RuntimeError, match='rank 3 outside'):
+        h.call('pcnn_comm_init', ident, ctypes.c_int(3), ctypes.c_int(2))
+    h.call('pcnn_comm_init', ident, ctypes.c_int(0), ctypes.c_int(1))
+    with pytest.raises(RuntimeError, match='already has a communicator'):
+        h.call('pcnn_comm_init', ident, ctypes.c_int(0), ctypes.c_int(1))
+    g = torch.Generator(device='cuda').manual_seed(0)
+    flat = torch.randn(5_560_000, device='cuda', generator=g)
+    ref = flat.clone()
+    h.call('pcnn_allreduce', ctypes.c_void_p(flat.data_ptr()), ctypes.c_size_t(flat.numel()))
+    h.call('pcnn_broadcast', ctypes.c_void_p(flat.data_ptr()), ctypes.c_size_t(flat.numel()), ctypes.c_int(0))
+    torch.cuda.synchronize()
+    assert torch.equal(flat, ref)
+    h.call('pcnn_comm_destroy')
+    # the same path behind the trainer's hook
+    dp = DataParallel(0, 1, 0, None).enable_c_abi_collective()
+    assert 'pcnn_allreduce' in dp.collective_name()
+    m1, m2 = _make(), dp.attach(_make())
+    rhs, dx, tgt = _batch()
+    l1 = m1.train_step(((rhs, dx), tgt))
+    l2 = m2.train_step(((rhs, dx), tgt))
+    torch.cuda.synchronize()
+    assert float(l1['loss']) == float(l2['loss'])
+    assert torch.equal(m1.store.flat_w, m2.store.flat_w)
+    h.call('pcnn_comm_destroy')
