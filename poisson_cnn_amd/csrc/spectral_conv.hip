@@ -57,6 +57,9 @@ __device__ __forceinline__ f32x16 zero16() {
 // consumes it (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, one LDS round trip exposed per MFMA); with it a unit's operands are
 // fetched as one burst and the MFMA chain then issues back to back.
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also drains vmcnt, i.e. waits for the next item's prefetch loads and the
+// spectrum stores in flight; the prefetched registers are waited for where they are consumed, global stores need no ordering here).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // accumulator register r of lane (half) <-> row of the 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
 
@@ -100,6 +103,14 @@ __device__ __forceinline__ void fwd_item(const FwdParams& p, int item, int half,
   it.xlim = min(p.xlim, p.ext_x - txg * p.pack * p.Vx);                       // uniform bound (the group's first tile); per lane: zmask
   const int xlim_lane = min(p.xlim, p.ext_x - tx * p.Vx);
   it.cmask = 0u; it.zmask = 0u;
+  if (p.pack == 1 && wx0 >= 0 && wx0 + T <= p.W) {                          // (uniform) the window lies inside the image in x: no index maps
+    const unsigned base = (unsigned)((wx0 + half) * p.ld + (it.cok ? chan : 0));
+    const int nz = min(16, max(0, (xlim_lane - half + 1) >> 1));            // columns 2 xs + half < xlim
+    it.zmask = 0xffffu & ~((1u << nz) - 1u);
+#pragma unroll
+    for (int xs = 0; xs < 16; ++xs) it.off[xs] = base + (unsigned)(2 * xs * p.ld);
+    return;
+  }
 #pragma unroll
   for (int xs = 0; xs < 16; ++xs) {
     const int xc = 2 * xs + half;
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) fwd_load_row<MASKED>(p, cur, wave + 8 * j, v[j]);
     }
-    __syncthreads();
+    lds_barrier();  
     // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = parity of the output frequencies fy it produces.
     float* out = p.sp + sp_item(item);
 #pragma unroll 1
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
     }
     if (next >= total) break;
     item = next;
-    __syncthreads();                                                     // U is free for the next item
+    lds_barrier();                                                       // U is free for the next item
   }
 }
 
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();  
     // ---- x axis inverse on the valid rows + epilogue (lane = channel: per-channel constants are per-lane scalars)
     {
       const int g = item % p.groups;
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
     }
     if (next >= total) break;
     item = next;
-    __syncthreads();                                                     // U is free for the next item
+    lds_barrier();                                                       // U is free for the next item
   }
   if (p.absmax) {
 #pragma unroll
