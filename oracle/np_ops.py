@@ -122,7 +122,7 @@ def conv2d_transpose_same(x, k, bias, out_hw, stride, act='linear'):
     assert h == -(-H // stride) and w_ == -(-W // stride), 'SAME transpose needs in = ceil(out/stride)'
     pb_y = max((h - 1) * stride + kh - H, 0) // 2
     pb_x = max((w_ - 1) * stride + kw - W, 0) // 2
-    full = np.zeros((N, Co, (h - 1) * stride + kh, (w_ - 1) * stride + kw))
+    full = np.zeros((N, Co, max((h - 1) * stride + kh, pb_y + H), max((w_ - 1) * stride + kw, pb_x + W)))   # kh < stride: rows no tap reaches stay 0
     for ty in range(kh):
         for tx in range(kw):
             contrib = np.einsum('nchw,oc->nohw', x, k[ty, tx])

@@ -87,6 +87,7 @@ def conv2d_transpose_same(x, k, bias, out_hw, stride, act='linear'):
     pb_y = max((h - 1) * stride + kh - H, 0) // 2
     pb_x = max((w_ - 1) * stride + kw - W, 0) // 2
     full = F.conv_transpose2d(x, asarray(k).permute(3, 2, 0, 1), None, stride=stride)
+    full = F.pad(full, (0, max(pb_x + W - full.shape[3], 0), 0, max(pb_y + H - full.shape[2], 0)))        # kh < stride: positions no tap reaches stay 0
     out = full[:, :, pb_y:pb_y + H, pb_x:pb_x + W]
     if bias is not None:
         out = out + asarray(bias)[None, :, None, None]

@@ -300,8 +300,8 @@ class bottleneck_block_deconvupsample(_bottleneck):
 # ----------------------------------------------------------------------------------------------------------------- layers
 class deconvupscale(_Layer):
     """layers/deconvupscale.py:8-109: tf.nn.conv2d_transpose(x, K, output_shape, strides=upsample_ratio, padding='SAME') + bias + activation;
-    kernel (k, k, filters, Cin); Keras-default (Glorot) initialiser for kernel AND bias (:37-38).  Implemented for kernel_size == upsample_ratio
-    (every reference config)."""
+    kernel (k, k, filters, Cin); Keras-default (Glorot) initialiser for kernel AND bias (:37-38).  kernel_size == upsample_ratio (every reference
+    config) runs on the dedicated per-tap MFMA kernels, any other kernel size as zero insertion + the fused pad+conv kernels (ops.deconv_*)."""
 
     def __init__(self, upsample_ratio, filters, kernel_size, data_format='channels_first', activation=None, use_bias=True, dimensions=None, device=None,
                  seed=0, **unused):
@@ -310,18 +310,16 @@ class deconvupscale(_Layer):
         k = kernel_size if np.isscalar(kernel_size) else kernel_size[0]
         if (not np.isscalar(upsample_ratio) and len(set(upsample_ratio)) != 1) or (not np.isscalar(kernel_size) and len(set(kernel_size)) != 1):
             raise NotImplementedError('anisotropic upsample_ratio / kernel_size')
-        if int(k) != int(up):
-            raise NotImplementedError('deconvupscale is implemented for kernel_size == upsample_ratio (all shipped configs)')
         if canonical_activation(activation) != 'linear':
             raise NotImplementedError('activation other than linear is not used by any reference config')
-        self.up, self.filters, self.use_bias = int(up), int(filters), use_bias
+        self.up, self.k, self.filters, self.use_bias = int(up), int(k), int(filters), use_bias
 
     def call(self, inputs, training=False):
         x, output_shape = inputs
         x = _nhwc(x, self.device)
         if not self.built:
             self._begin_build()
-            self.store.add('kernel', (self.up, self.up, self.filters, x.shape[3]), 'glorot')
+            self.store.add('kernel', (self.k, self.k, self.filters, x.shape[3]), 'glorot')
             if self.use_bias:
                 self.store.add('bias', (self.filters,), 'glorot')
             self._end_build()
@@ -337,7 +335,7 @@ class deconvupscale(_Layer):
         x, _ = self._saved
         dy = _nhwc(dy, self.device)
         g = self.store.g
-        ops.deconv_bwd_filter(x, dy, self.up, dk=g['kernel'], dbias=g['bias'] if self.use_bias else None, ws=self.ctx.ws)
+        ops.deconv_bwd_filter(x, dy, self.up, dk=g['kernel'], dbias=g['bias'] if self.use_bias else None, ws=self.ctx.ws, kernel_size=(self.k, self.k))
         return _nchw(ops.deconv_bwd_data(dy, self.store.w['kernel'], (x.shape[1], x.shape[2]), self.up))
 
 

@@ -417,12 +417,11 @@ class bottleneck_block_deconvupsample(_bottleneck_base):
 
     def __init__(self, store, ctx, name, cin, *, deconv_kernel_size, deconv_use_bias=True, **kw):
         super().__init__(store, ctx, name, cin, **kw)
-        if int(deconv_kernel_size) != self.up:
-            raise NotImplementedError('deconvupscale is implemented for kernel_size == upsample_ratio (all shipped configs)')
+        self.dk = int(deconv_kernel_size)           # != upsample ratio: ops.deconv_* compose it from zero insertion + the fused pad+conv kernels
         self.store = store
         self.ctx = ctx
         self.deconv_use_bias = deconv_use_bias
-        store.add(name + '/deconv/kernel', (self.up, self.up, self.filters, self.filters), 'glorot')
+        store.add(name + '/deconv/kernel', (self.dk, self.dk, self.filters, self.filters), 'glorot')
         if deconv_use_bias:
             store.add(name + '/deconv/bias', (self.filters,), 'glorot')
 
@@ -440,7 +439,7 @@ class bottleneck_block_deconvupsample(_bottleneck_base):
         o = self.coarse
         self.coarse = None
         ops.deconv_bwd_filter(o, dmerged, self.up, alpha=alpha, dk=g[self.name + '/deconv/kernel'],
-                              dbias=g[self.name + '/deconv/bias'] if self.deconv_use_bias else None, ws=self.ctx.ws)
+                              dbias=g[self.name + '/deconv/bias'] if self.deconv_use_bias else None, ws=self.ctx.ws, kernel_size=(self.dk, self.dk))
         dcoarse = ops.deconv_bwd_data(dmerged, k, (o.shape[1], o.shape[2]), self.up, alpha=alpha)
         self._backward_convs_and_down(dcoarse, d_in)
 

@@ -322,10 +322,34 @@ def pool2d_bwd(x, dy, f, kind='average', dx=None, accumulate=False):
     return dx
 
 
+def _deconv_same_pads(k, hc, wc, H, W, f):
+    """tf.nn.conv2d_transpose(padding='SAME') is the adjoint of the SAME forward convolution: pad_before = max((in - 1) f + k - out, 0) // 2."""
+    kh, kw = k.shape[0], k.shape[1]
+    if hc != -(-H // f) or wc != -(-W // f):
+        raise ValueError('SAME transposed convolution needs input = ceil(output / stride): got %s for output %s at stride %d' % ((hc, wc), (H, W), f))
+    return max((hc - 1) * f + kh - H, 0) // 2, max((wc - 1) * f + kw - W, 0) // 2
+
+
+def _deconv_general_fwd(x, k, bias, out_hw, f, alpha, beta, out):
+    """kernel_size != upsample_ratio (layers/deconvupscale.py:100-106 allows it; no shipped config uses it): zero insertion (the adjoint of
+    the strided sub-sampling) followed by the stride-1 correlation with the flipped / transposed kernel - the fused pad+conv kernels."""
+    N, hc, wc, Cin = x.shape
+    kh, kw, Cout, _ = k.shape
+    H, W = out_hw
+    pt, pl = _deconv_same_pads(k, hc, wc, H, W, f)
+    x_up = subsample_bwd(x, ((hc - 1) * f + 1, (wc - 1) * f + 1), f)
+    y = conv2d_fwd(x_up, flip_transpose_weights(k.contiguous()), bias, pad_top=kh - 1 - pt, pad_left=kw - 1 - pl, out_hw=(H, W))
+    if out is None:
+        return y if alpha == 1.0 else axpby(alpha, y, 0.0, y)
+    return axpby(alpha, y, beta, out)
+
+
 def deconv_fwd(x, k, bias, out_hw, f, *, alpha=1.0, beta=0.0, out=None):
     N, hc, wc, Cin = x.shape
     Cout = k.shape[2]
     H, W = out_hw
+    if k.shape[0] != f or k.shape[1] != f:
+        return _deconv_general_fwd(x, k, bias, out_hw, f, alpha, beta, out)
     y = out if out is not None else empty((N, H, W, Cout), x.device)
     # algorithmic bytes: x read once, y written once (+ read once when the branch merge accumulates in place, beta != 0), filter
     _launch('deconv_fwd', 2.0 * N * H * W * Cin * Cout,
@@ -339,15 +363,39 @@ def deconv_bwd_data(dy, k, coarse_hw, f, *, alpha=1.0, out=None):
     N, H, W, Cout = dy.shape
     Cin = k.shape[3]
     hc, wc = coarse_hw
+    if k.shape[0] != f or k.shape[1] != f:               # the SAME strided convolution of dy with k: stride-1 launch + sub-sampling
+        pt, pl = _deconv_same_pads(k, hc, wc, H, W, f)
+        full = conv2d_fwd(dy, k.contiguous(), None, pad_top=pt, pad_left=pl, out_hw=((hc - 1) * f + 1, (wc - 1) * f + 1))
+        dx_ = subsample(full, f)
+        if alpha != 1.0:
+            axpby(alpha, dx_, 0.0, dx_)
+        if out is None:
+            return dx_
+        return axpby(1.0, dx_, 0.0, out)
     dx = out if out is not None else empty((N, hc, wc, Cin), dy.device)
     handle().call('pcnn_deconv_bwd_data', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(dy), c_int(_ld(dy)),
                   _p(k), c_float(alpha), _p(dx), c_int(_ld(dx)))
     return dx
 
 
-def deconv_bwd_filter(x, dy, f, *, alpha=1.0, dk=None, dbias=None, ws=None):
+def deconv_bwd_filter(x, dy, f, *, alpha=1.0, dk=None, dbias=None, ws=None, kernel_size=None):
     N, hc, wc, Cin = x.shape
     _, H, W, Cout = dy.shape
+    if kernel_size is not None and tuple(kernel_size) != (f, f):   # weight gradient of the zero-insertion + correlation form, flipped back
+        kh, kw = kernel_size
+        pt, pl = max((hc - 1) * f + kh - H, 0) // 2, max((wc - 1) * f + kw - W, 0) // 2
+        x_up = subsample_bwd(x, ((hc - 1) * f + 1, (wc - 1) * f + 1), f)
+        dwf = conv2d_wgrad(x_up, dy, (kh, kw, Cin, Cout), pad_top=kh - 1 - pt, pad_left=kw - 1 - pl, ws=ws)
+        g = flip_transpose_weights(dwf)                              # (kh, kw, Cout, Cin)
+        if dk is None:
+            dk = g if alpha == 1.0 else axpby_flat(alpha, g, 0.0, g)
+        else:
+            axpby_flat(alpha, g, 0.0, dk)
+        if dbias is not None:
+            epilogue_bwd(dy, None, dbias=dbias, ws=ws)
+            if alpha != 1.0:
+                axpby_flat(alpha, dbias, 0.0, dbias)
+        return dk
     lib = _lib.load()
     nbytes = lib.pcnn_deconv_wgrad_workspace(c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(Cout), c_int(f))
     wsb = (ws or _default_ws).get(nbytes, x.device)

@@ -131,6 +131,55 @@ def test_deconv_fwd_bwd(H, W, f):
     assert rel(dbias.cpu().numpy(), bt.grad.numpy() * alpha) < TOL_RED
 
 
+@pytest.mark.parametrize('H,W,f,k,Ci,Co', [(40, 52, 2, 5, 8, 6), (33, 47, 3, 4, 20, 32), (48, 64, 4, 7, 32, 32), (30, 45, 3, 2, 5, 7), (26, 26, 2, 3, 4, 4)])
+def test_deconv_kernel_size_differs_from_stride(H, W, f, k, Ci, Co):
+    """layers/deconvupscale.py:100-106 with kernel_size != upsample_ratio (the reference's own self-test uses upsample_ratio 2, kernel 5, :111):
+    zero insertion + the fused pad+conv kernels, forward with the branch-merge alpha / beta, data gradient, filter and bias gradients."""
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(100 * f + k)
+    hc, wc = -(-H // f), -(-W // f)
+    x = f32(rng.standard_normal((2, Ci, hc, wc))); kk = f32(rng.standard_normal((k, k, Co, Ci)) / (k * np.sqrt(Ci))); b = f32(rng.standard_normal(Co))
+    xt, kt, bt = torch.tensor(x, requires_grad=True), torch.tensor(kk, requires_grad=True), torch.tensor(b, requires_grad=True)
+    yt = torch_twin.conv2d_transpose_same(xt, kt, bt, (H, W), f)
+    dy = f32(rng.standard_normal(yt.shape))
+    (yt * torch.tensor(dy)).sum().backward()
+    assert rel(np_ops.conv2d_transpose_same(x, kk, b, (H, W), f), yt.detach().numpy()) < 1e-12        # the two oracles agree
+    alpha = 0.25
+    base = f32(rng.standard_normal((2, H, W, Co)))
+    y = dev(base).clone()
+    ops.deconv_fwd(nhwc(x), dev(kk), dev(b), (H, W), f, alpha=alpha, beta=1.0, out=y)
+    assert rel(nchw(y), yt.detach().numpy() * alpha + base.transpose(0, 3, 1, 2)) < TOL
+    assert rel(nchw(ops.deconv_fwd(nhwc(x), dev(kk), dev(b), (H, W), f)), yt.detach().numpy()) < TOL
+    dx = ops.deconv_bwd_data(nhwc(dy), dev(kk), (hc, wc), f, alpha=alpha)
+    assert rel(nchw(dx), xt.grad.numpy() * alpha) < TOL
+    dbias = ops.empty((Co,))
+    dk = ops.deconv_bwd_filter(nhwc(x), nhwc(dy), f, alpha=alpha, dbias=dbias, kernel_size=(k, k))
+    assert rel(dk.cpu().numpy(), kt.grad.numpy() * alpha) < TOL_RED
+    assert rel(dbias.cpu().numpy(), bt.grad.numpy() * alpha) < TOL_RED
+
+
+def test_deconvupscale_layer_with_the_reference_self_test_shape():
+    """deconvupscale(upsample_ratio=2, filters=2, kernel_size=5) - the constructor call of the reference's own __main__ block
+    (layers/deconvupscale.py:111) - through the Keras-style layer: forward and gradients vs the oracle."""
+    from poisson_cnn_amd.keras_layers import deconvupscale
+    rng = np.random.default_rng(5)
+    x = f32(rng.standard_normal((3, 4, 9, 11)))
+    lyr = deconvupscale(upsample_ratio=2, filters=2, kernel_size=5, dimensions=2, seed=1)
+    shp = np.array([3, 2, 18, 21], dtype=np.int32)
+    y = lyr([dev(x), shp], training=True)
+    w = dict(zip(lyr.weight_names, lyr.get_weights()))
+    xt = torch.tensor(x, requires_grad=True)
+    kt, bt = torch.tensor(f32(w['kernel']), requires_grad=True), torch.tensor(f32(w['bias']), requires_grad=True)
+    yt = torch_twin.conv2d_transpose_same(xt, kt, bt, (18, 21), 2)
+    assert tuple(y.shape) == (3, 2, 18, 21) and rel(y.cpu().numpy(), yt.detach().numpy()) < TOL
+    dy = f32(rng.standard_normal(yt.shape))
+    (yt * torch.tensor(dy)).sum().backward()
+    dx = lyr.backward(dev(dy))
+    g = lyr.gradients
+    assert rel(dx.cpu().numpy(), xt.grad.numpy()) < TOL
+    assert rel(g['kernel'].cpu().numpy(), kt.grad.numpy()) < TOL_RED and rel(g['bias'].cpu().numpy(), bt.grad.numpy()) < TOL_RED
+
+
 @pytest.mark.parametrize('method', ['nearest', 'bilinear', 'bicubic'])
 @pytest.mark.parametrize('hc,wc,Ho,Wo', [(2, 3, 64, 70), (5, 7, 33, 41), (1, 1, 40, 36), (8, 8, 128, 128)])
 def test_resize_fwd_bwd(method, hc, wc, Ho, Wo):
