@@ -157,8 +157,16 @@ def test_deconvupscale_upsample_spp_jacobi_scaling():
     assert rel(y, ref) < TOL
     dy = f32(rng.standard_normal(ref.shape))
     check_grads(lay, w, lambda p, xx: torch_twin.conv2d_transpose_same(xx, p['kernel'], p['bias'], (27, 34), 4, 'linear'), [x], dy, lay.backward(dy))
-    with pytest.raises(NotImplementedError):
-        deconvupscale(upsample_ratio=2, filters=4, kernel_size=3)
+    # kernel_size != upsample_ratio (zero insertion + the fused pad+conv kernels)
+    lay = deconvupscale(upsample_ratio=2, filters=4, kernel_size=3)
+    out_shape = np.array([2, 4, 13, 18], dtype=np.int32)
+    lay([x, out_shape])
+    w = randomize(lay, rng)
+    y = lay([x, out_shape], training=True)
+    ref = np_ops.conv2d_transpose_same(x, w['kernel'], w['bias'], (13, 18), 2, 'linear')
+    assert rel(y, ref) < TOL
+    dy = f32(rng.standard_normal(ref.shape))
+    check_grads(lay, w, lambda p, xx: torch_twin.conv2d_transpose_same(xx, p['kernel'], p['bias'], (13, 18), 2, 'linear'), [x], dy, lay.backward(dy))
     # Upsample([x, domain_sizes, out_hw])
     for method in ('bilinear', 'bicubic', 'nearest'):
         up = Upsample(2, resize_method=method)
