@@ -249,6 +249,14 @@ int pcnn_loss_bwd(pcnn_handle h, int N, int64_t hw, const float* pred, const flo
 int pcnn_loss_coefficients(pcnn_handle h, int N, int64_t hw, const float* partials, float w_mae, float w_mse, float w_int,
                            int scale_by_peak, int global_batch_size, const float* extra, float* loss, float* c_mae, float* c_mse,
                            float* c_int, float* mse);
+/* The same three with the integral term's exponent explicit (losses/integral_loss.py:88,153 `Lp_norm_power`: sum G (target - pred)^p; the
+ * per-sample weight becomes 1 / peak^p, losses/loss_wrapper.py:68).  The entry points above are these with p = 2 (every shipped config). */
+int pcnn_loss_partials_p(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, float lp_power, float* partials);
+int pcnn_loss_bwd_p(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, const float* c_mae,
+                    const float* c_mse, const float* c_int, float lp_power, float* dpred);
+int pcnn_loss_coefficients_p(pcnn_handle h, int N, int64_t hw, const float* partials, float w_mae, float w_mse, float w_int, float lp_power,
+                             int scale_by_peak, int global_batch_size, const float* extra, float* loss, float* c_mae, float* c_mse,
+                             float* c_int, float* mse);
 /* FD-Laplacian residual loss (losses/physics_informed_loss.py:35-50): per-sample sum of (rhs - conv(pred,kern_n))^2 over
  * the interior; kern (N, s, s); bwd accumulates into dpred.  */
 int pcnn_pi_loss_partials(pcnn_handle h, int N, int H, int W, int s, const float* pred, const float* rhs, const float* kern, float* out /*N*/);

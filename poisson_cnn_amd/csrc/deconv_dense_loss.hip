@@ -168,14 +168,14 @@ __global__ void spp_max_bwd_kernel(int N, int64_t per, int nb, const int32_t* __
 // ---------------------------------------------------------------- loss
 // one workgroup per sample: out[n] = {sum|p-t|, sum (p-t)^2, sum G (p-t)^2, max|t|}
 __global__ __launch_bounds__(1024) void loss_partials_kernel(int64_t hw, const float* __restrict__ pred, const float* __restrict__ tgt,
-                                                             const float* __restrict__ G, float* __restrict__ out) {
+                                                             const float* __restrict__ G, float lp, float* __restrict__ out) {
   __shared__ float red[4][1024];
   const int n = blockIdx.x;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, mx = 0.f;
   for (int64_t q = threadIdx.x; q < hw; q += blockDim.x) {
     const float t = tgt[(int64_t)n * hw + q], d = pred[(int64_t)n * hw + q] - t;
     s0 += fabsf(d); s1 += d * d;
-    if (G) s2 += G[q] * d * d;
+    if (G) s2 += G[q] * (lp == 2.0f ? d * d : powf(-d, lp));          // integral_loss.py:153: (y_true - y_pred) ** Lp_norm_power
     mx = fmaxf(mx, fabsf(t));
   }
   red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = mx;
@@ -191,14 +191,16 @@ __global__ __launch_bounds__(1024) void loss_partials_kernel(int64_t hw, const f
 }
 
 __global__ void loss_bwd_kernel(int N, int64_t hw, const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ G,
-                                const float* __restrict__ c_mae, const float* __restrict__ c_mse, const float* __restrict__ c_int,
+                                const float* __restrict__ c_mae, const float* __restrict__ c_mse, const float* __restrict__ c_int, float lp,
                                 float* __restrict__ dpred) {
   const int64_t total = (int64_t)N * hw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = i / hw; const int64_t q = i % hw;
     const float d = pred[i] - tgt[i];
     const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    dpred[i] = c_mae[n] * sg + 2.0f * d * (c_mse[n] + (G ? c_int[n] * G[q] : 0.f));
+    float g = c_mae[n] * sg + 2.0f * d * c_mse[n];
+    if (G) g += c_int[n] * G[q] * (lp == 2.0f ? 2.0f * d : -lp * powf(-d, lp - 1.0f));        // d/dpred of (target - pred)^lp
+    dpred[i] = g;
   }
 }
 
@@ -368,19 +370,28 @@ extern "C" int pcnn_spp_max_bwd(pcnn_handle h, int N, int H, int W, int C, int n
   return 0;
 }
 
-extern "C" int pcnn_loss_partials(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, float* out) {
+extern "C" int pcnn_loss_partials_p(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, float lp_power, float* out) {
   PCNN_REQUIRE(h, h && pred && target && out, "pcnn_loss_partials: null argument");
-  hipLaunchKernelGGL(loss_partials_kernel, dim3(N), dim3(1024), 0, h->stream, hw, pred, target, G, out);
+  hipLaunchKernelGGL(loss_partials_kernel, dim3(N), dim3(1024), 0, h->stream, hw, pred, target, G, lp_power, out);
   PCNN_CHECK_LAUNCH(h, "pcnn_loss_partials");
+  return 0;
+}
+
+extern "C" int pcnn_loss_partials(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, float* out) {
+  return pcnn_loss_partials_p(h, N, hw, pred, target, G, 2.0f, out);
+}
+
+extern "C" int pcnn_loss_bwd_p(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, const float* c_mae,
+                               const float* c_mse, const float* c_int, float lp_power, float* dpred) {
+  PCNN_REQUIRE(h, h && pred && target && c_mae && c_mse && c_int && dpred, "pcnn_loss_bwd: null argument");
+  hipLaunchKernelGGL(loss_bwd_kernel, grid1d((int64_t)N * hw), dim3(256), 0, h->stream, N, hw, pred, target, G, c_mae, c_mse, c_int, lp_power, dpred);
+  PCNN_CHECK_LAUNCH(h, "pcnn_loss_bwd");
   return 0;
 }
 
 extern "C" int pcnn_loss_bwd(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, const float* c_mae,
                              const float* c_mse, const float* c_int, float* dpred) {
-  PCNN_REQUIRE(h, h && pred && target && c_mae && c_mse && c_int && dpred, "pcnn_loss_bwd: null argument");
-  hipLaunchKernelGGL(loss_bwd_kernel, grid1d((int64_t)N * hw), dim3(256), 0, h->stream, N, hw, pred, target, G, c_mae, c_mse, c_int, dpred);
-  PCNN_CHECK_LAUNCH(h, "pcnn_loss_bwd");
-  return 0;
+  return pcnn_loss_bwd_p(h, N, hw, pred, target, G, c_mae, c_mse, c_int, 2.0f, dpred);
 }
 
 extern "C" int pcnn_pi_loss_partials(pcnn_handle h, int N, int H, int W, int s, const float* pred, const float* rhs, const float* kern, float* out) {
@@ -400,18 +411,18 @@ extern "C" int pcnn_pi_loss_bwd(pcnn_handle h, int N, int H, int W, int s, const
 
 // ---- loss_wrapper bookkeeping (losses/loss_wrapper.py:45-71) on the N per-sample partial sums
 namespace {
-__global__ void loss_coefficients_kernel(int N, float inv_hw, const float* __restrict__ part, float w_mae, float w_mse, float w_int, int scale_by_peak,
+__global__ void loss_coefficients_kernel(int N, float inv_hw, const float* __restrict__ part, float w_mae, float w_mse, float w_int, float lp, int scale_by_peak,
                                          float inv_gbs, const float* __restrict__ extra /*optional scalar added to the loss*/, float* __restrict__ loss,
                                          float* __restrict__ c_mae, float* __restrict__ c_mse, float* __restrict__ c_int, float* __restrict__ mse) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   float L = 0.f, sq = 0.f;
   for (int n = 0; n < N; ++n) {
     const float pk = scale_by_peak ? part[4 * n + 3] : 1.f;
-    const float i1 = 1.f / pk, i2 = 1.f / (pk * pk);
-    L += (w_mae * part[4 * n] * inv_hw * i1 + w_mse * part[4 * n + 1] * inv_hw * i2 + w_int * part[4 * n + 2] * i2) * inv_gbs;
+    const float i1 = 1.f / pk, i2 = 1.f / (pk * pk), ip = lp == 2.0f ? i2 : 1.f / powf(pk, lp);      // loss_wrapper.py:68: peak ** Lp_norm_power
+    L += (w_mae * part[4 * n] * inv_hw * i1 + w_mse * part[4 * n + 1] * inv_hw * i2 + w_int * part[4 * n + 2] * ip) * inv_gbs;
     c_mae[n] = w_mae * inv_hw * i1 * inv_gbs;
     c_mse[n] = w_mse * inv_hw * i2 * inv_gbs;
-    c_int[n] = w_int * i2 * inv_gbs;
+    c_int[n] = w_int * ip * inv_gbs;
     sq += part[4 * n + 1];
   }
   if (extra) L += extra[0];
@@ -420,13 +431,19 @@ __global__ void loss_coefficients_kernel(int N, float inv_hw, const float* __res
 }
 }  // namespace
 
-extern "C" int pcnn_loss_coefficients(pcnn_handle h, int N, int64_t hw, const float* partials, float w_mae, float w_mse, float w_int, int scale_by_peak,
-                                      int global_batch_size, const float* extra, float* loss, float* c_mae, float* c_mse, float* c_int, float* mse) {
+extern "C" int pcnn_loss_coefficients_p(pcnn_handle h, int N, int64_t hw, const float* partials, float w_mae, float w_mse, float w_int, float lp_power,
+                                        int scale_by_peak, int global_batch_size, const float* extra, float* loss, float* c_mae, float* c_mse, float* c_int,
+                                        float* mse) {
   PCNN_REQUIRE(h, h && partials && loss && c_mae && c_mse && c_int && mse && N >= 1 && global_batch_size >= 1, "pcnn_loss_coefficients: bad argument");
-  hipLaunchKernelGGL(loss_coefficients_kernel, dim3(1), dim3(64), 0, h->stream, N, 1.0f / (float)hw, partials, w_mae, w_mse, w_int, scale_by_peak,
+  hipLaunchKernelGGL(loss_coefficients_kernel, dim3(1), dim3(64), 0, h->stream, N, 1.0f / (float)hw, partials, w_mae, w_mse, w_int, lp_power, scale_by_peak,
                      1.0f / (float)global_batch_size, extra, loss, c_mae, c_mse, c_int, mse);
   PCNN_CHECK_LAUNCH(h, "pcnn_loss_coefficients");
   return 0;
+}
+
+extern "C" int pcnn_loss_coefficients(pcnn_handle h, int N, int64_t hw, const float* partials, float w_mae, float w_mse, float w_int, int scale_by_peak,
+                                      int global_batch_size, const float* extra, float* loss, float* c_mae, float* c_mse, float* c_int, float* mse) {
+  return pcnn_loss_coefficients_p(h, N, hw, partials, w_mae, w_mse, w_int, 2.0f, scale_by_peak, global_batch_size, extra, loss, c_mae, c_mse, c_int, mse);
 }
 
 // ---------------------------------------------------------------- LayerNormalization over the feature axis of an (N, F) matrix

@@ -92,8 +92,7 @@ class loss_wrapper:
         self.global_batch_size = global_batch_size
         icfg = {k: v for k, v in integral_loss_config.items() if k not in ('ndims', 'data_format')}
         self.integral_loss = integral_loss(ndims=ndims, reduce_results=True, **icfg)
-        if self.integral_loss_weight != 0.0 and self.integral_loss.Lp_norm_power != 2:
-            raise NotImplementedError('integral loss kernel implements Lp_norm_power = 2 (all shipped configs)')
+        self.lp = float(self.integral_loss.Lp_norm_power)      # exponent of the integral term (integral_loss.py:153) and of its peak scaling (:68)
         pcfg = {k: v for k, v in physics_informed_loss_config.items() if k not in ('ndims', 'data_format')}
         self.pi_stencil = build_fd_coefficients(pcfg.get('stencil_sizes', 5), pcfg.get('orders', 2), ndims)
         if self.pi_stencil.shape[1] != self.pi_stencil.shape[2]:
@@ -120,7 +119,7 @@ class loss_wrapper:
         y_pred = y_pred.contiguous()
         gbs = N if self.global_batch_size is None else int(self.global_batch_size)
         G = self.integral_loss.weight_map(H, W, dev) if self.integral_loss_weight != 0.0 else None
-        part = ops.loss_partials(y_pred, y_true, G)
+        part = ops.loss_partials(y_pred, y_true, G, self.lp)
         extra = None
         pi = None
         if self.physics_informed_loss_weight != 0.0:
@@ -136,13 +135,13 @@ class loss_wrapper:
         out = ops.empty((3 * N + 2,), dev)
         loss, mse = out[0:1], out[1:2]
         c_mae, c_mse, c_int = out[2:2 + N], out[2 + N:2 + 2 * N], out[2 + 2 * N:2 + 3 * N]
-        ops.handle().call('pcnn_loss_coefficients', c_int_(N), c_int64(H * W), ops._p(part), c_float(self.mae_loss_weight), c_float(self.mse_loss_weight),
-                          c_float(self.integral_loss_weight), c_int_(1 if self.scale else 0), c_int_(gbs), ops._p(extra), ops._p(loss), ops._p(c_mae),
+        ops.handle().call('pcnn_loss_coefficients_p', c_int_(N), c_int64(H * W), ops._p(part), c_float(self.mae_loss_weight), c_float(self.mse_loss_weight),
+                          c_float(self.integral_loss_weight), c_float(self.lp), c_int_(1 if self.scale else 0), c_int_(gbs), ops._p(extra), ops._p(loss), ops._p(c_mae),
                           ops._p(c_mse), ops._p(c_int), ops._p(mse))
         self._last = {'mse': mse}
         if not want_grad:
             return loss[0], None
-        dpred = ops.loss_bwd(y_pred, y_true, G, c_mae, c_mse, c_int)
+        dpred = ops.loss_bwd(y_pred, y_true, G, c_mae, c_mse, c_int, lp_power=self.lp)
         if pi is not None:
             ops.pi_loss_bwd(y_pred, pi[0], pi[1], pi[2], dpred)
         return loss[0], dpred

@@ -601,17 +601,18 @@ def jacobi_sweep_bwd(dout, dx2):
 
 
 # ----------------------------------------------------------------------------- loss / optimizer
-def loss_partials(pred, target, G):
+def loss_partials(pred, target, G, lp_power=2.0):
     N = pred.shape[0]
     out = empty((N, 4), pred.device)
-    handle().call('pcnn_loss_partials', c_int(N), c_int64(pred.numel() // N), _p(pred), _p(target), _p(G), _p(out))
+    handle().call('pcnn_loss_partials_p', c_int(N), c_int64(pred.numel() // N), _p(pred), _p(target), _p(G), c_float(lp_power), _p(out))
     return out
 
 
-def loss_bwd(pred, target, G, c_mae, c_mse, c_int_, out=None):
+def loss_bwd(pred, target, G, c_mae, c_mse, c_int_, out=None, lp_power=2.0):
     N = pred.shape[0]
     d = out if out is not None else torch.empty_like(pred)
-    handle().call('pcnn_loss_bwd', c_int(N), c_int64(pred.numel() // N), _p(pred), _p(target), _p(G), _p(c_mae), _p(c_mse), _p(c_int_), _p(d))
+    handle().call('pcnn_loss_bwd_p', c_int(N), c_int64(pred.numel() // N), _p(pred), _p(target), _p(G), _p(c_mae), _p(c_mse), _p(c_int_), c_float(lp_power),
+                  _p(d))
     return d
 
 

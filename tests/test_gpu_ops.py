@@ -293,6 +293,28 @@ def test_loss_partials_and_bwd():
     assert rel(g, refg) < TOL
 
 
+@pytest.mark.parametrize('p,scale', [(2, True), (3, True), (4, False), (1, True)])
+def test_loss_wrapper_with_other_integral_exponents(p, scale):
+    """losses/integral_loss.py:88,153 Lp_norm_power != 2 (odd p keeps the sign of y_true - y_pred, as the reference does) together with the
+    1 / peak^p sample weights of losses/loss_wrapper.py:68: loss value and d loss / d prediction vs autograd of the oracle."""
+    from poisson_cnn_amd.losses import loss_wrapper
+    rng = np.random.default_rng(40 + p)
+    N, H, W = 3, 36, 44
+    yt, yp = f32(rng.standard_normal((N, 1, H, W))), f32(rng.standard_normal((N, 1, H, W)))
+    rhs = f32(rng.standard_normal((N, 1, H, W)))
+    dx = f32(rng.uniform(0.01, 0.05, (N, 1)))
+    cfg = dict(ndims=2, integral_loss_weight=0.7, integral_loss_config={'n_quadpts': 31, 'Lp_norm_power': p}, physics_informed_loss_weight=0.0,
+               physics_informed_loss_config={'stencil_sizes': [5, 5], 'orders': [2, 2], 'normalize': False}, mse_loss_weight=0.2, mae_loss_weight=0.1,
+               scale_sample_loss_by_target_peak_magnitude=scale, global_batch_size=6)
+    ypt = torch.tensor(yp, requires_grad=True)
+    ref = oloss.loss_wrapper(**cfg)(yt, ypt, torch.tensor(rhs), np.concatenate([dx, dx], 1))
+    ref.backward()
+    L = loss_wrapper(**cfg)
+    loss, dpred = L._evaluate(dev(yt), dev(yp), dev(rhs), dev(np.concatenate([dx, dx], 1)), True)
+    assert abs(float(loss) - float(ref.detach())) < 2e-5 * abs(float(ref.detach()))
+    assert rel(dpred.cpu().numpy(), ypt.grad.numpy()) < 5e-6
+
+
 @pytest.mark.parametrize('padding,mode', [('same', 'SYMMETRIC'), ('same', 'CONSTANT'), ('valid', 'constant')])
 def test_metalearning_conv_forward_backward(padding, mode):
     """Per-sample hyper-network filters (layers/metalearning_conv.py): forward and all gradients vs autograd of the oracle twin."""
