@@ -436,8 +436,9 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         # SPP (:68) + domain-info MLP (:69-74)
         self.spp_levels = [lv if isinstance(lv, int) else lv[0] for lv in spp_config['levels']]
         kind = spp_config.get('pooling_type', 'average').lower()
-        if kind not in ('average', 'avg'):
-            raise NotImplementedError('Dirichlet_BC_NN_Legacy_2: only average spatial pyramid pooling (the shipped config) is implemented')
+        if kind not in ('average', 'avg', 'max'):
+            raise ValueError('spp_config pooling_type must be "average" or "max" (layers/SpatialPyramidPool.py:17-24)')
+        self.spp_max = kind == 'max'
         din = 3 + sum(self.spp_levels)
         self.mlp = []
         for k, (u, a) in enumerate(zip(domain_info_mlp_config['units'], domain_info_mlp_config['activations'])):
@@ -509,7 +510,11 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
             hint = lyr.out_absmax
         bc_conv = o                                                            # (N,1,L,M)
         bins = self._bin_table(Lh)
-        feats = ops.spp_avg_fwd(bc_conv, bins)
+        spp_arg = None
+        if self.spp_max:
+            feats, spp_arg = ops.spp_max_fwd(bc_conv.contiguous(), bins)
+        else:
+            feats = ops.spp_avg_fwd(bc_conv, bins)
         ds = torch.cat([dx * float(X - 1), dx * float(Lh - 1)], 1)           # compute_domain_sizes (:131); tiny (N,2) host-side assembly
         d = torch.cat([dx, ds / ds.amax(dim=1, keepdim=True), feats], 1).contiguous()
         for lyr in self.mlp:
@@ -524,7 +529,7 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         out, _ = ops.set_max_magnitude_fwd(pre, 1.0)                          # (:163)
         ops.set_first_row(out, bc2)                                           # (:165-166)
         if training:
-            self._saved = {'bc_conv': bc_conv, 'mlp_out': d, 'sinh': sh, 'pre': pre, 'bins': bins, 'shape': (N, X, Lh)}
+            self._saved = {'bc_conv': bc_conv, 'mlp_out': d, 'sinh': sh, 'pre': pre, 'bins': bins, 'spp_arg': spp_arg, 'shape': (N, X, Lh)}
         if self.postsmoother is not None:
             dx2 = torch.cat([dx, dx], 1).contiguous()
             out = self.postsmoother.forward(out.view(N, X, Lh, 1), torch.zeros_like(out).view(N, X, Lh, 1), dx2, training=training).view(N, X, Lh)
@@ -547,7 +552,9 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         for lyr in reversed(self.mlp):
             dd = lyr.backward(dd, need_dx=True)
         dfeats = dd[:, 3:].contiguous()                                       # [dx, domain sizes] carry no parameters upstream
-        dbc_conv = ops.axpby(1.0, ops.spp_avg_bwd(sv['bins'], dfeats, tuple(sv['bc_conv'].shape)), 1.0, dbc_conv)
+        dspp = (ops.spp_max_bwd(sv['spp_arg'], dfeats, tuple(sv['bc_conv'].shape)) if self.spp_max
+                else ops.spp_avg_bwd(sv['bins'], dfeats, tuple(sv['bc_conv'].shape)))
+        dbc_conv = ops.axpby(1.0, dspp, 1.0, dbc_conv)
         d = dbc_conv
         for i, lyr in enumerate(reversed(self.boundary)):
             last = i == len(self.boundary) - 1

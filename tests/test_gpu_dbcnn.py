@@ -92,6 +92,27 @@ def test_tiny_train_step(post):
         assert rel(g[n], ref_g[n]) < 3e-3, n
 
 
+def test_max_pyramid_pooling_forward_and_train_step():
+    """spp_config pooling_type = "max" (layers/SpatialPyramidPool.py:17-24; the shipped config uses "average"): forward and every gradient."""
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import Adam
+    full = configs.dbcnn_tiny()
+    cfg = full['model']
+    cfg['spp_config'] = dict(cfg['spp_config'], pooling_type='max')
+    lossp = dict(full['training']['loss_parameters'])
+    model, p = build(cfg, 17)
+    bc, dx = make_inputs(3, 44, 19)
+    assert rel(model([bc, dx, 39]).cpu().numpy(), odb.forward(np_ops, cfg, p, bc, dx, 39)) < TOL_FWD
+    target = f32(np.random.default_rng(3).standard_normal((3, 1, 39, 44)) * 0.3)
+    ref_loss, ref_pred, ref_g = _train_reference(cfg, p, bc, dx, target, lossp, 3)
+    model.compile(loss=loss_wrapper(global_batch_size=3, **lossp), optimizer=Adam(learning_rate=1e-3))
+    logs = model.train_step(((bc, dx), target))
+    assert abs(float(logs['loss']) - ref_loss) < 2e-5 * abs(ref_loss)
+    g = {n: model.store.g[n].cpu().numpy() for n in model.store.trainable_names()}
+    flat = np.concatenate([g[n].ravel() for n in g]); flat_ref = np.concatenate([ref_g[n].ravel() for n in g])
+    assert rel(flat, flat_ref) < 3e-4
+
+
 def test_set_max_magnitude_bwd_and_expand_bwd():
     from poisson_cnn_amd import ops
     rng = np.random.default_rng(0)
