@@ -270,6 +270,10 @@ int pcnn_adam_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m,
 int pcnn_adam_amsgrad_step(pcnn_handle h, int64_t n, float* w, const float* g, float* m, float* v, float* vhat, float lr, float beta1,
                            float beta2, float eps, int step, float grad_scale);
 int pcnn_sgd_step(pcnn_handle h, int64_t n, float* w, const float* g, float lr, float grad_scale);
+/* tf.keras.optimizers.SGD(momentum, nesterov) (train/utils.py:7-8 hands optimizer_parameters to it): v = momentum v - lr g; w += v
+ * (nesterov: w += momentum v - lr g). */
+int pcnn_sgd_momentum_step(pcnn_handle h, int64_t n, float* w, const float* g, float* velocity, float lr, float momentum, int nesterov,
+                           float grad_scale);
 
 /* ---- dataset: reference-solution generators (poisson_CNN/dataset) ------------------------------------------- */
 /* Dirichlet 5-point FD Poisson solve by DST-I diagonalisation, fp64 on the f64 matrix cores; replaces

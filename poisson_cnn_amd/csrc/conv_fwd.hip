@@ -264,7 +264,9 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
   PCNN_REQUIRE(h, lds <= 160 * 1024, "pcnn_conv2d_fwd: halo tile needs %zu B of LDS", lds);
   {
     const int NTh = d->Cout <= 32 ? 1 : 2;
-    const size_t need = ((size_t)d->kh * d->kw * cin_pad + 16) * NTh * 32 * sizeof(float);   // + spare K-steps for the prefetch past the end
+    // + one full tap of spare K-steps: with several Cin chunks the last chunk's unconditional prefetch reads up to cin_pad / 8 - 1 steps past
+    // the end (16 spare channels were only safe under the 4 MB minimum allocation)
+    const size_t need = ((size_t)d->kh * d->kw * cin_pad + cin_pad + 16) * NTh * 32 * sizeof(float);
     if (h->scratch_bytes < need) {
       // grown on demand; stream-ordered reuse is safe because pack and conv run back to back on the handle's stream
       if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }

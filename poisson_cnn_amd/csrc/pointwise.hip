@@ -338,6 +338,17 @@ __global__ void sgd_kernel(int64_t n, float* __restrict__ w, const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) w[i] -= lr * gscale * g[i];
 }
 
+// tf.keras.optimizers.SGD with momentum (TF 2.4): v = momentum v - lr g;  w += v  (nesterov: w += momentum v - lr g)
+__global__ void sgd_momentum_kernel(int64_t n, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, float lr, float momentum,
+                                    int nesterov, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = gscale * g[i];
+    const float vi = momentum * v[i] - lr * gi;
+    v[i] = vi;
+    w[i] += nesterov ? momentum * vi - lr * gi : vi;
+  }
+}
+
 __global__ void bn_fold_kernel(int n, const float* gamma, const float* beta, const float* mean, const float* var, float eps, float* scale, float* shift) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -544,6 +555,14 @@ extern "C" int pcnn_sgd_step(pcnn_handle h, int64_t n, float* w, const float* g,
   PCNN_REQUIRE(h, h && w && g, "pcnn_sgd_step: null argument");
   hipLaunchKernelGGL(sgd_kernel, grid1d(n), dim3(256), 0, h->stream, n, w, g, lr, grad_scale);
   PCNN_CHECK_LAUNCH(h, "pcnn_sgd_step");
+  return 0;
+}
+
+extern "C" int pcnn_sgd_momentum_step(pcnn_handle h, int64_t n, float* w, const float* g, float* velocity, float lr, float momentum, int nesterov,
+                                      float grad_scale) {
+  PCNN_REQUIRE(h, h && w && g && velocity, "pcnn_sgd_momentum_step: null argument");
+  hipLaunchKernelGGL(sgd_momentum_kernel, grid1d(n), dim3(256), 0, h->stream, n, w, g, velocity, lr, momentum, nesterov, grad_scale);
+  PCNN_CHECK_LAUNCH(h, "pcnn_sgd_momentum_step");
   return 0;
 }
 

@@ -638,6 +638,10 @@ def sgd_step(w, g, lr, grad_scale=1.0):
     handle().call('pcnn_sgd_step', c_int64(w.numel()), _p(w), _p(g), c_float(lr), c_float(grad_scale))
 
 
+def sgd_momentum_step(w, g, v, lr, momentum, nesterov, grad_scale=1.0):
+    handle().call('pcnn_sgd_momentum_step', c_int64(w.numel()), _p(w), _p(g), _p(v), c_float(lr), c_float(momentum), c_int(1 if nesterov else 0), c_float(grad_scale))
+
+
 # ----------------------------------------------------------------------------- Dirichlet_BC_NN_Legacy_2 / Poisson_CNN_Legacy
 def dbc_assemble_input(bc_nl):
     """(N, L) boundary values -> (N, 1, L, 3) NHWC [bc, 1, cos(pi y/(L-1))] (models/Dirichlet_BC_NN_Legacy.py:136-139)."""

@@ -11,6 +11,7 @@ import math
 import os
 
 import numpy as np
+import torch
 
 from . import ops
 
@@ -62,15 +63,19 @@ class Adam(_Optimizer):
 class SGD(_Optimizer):
     def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False, name='SGD', **kwargs):
         _reject_unsupported_optimizer_kwargs('SGD', kwargs)
-        if float(momentum) != 0.0 or nesterov:
-            raise NotImplementedError('SGD: momentum / nesterov are not implemented (pcnn_sgd_step is plain gradient descent)')
-        self.learning_rate = float(learning_rate)
+        self.learning_rate, self.momentum, self.nesterov = float(learning_rate), float(momentum), bool(nesterov)
         self.iterations = 0
+
+    def _init_state(self):
+        self.vs = [torch.zeros_like(s.flat_w) for s in self.stores] if self.momentum != 0.0 else None
 
     def apply_gradients(self, grad_scale=1.0):
         self.iterations += 1
-        for s in self.stores:
-            ops.sgd_step(s.flat_w, s.flat_g, self.learning_rate, grad_scale)
+        for k, s in enumerate(self.stores):
+            if self.momentum != 0.0:
+                ops.sgd_momentum_step(s.flat_w, s.flat_g, self.vs[k], self.learning_rate, self.momentum, self.nesterov, grad_scale)
+            else:
+                ops.sgd_step(s.flat_w, s.flat_g, self.learning_rate, grad_scale)
 
 
 def choose_optimizer(name):

@@ -277,6 +277,24 @@ def test_assemble_axpby_adam():
     assert rel(wd.cpu().numpy(), wr) < TOL and rel(vh.cpu().numpy(), vhat) < 1e-4      # (1 - beta_2) is formed in fp32, as in Keras
 
 
+@pytest.mark.parametrize('nesterov', [False, True])
+def test_sgd_momentum(nesterov):
+    """tf.keras.optimizers.SGD(momentum, nesterov) (train/utils.py:7-8): three steps vs the update rule in float64."""
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(7)
+    w0 = f32(rng.standard_normal(1000)); wr = w0.copy(); vr = np.zeros_like(w0)
+    w, v = dev(w0), dev(np.zeros(1000))
+    lr, mom, gs = 0.05, 0.9, 0.5
+    for t in range(3):
+        g = f32(rng.standard_normal(1000))
+        ops.sgd_momentum_step(w, dev(g), v, lr, mom, nesterov, grad_scale=gs)
+        vr = mom * vr - lr * gs * g
+        wr = wr + (mom * vr - lr * gs * g if nesterov else vr)
+    assert rel(w.cpu().numpy(), wr) < TOL and rel(v.cpu().numpy(), vr) < TOL
+    from poisson_cnn_amd.train import SGD
+    assert SGD(learning_rate=0.1, momentum=0.9, nesterov=True).momentum == 0.9
+
+
 def test_loss_partials_and_bwd():
     from poisson_cnn_amd import ops
     rng = np.random.default_rng(12)
