@@ -201,6 +201,22 @@ def traffic_from_profiles(math, workload, kernel_prefix):
             'profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes; source stamp %s matches)' % (name, summ['source_hash']))
 
 
+def mfma_busy_from_profiles(math, workload):
+    """Matrix-pipe busy fraction over all convolution kernels of a step (third PMC pass of tools/collect_pmc.sh), same provenance rule."""
+    from poisson_cnn_amd import _lib
+    path = os.path.join(ROOT, 'profiles', 'r02_c4_pmc_summary_%s.json' % math)
+    if workload != 'c4' or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        summ = json.load(f)
+    if summ.get('source_hash') != _lib.source_hash():
+        return None
+    for k, v in summ['kernels'].items():
+        if k.startswith('conv ('):
+            return v.get('mfma_busy_frac')
+    return None
+
+
 def run(args):
     import numpy as np
     import torch
@@ -285,6 +301,13 @@ def run(args):
         bf, bs, bc = prof.totals('conv_bwd_fused')
         af, as_, ac = flops + wf + bf, secs + ws_ + bs, calls + wc + bc
         traffic, tsrc = traffic_from_profiles(mode, args.workload, 'conv')
+        busy = mfma_busy_from_profiles(mode, args.workload)
+        conv_s_per_step = as_ / max(args.steps, 1)
+        executed = {'what': 'the work the convolution kernels actually execute (the spectral route does not execute the direct-convolution FLOP of '
+                            '`achieved`): their HBM traffic from the PMC passes over their summed HIP-event time of this run, and the fraction of '
+                            'cycles their matrix pipes are busy (SQ_VALU_MFMA_BUSY_CYCLES / (128 GRBM_GUI_ACTIVE), PMC)',
+                    'hbm_achieved': traffic / conv_s_per_step / 1e9 if (traffic and conv_s_per_step) else None, 'hbm_peak': PEAK_HBM_GBS, 'hbm_unit': 'GB/s',
+                    'hbm_frac': traffic / conv_s_per_step / 1e9 / PEAK_HBM_GBS if (traffic and conv_s_per_step) else None, 'mfma_busy_frac': busy}
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
         hf, hb, hs, hc = prof.select(lambda k, f, b: k == 'conv_fwd' and b > 0 and f / b < ridge)
         df, db, ds, dc = prof.select(lambda k, f, b: k == 'deconv_fwd')
@@ -299,6 +322,7 @@ def run(args):
                 'achieved': af / as_ / 1e12 if as_ else None, 'peak': peak, 'unit': 'TFLOP/s (ALGORITHMIC direct-convolution fp32 FLOP, 2 N Ho Wo kh kw Cin Cout per launch)',
                 'frac': af / as_ / 1e12 / peak if as_ else None,
                 'note': 'frac > 1 is possible: the spectral route needs ~k^2/25 times fewer multiply-adds than the direct convolution the numerator counts',
+                'executed': executed,
                 'traffic': traffic, 'traffic_unit': 'bytes per training step over all convolution kernels (2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': tsrc, 'launches': ac, 'avg_launch_ms': 1e3 * as_ / ac if ac else None,
                 'algorithmic_bytes_per_step': (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad')) / max(args.steps, 1),
                 'forward_and_data_gradient': blk(flops, secs, calls), 'wgrad_kernel': blk(wf, ws_, wc), 'backward_fused': blk(bf, bs, bc),

@@ -3,7 +3,10 @@
 stamped with the hash of the kernel sources it was measured on (poisson_cnn_amd._lib.source_hash) - bench.py reports `traffic` only when
 the stamp matches the tree it runs from.
 
-usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <math>"""
+A third pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE, optional) adds the matrix-pipe busy fraction per kernel: BUSY sums the busy cycles
+of the 1024 SIMDs, GUI_ACTIVE the active cycles of the 8 XCDs, so busy fraction = BUSY / (128 * GUI_ACTIVE).
+
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <math> [<mfma_counter_collection.csv>]"""
 import collections
 import csv
 import json
@@ -18,31 +21,40 @@ KERNELS = (r'(conv_fwd_split_kernel<\d, \d>|conv_fwd_kernel<\d>|wgrad_split_kern
 CONV = ('conv_fwd', 'wgrad', 'spec_', 'conv_small')      # what bench.py's `roofline` covers: every convolution launch
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, scale=1024.0):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
         m = re.search(KERNELS, r['Kernel_Name'])
         if m:
-            acc[m.group(1)].append(float(r['Counter_Value']) * 1024.0)
+            acc[m.group(1)].append(float(r['Counter_Value']) * scale)
     return acc
 
 
 def main():
     from poisson_cnn_amd import _lib
     fetch, write, out, math = sys.argv[1:5]
+    mfma = sys.argv[5] if len(sys.argv) > 5 else None
     f, w = per_kernel(fetch, 'FETCH_SIZE'), per_kernel(write, 'WRITE_SIZE')
+    busy = per_kernel(mfma, 'SQ_VALU_MFMA_BUSY_CYCLES', 1.0) if mfma else {}
+    active = per_kernel(mfma, 'GRBM_GUI_ACTIVE', 1.0) if mfma else {}
     kernels = {}
     for k in sorted(set(f) | set(w)):
         fr = sum(f[k]) / max(len(f[k]), 1)
         wr = sum(w[k]) / max(len(w[k]), 1)
         kernels[k] = {'launches': len(f[k]), 'fetch_size_bytes_per_launch_raw': fr, 'write_size_bytes_per_launch': wr,
                       'traffic_bytes_per_launch': 2.0 * fr + wr}
+        if k in busy and sum(active.get(k, [])) > 0:
+            kernels[k]['mfma_busy_frac'] = sum(busy[k]) / (128.0 * sum(active[k]))
     conv = [v for k, v in kernels.items() if k.startswith(CONV)]
     total = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in conv)
     kernels['conv (all convolution kernels of one training step)'] = {'launches': 1, 'fetch_size_bytes_per_launch_raw': None, 'write_size_bytes_per_launch': None,
                                                                      'traffic_bytes_per_launch': total}
+    cb = sum(sum(busy[k]) for k in busy if k.startswith(CONV))
+    ca = sum(sum(active[k]) for k in active if k.startswith(CONV))
+    if ca > 0:
+        kernels['conv (all convolution kernels of one training step)']['mfma_busy_frac'] = cb / (128.0 * ca)
     json.dump({'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --math %s --steps 1 --warmup 0 '
                           '--no-cpu-baseline --no-dataset (two separate passes; tools/collect_pmc.sh)' % math,
                'source_hash': _lib.source_hash(),
@@ -51,7 +63,8 @@ def main():
                        'an upper bound on HBM reads.  The "conv (...)" row is the sum over all convolution kernels of the step.',
                'kernels': kernels}, open(out, 'w'), indent=1)
     for k, v in kernels.items():
-        print('%-60s launches %4d  traffic/launch %.1f MB' % (k, v['launches'], v['traffic_bytes_per_launch'] / 1e6))
+        print('%-60s launches %4d  traffic/launch %.1f MB  mfma busy %s' % (k, v['launches'], v['traffic_bytes_per_launch'] / 1e6,
+                                                                               ('%.2f' % v['mfma_busy_frac']) if 'mfma_busy_frac' in v else '-'))
 
 
 if __name__ == '__main__':
