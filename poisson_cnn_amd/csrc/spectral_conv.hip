@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
     f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll
     for (int gi = 0; gi < GIN; ++gi) {
-      // the next operand block (next channel group, or the next M-tile's first group) is requested before this one's MFMAs
+      // the next operand block (next channel group, or the next M-tile's first group) is requested before this one's MFMAs (two blocks
+      // ahead and 16-byte stores through an in-quad transpose were measured: no gain - the kernel waits on neither)
       if (gi + 1 < GIN) load_a(mt, gi + 1, an);
       else if (mt + mstride < nMt) load_a(mt + mstride, 0, an);
 #pragma unroll
@@ -489,17 +490,23 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
   const float* xr = p.xs + sl.x * RS, *xi = p.xs + sl.y * RS;
   const float* dr = p.ds + sl.x * RS, *di = p.ds + sl.y * RS;
   f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
-  for (int tb = t0; tb < t1; tb += 8) {
-    float ar[4], ai[4], br[4], bi[4];
+  // operands of 2 WU tiles per step, requested one step ahead (two register sets): the loads of step i + 1 fly under the 4 WU MFMAs of step i
+  constexpr int WU = 4;
+  float ar[WU], ai[WU], br[WU], bi[WU], nar[WU], nai[WU], nbr[WU], nbi[WU];
+  auto load = [&](int tb, float (&a0)[WU], float (&a1)[WU], float (&b0)[WU], float (&b1)[WU]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < WU; ++u) {
       const int tt = tb + 2 * u + half;
       const unsigned tc = (unsigned)(tt < t1 ? tt : t0);
       const unsigned ix = (unsigned)sp_item((int64_t)tc * p.gin + gi) + c, id = (unsigned)sp_item(tc) + c;
-      ar[u] = xr[ix]; ai[u] = xi[ix]; br[u] = dr[id]; bi[u] = di[id];
+      a0[u] = xr[ix]; a1[u] = xi[ix]; b0[u] = dr[id]; b1[u] = di[id];
     }
+  };
+  if (t0 < t1) load(t0, ar, ai, br, bi);
+  for (int tb = t0; tb < t1; tb += 2 * WU) {
+    if (tb + 2 * WU < t1) load(tb + 2 * WU, nar, nai, nbr, nbi);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < WU; ++u) {
       const bool ok = tb + 2 * u + half < t1;
       const float a0 = ok ? ar[u] : 0.f, a1 = ok ? ai[u] : 0.f;
       acc[0] = mfma(a0, br[u], acc[0]);
@@ -507,6 +514,8 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
       acc[2] = mfma(a0, bi[u], acc[2]);
       acc[3] = mfma(a1, bi[u], acc[3]);
     }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) { ar[u] = nar[u]; ai[u] = nai[u]; br[u] = nbr[u]; bi[u] = nbi[u]; }
   }
   float* o = p.part + (((int64_t)part * NSLOT + slot) * p.gin + gi) * 4 * 1024 + c;
 #pragma unroll
