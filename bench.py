@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_SPLIT_TFLOPS = 2500.0 / 3  # 3 fp16 MFMA FLOP per algorithmic fp32 FLOP at the ~2.5 PFLOP/s dense fp16 peak
+PEAK_FP64_MFMA_TFLOPS = 78.6    # MI355X data-sheet fp64 matrix rate (v_mfma_f64_16x16x4_f64: 256 FLOP/clk/CU at 2.4 GHz, 256 CUs, half the MI300X rate)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s is what a float4 copy achieves)
 WORKLOADS = {'c4': (8, 1024), 'c3': (32, 512), 'small': (2, 256), 'launch-check': (0, 0)}
 
@@ -139,11 +140,14 @@ def dataset_block():
     for _ in range(3):
         gen[0]
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        inp, soln = gen[0]
-    torch.cuda.synchronize()
-    t = (time.perf_counter() - t0) / 10
+    rounds = []
+    for _ in range(3):           # three rounds of ten batches, the fastest round counts: the generator's host side (numpy control points, launch
+        t0 = time.perf_counter()  # glue) shares the box's cores with whatever else runs there, and single rounds were seen 4x apart between boxes
+        for _ in range(10):
+            inp, soln = gen[0]
+        torch.cuda.synchronize()
+        rounds.append((time.perf_counter() - t0) / 10)
+    t = min(rounds)
     rhs, left, top, right, bottom, dx = [x.cpu().numpy().astype(np.float64) for x in inp]
     t0 = time.perf_counter()
     ref = ods.multigrid_poisson_solve(rhs[:2, 0], {'left': left[:2, 0], 'right': right[:2, 0], 'top': top[:2, 0], 'bottom': bottom[:2, 0]}, dx[:2, 0])
@@ -151,7 +155,8 @@ def dataset_block():
     err = float(np.linalg.norm(soln[:2, 0].cpu().numpy() - ref) / np.linalg.norm(ref))
     n = H - 2
     return {'metric': 'reference-solution samples/s at 512^2 (control points -> legacy bicubic -> fp64 DST-I solve, on device)', 'value': N / t,
-            'fp64_mfma_tflops': 8.0 * n ** 3 * N / t / 1e12, 'algorithm': 'GEMM DST-I on v_mfma_f64_16x16x4_f64, 8 n^3 FLOP per sample',
+            'seconds_per_batch_rounds': rounds, 'fp64_mfma_tflops': 8.0 * n ** 3 * N / t / 1e12, 'fp64_mfma_peak_tflops': PEAK_FP64_MFMA_TFLOPS,
+            'fp64_mfma_frac': 8.0 * n ** 3 * N / t / 1e12 / PEAK_FP64_MFMA_TFLOPS, 'algorithm': 'GEMM DST-I on v_mfma_f64_16x16x4_f64, 8 n^3 FLOP per sample',
             'cpu_baseline': {'value': 1.0 / tc, 'unit': 'samples/s', 'kind': 'port',
                              'sample': '2 samples, scipy.sparse.linalg.splu of the same 5-point system (stand-in for pyamg), 1 thread'},
             'rel_l2_gpu_vs_cpu': err}

@@ -100,18 +100,12 @@ def _process_normalizations(n):
 
 
 def _poly_and_second_derivative(roots, x):
-    """p(x) = prod_r (x + roots[r]) and d2p/dx2 = sum_{i != j} prod_{k != i,j} (x + roots[k]) on the points x.
-    The reference differentiates the product twice with tf.gradients and patches the NaNs that produces wherever a factor
-    vanishes (dataset/generators/reverse.py:39-71); the closed form needs no patch."""
-    f = x[:, None] + roots[None, :]
-    d = roots.shape[0]
-    p = np.prod(f, axis=1)
-    ddp = np.zeros_like(x)
-    for i in range(d):
-        for j in range(d):
-            if i != j:
-                ddp += np.prod(np.delete(f, [i, j], axis=1), axis=1)
-    return p, ddp
+    """p(x) = prod_r (x + roots[r]) and d2p/dx2 on the points x.  The reference differentiates the product twice with tf.gradients and
+    patches the NaNs that produces wherever a factor vanishes (dataset/generators/reverse.py:39-71); here the product is expanded once
+    (degree <= ~12, roots in [-1, 0]: exact to ~1e-13 in float64) and both are Horner evaluations - no patch, no per-pair products."""
+    from numpy.polynomial import polynomial as npoly
+    c = npoly.polyfromroots(-np.asarray(roots, dtype=np.float64))
+    return npoly.polyval(x, c), (npoly.polyval(x, npoly.polyder(c, 2)) if c.shape[0] > 2 else np.zeros_like(x))
 
 
 # ----------------------------------------------------------------------------- analytic ("reverse") generators
