@@ -53,17 +53,30 @@ def _nchw(y):
 
 
 class _Layer:
-    """Lazy build, Keras-style weight access, channels_first I/O."""
+    """Lazy build, Keras-style weight access; I/O in the layer's data_format (channels_first as in every reference config, or channels_last =
+    the kernels' own NHWC layout, in which case nothing is permuted)."""
 
     def __init__(self, data_format='channels_first', device=None, seed=0, name=None):
-        if data_format != 'channels_first':
-            raise NotImplementedError('only data_format="channels_first" (every shipped config of the reference) is supported at the API')
+        if data_format not in ('channels_first', 'channels_last'):
+            raise ValueError('data_format must be channels_first or channels_last')
         self.data_format = data_format
         self.device = _dev(device)
         self.seed = seed
         self.name = name or type(self).__name__
         self.built = False
         self.store, self.ctx = None, None
+
+    # -- layout: user tensor <-> NHWC
+    def _in(self, x):
+        if self.data_format == 'channels_first':
+            return _nhwc(x, self.device)
+        x = _t(x, self.device)
+        if x.dim() != 4:
+            raise ValueError('expected a (N,H,W,C) tensor, got shape %s' % (tuple(x.shape),))
+        return x.contiguous()
+
+    def _out(self, y):
+        return _nchw(y) if self.data_format == 'channels_first' else y.contiguous()
 
     # -- building
     def _begin_build(self):
@@ -150,7 +163,7 @@ class Conv2D(_Layer):
         self._end_build()
 
     def call(self, x, training=False):
-        x = _nhwc(x, self.device)
+        x = self._in(x)
         if not self.built:
             self._build(x.shape[3])
         if self._advanced is None and self.padding == 'valid':
@@ -160,13 +173,13 @@ class Conv2D(_Layer):
             if training:
                 raise NotImplementedError('training through an un-padded VALID Conv2D is not part of the hot path; wrap it with '
                                           'apply_advanced_padding_and_call_conv_layer or use padding="same"')
-            return _nchw(y)
-        return _nchw(self.unit.forward(x, training=training))
+            return self._out(y)
+        return self._out(self.unit.forward(x, training=training))
 
     def backward(self, dy):
-        dx = self.unit.backward(_nhwc(dy, self.device), need_dx=True)
+        dx = self.unit.backward(self._in(dy), need_dx=True)
         self._post_backward()
-        return _nchw(dx)
+        return self._out(dx)
 
 
 def apply_advanced_padding_and_call_conv_layer(padding_mode, conv_layer, constant_padding_value=0.0):
@@ -216,7 +229,7 @@ class resnet(_Layer):
                          constant_padding_value=constant_padding_value, activation=act, use_bias=ub)
 
     def call(self, x, training=False):
-        x = _nhwc(x, self.device)
+        x = self._in(x)
         if not self.built:
             if x.shape[3] != self.args['filters']:
                 raise ValueError('resnet needs as many input channels as filters (%d vs %d): the skip connection adds them' % (x.shape[3], self.args['filters']))
@@ -224,12 +237,12 @@ class resnet(_Layer):
             self.block = L.resnet(self.store, self.ctx, 'resnet', **self.args)
             self._end_build()
         self._pre()
-        return _nchw(self.block.forward(x, training=training))
+        return self._out(self.block.forward(x, training=training))
 
     def backward(self, dy):
-        dx = self.block.backward(_nhwc(dy, self.device))
+        dx = self.block.backward(self._in(dy))
         self._post_backward()
-        return _nchw(dx)
+        return self._out(dx)
 
 
 class _bottleneck(_Layer):
@@ -251,7 +264,7 @@ class _bottleneck(_Layer):
         self.filters = filters
 
     def _run(self, x, training):
-        x = _nhwc(x, self.device)
+        x = self._in(x)
         if not self.built:
             self._begin_build()
             self.block = self.KIND(self.store, self.ctx, 'block', x.shape[3], **self.kw)
@@ -262,13 +275,13 @@ class _bottleneck(_Layer):
         out = ops.empty((N, Ho, Wo, self.filters), x.device)
         self.block.forward_into(x, out, 1.0, 0.0, training=training)
         self._in_shape = tuple(x.shape)
-        return _nchw(out)
+        return self._out(out)
 
     def backward(self, dy):
         d_in = ops.zeros(self._in_shape, self.device)
-        self.block.backward_from(_nhwc(dy, self.device), 1.0, d_in)
+        self.block.backward_from(self._in(dy), 1.0, d_in)
         self._post_backward()
-        return _nchw(d_in)
+        return self._out(d_in)
 
 
 class bottleneck_block_multilinearupsample(_bottleneck):
@@ -316,7 +329,7 @@ class deconvupscale(_Layer):
 
     def call(self, inputs, training=False):
         x, output_shape = inputs
-        x = _nhwc(x, self.device)
+        x = self._in(x)
         if not self.built:
             self._begin_build()
             self.store.add('kernel', (self.k, self.k, self.filters, x.shape[3]), 'glorot')
@@ -325,18 +338,18 @@ class deconvupscale(_Layer):
             self._end_build()
         shp = [int(v) for v in (output_shape.tolist() if hasattr(output_shape, 'tolist') else output_shape)]
         if len(shp) != 4:
-            raise ValueError('output_shape must have 4 entries (N, C, H, W)')
-        H, W = shp[2], shp[3]
+            raise ValueError('output_shape must have 4 entries ((N, C, H, W), or (N, H, W, C) for channels_last)')
+        H, W = (shp[2], shp[3]) if self.data_format == 'channels_first' else (shp[1], shp[2])
         y = ops.deconv_fwd(x, self.store.w['kernel'], self.store.w['bias'] if self.use_bias else None, (H, W), self.up)
         self._saved = (x, (H, W)) if training else None
-        return _nchw(y)
+        return self._out(y)
 
     def backward(self, dy):
         x, _ = self._saved
-        dy = _nhwc(dy, self.device)
+        dy = self._in(dy)
         g = self.store.g
         ops.deconv_bwd_filter(x, dy, self.up, dk=g['kernel'], dbias=g['bias'] if self.use_bias else None, ws=self.ctx.ws, kernel_size=(self.k, self.k))
-        return _nchw(ops.deconv_bwd_data(dy, self.store.w['kernel'], (x.shape[1], x.shape[2]), self.up))
+        return self._out(ops.deconv_bwd_data(dy, self.store.w['kernel'], (x.shape[1], x.shape[2]), self.up))
 
 
 class Upsample(_Layer):
@@ -353,13 +366,13 @@ class Upsample(_Layer):
 
     def call(self, inputs, training=False):
         x, _domain_sizes, out_hw = inputs
-        x = _nhwc(x, self.device)
+        x = self._in(x)
         hw = tuple(int(v) for v in (out_hw.tolist() if hasattr(out_hw, 'tolist') else out_hw))
         self._coarse = (x.shape[1], x.shape[2])
-        return _nchw(ops.resize_fwd(x, hw, self.method))
+        return self._out(ops.resize_fwd(x, hw, self.method))
 
     def backward(self, dy):
-        return _nchw(ops.resize_bwd(_nhwc(dy, self.device), self._coarse, self.method))
+        return self._out(ops.resize_bwd(self._in(dy), self._coarse, self.method))
 
 
 class SpatialPyramidPool(_Layer):
@@ -394,7 +407,7 @@ class SpatialPyramidPool(_Layer):
         return self._bins[(H, W)]
 
     def call(self, x, training=False):
-        x = _nhwc(x, self.device)
+        x = self._in(x)
         bins = self._bin_table(x.shape[1], x.shape[2])
         if self.max:
             out, arg = ops.spp_max_fwd(x, bins)
@@ -407,7 +420,7 @@ class SpatialPyramidPool(_Layer):
     def backward(self, dout):
         a, shape = self._saved
         dout = _t(dout, self.device).contiguous()
-        return _nchw(ops.spp_max_bwd(a, dout, shape) if self.max else ops.spp_avg_bwd(a, dout, shape))
+        return self._out(ops.spp_max_bwd(a, dout, shape) if self.max else ops.spp_avg_bwd(a, dout, shape))
 
 
 class Scaling(_Layer):
@@ -426,20 +439,20 @@ class Scaling(_Layer):
 
     def call(self, inputs, training=False):
         x, other = inputs
-        x, other = _nhwc(x, self.device), _nhwc(other, self.device)
+        x, other = self._in(x), self._in(other)
         if x.shape[3] != 1 or other.shape[3] != 1:
             raise NotImplementedError('Scaling is implemented for one-channel inputs (the model scales its (N,1,H,W) output by the (N,1,H,W) rhs)')
         if not self.built:
             self._begin_build()
             self.layer = L.Scaling(self.store, self.ctx, 'scaling', **self.kw)
             self._end_build()
-        return _nchw(self.layer.forward(x, other, training=training))
+        return self._out(self.layer.forward(x, other, training=training))
 
     def backward(self, dy):
         """Gradient w.r.t. x_to_scale (`other` - the right-hand side in the model - gets none, as in the reference's graph)."""
-        d = self.layer.backward(_nhwc(dy, self.device))
+        d = self.layer.backward(self._in(dy))
         self._post_backward()
-        return _nchw(d)
+        return self._out(d)
 
 
 class JacobiIterationLayer(_Layer):
@@ -457,12 +470,12 @@ class JacobiIterationLayer(_Layer):
 
     def call(self, inputs, training=False):
         guess, rhs, dx = inputs
-        g, r = _nhwc(guess, self.device), _nhwc(rhs, self.device)
+        g, r = self._in(guess), self._in(rhs)
         if g.shape[3] != 1 or r.shape[3] != 1:
             raise ValueError('guess and rhs must have one channel')
         dx = _t(dx, self.device).reshape(g.shape[0], -1)
         dx2 = (torch.cat([dx, dx], 1) if dx.shape[1] == 1 else dx[:, :2]).contiguous()
-        return _nchw(self.layer.forward(g, r, dx2, training=training))
+        return self._out(self.layer.forward(g, r, dx2, training=training))
 
     def backward(self, dout):
-        return _nchw(self.layer.backward(_nhwc(dout, self.device)))
+        return self._out(self.layer.backward(self._in(dout)))

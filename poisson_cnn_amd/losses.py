@@ -82,9 +82,10 @@ class loss_wrapper:
     def __init__(self, ndims, integral_loss_weight, integral_loss_config, physics_informed_loss_weight, physics_informed_loss_config,
                  data_format='channels_first', mse_loss_weight=0.0, mae_loss_weight=0.0, scale_sample_loss_by_target_peak_magnitude=False,
                  global_batch_size=None):
-        if ndims != 2 or data_format != 'channels_first':
-            raise NotImplementedError('loss_wrapper: 2-D channels_first only')
-        self.ndims = ndims
+        if ndims != 2 or data_format not in ('channels_first', 'channels_last'):
+            raise NotImplementedError('loss_wrapper: 2-D only')
+        self.ndims, self.data_format = ndims, data_format       # channels_last: the public __call__ takes (N,H,W,1) tensors (one channel: a reshape)
+        integral_loss_config = dict(integral_loss_config, data_format='channels_first')
         self.integral_loss_weight = float(integral_loss_weight)
         self.physics_informed_loss_weight = float(physics_informed_loss_weight)
         self.mse_loss_weight, self.mae_loss_weight = float(mse_loss_weight), float(mae_loss_weight)
@@ -147,6 +148,8 @@ class loss_wrapper:
         return loss[0], dpred
 
     def __call__(self, y_true, y_pred, rhs, dx):
+        if self.data_format == 'channels_last':
+            y_true, y_pred, rhs = [t.reshape((t.shape[0], 1) + tuple(t.shape[1:-1])) if (t is not None and t.dim() == 4) else t for t in (y_true, y_pred, rhs)]
         return self._evaluate(y_true, y_pred, rhs, dx, False)[0]
 
     def value_and_grad(self, y_true, y_pred, rhs, dx):

@@ -102,8 +102,32 @@ class _ModelBase:
             print_fn('  %-44s %-20s %s' % (name, shape, 'trainable' if kind in ('w', 'bn_gamma', 'bn_beta') else 'non-trainable'))
         print_fn('Trainable params: %d' % self.store.n_trainable)
 
+    # ------------------------------------------------------------------ data_format
+    # The network's boundary tensors all have ONE channel, so (N,1,H,W) and (N,H,W,1) are the same memory: data_format='channels_last' is a
+    # reshape at the public entry points (__call__, train_step / fit); call() and everything inside stay channels_first.
+    def _channels_last(self):
+        return getattr(self, 'data_format', 'channels_first') == 'channels_last'
+
+    def _cf(self, t):
+        """one user tensor -> channels_first view: (N,H,W,1) -> (N,1,H,W), (N,L,1) -> (N,1,L); scalars / (N,k) arrays untouched"""
+        if not self._channels_last() or not hasattr(t, 'shape') or len(t.shape) < 3:
+            return t
+        if t.shape[-1] != 1:
+            raise ValueError('channels_last tensors of this model have one channel, got shape %s' % (tuple(t.shape),))
+        t = torch.as_tensor(np.asarray(t)) if isinstance(t, np.ndarray) else t
+        return t.reshape((t.shape[0], 1) + tuple(t.shape[1:-1]))
+
+    def _cl(self, t):
+        if not self._channels_last() or t.dim() < 3:
+            return t
+        return t.reshape((t.shape[0],) + tuple(t.shape[2:]) + (1,))
+
     def __call__(self, inp, training=False):
-        return self.call(inp, training=training)
+        return self._cl(self.call([self._cf(v) for v in inp], training=training))
+
+    def train_step(self, data):
+        inputs, y_true = data
+        return self._train_step_cf(([self._cf(v) for v in inputs], self._cf(y_true)))
 
     @property
     def stores(self):
@@ -174,8 +198,8 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
                  bottleneck_deconv_config=None, bottleneck_multilinear_config=None, input_normalization=None, output_scaling=None,
                  use_batchnorm=False, postsmoother_iterations=5, use_scaling=False, use_positional_embeddings=True, scaling_config=None,
                  gradient_accumulation_steps=None, bc_type='dirichlet', device=None, seed=0, batchnorm_training=False):
-        if data_format != 'channels_first':
-            raise NotImplementedError('only data_format="channels_first" (all shipped configs) is supported at the API')
+        if data_format not in ('channels_first', 'channels_last'):
+            raise ValueError('data_format must be channels_first or channels_last')
         if pre_bottleneck_convolutions_config is None:
             raise ValueError('Provide a config for pre bottleneck convolutions')
         if bottleneck_deconv_config is None or bottleneck_multilinear_config is None:
@@ -361,7 +385,7 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         self.backward(dpred)
         return loss, pred
 
-    def train_step(self, data):
+    def _train_step_cf(self, data):
         (rhs, dx), y_true = data
         rhs, dx, y_true = _as_device(rhs, self.device), _as_device(dx, self.device), _as_device(y_true, self.device)
         dx = dx.reshape(dx.shape[0], -1)[:, :1].contiguous()
@@ -396,8 +420,8 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
 
     def __init__(self, data_format='channels_first', boundary_conv_config=None, spp_config=None, domain_info_mlp_config=None,
                  final_convolutions_config=None, postsmoother_iterations=0, use_batchnorm=False, device=None, seed=0, batchnorm_training=False):
-        if data_format != 'channels_first':
-            raise NotImplementedError('only data_format="channels_first" (all shipped configs) is supported at the API')
+        if data_format not in ('channels_first', 'channels_last'):
+            raise ValueError('data_format must be channels_first or channels_last')
         if boundary_conv_config is None:
             raise ValueError('Provide a config for the boundary convolutions.')
         if spp_config is None:
@@ -562,7 +586,7 @@ class Dirichlet_BC_NN_Legacy_2(_ModelBase):
         self.ctx.join()                                            # weight gradients of the side stream
         self.store.finish_bn_grads()
 
-    def train_step(self, data):
+    def _train_step_cf(self, data):
         """reference :172-187: the loss sees rhs = 0 and dx repeated for both axes."""
         (bc, dx), y_true = data
         bc, dx, y_true = _as_device(bc, self.device), _as_device(dx, self.device), _as_device(y_true, self.device)
@@ -608,6 +632,7 @@ class Poisson_CNN_Legacy(_ModelBase):
             raise NotImplementedError('Poisson_CNN_Legacy: jacobi_iterations > 0 is unreachable in the reference (NameError at construction)')
         self.hpnn, self.dbcnn = hpnn, dbcnn
         self.device = hpnn.device
+        self.data_format = getattr(hpnn, 'data_format', 'channels_first')
         self.optimizer = self.loss_fn = self.grad_sync = None
 
     # weights: the two sub-models' lists, hpnn first (Keras tracks attributes in assignment order)
@@ -703,7 +728,7 @@ class Poisson_CNN_Legacy(_ModelBase):
             else:
                 ops.axpby_flat(1.0, acc, 1.0, g)                                              # the two passes share the weights
 
-    def train_step(self, data):
+    def _train_step_cf(self, data):
         """reference :56-66."""
         inputs, y_true = data
         inputs = [_as_device(v, self.device) for v in inputs]

@@ -209,3 +209,35 @@ def test_deconvupscale_upsample_spp_jacobi_scaling():
     assert rel(y, ref) < TOL
     dy = f32(rng.standard_normal(ref.shape))
     check_grads(sc, w, lambda p, xx: ohpnn.scaling_forward(torch_twin, p, meta, xx, torch.tensor(b)), [a], dy, sc.backward(dy))
+
+
+def test_channels_last_layers_match_channels_first():
+    """data_format='channels_last' (the kernels' own NHWC layout: nothing is permuted) gives the same numbers as channels_first: a padded
+    convolution with its gradients, a resnet block, and deconvupscale with an (N, H, W, C) output_shape."""
+    from poisson_cnn_amd.keras_layers import Conv2D, apply_advanced_padding_and_call_conv_layer, deconvupscale, resnet
+    rng = np.random.default_rng(77)
+    x = f32(rng.standard_normal((2, 6, 21, 17)))
+    xl = np.ascontiguousarray(x.transpose(0, 2, 3, 1))
+    dy = f32(rng.standard_normal((2, 5, 21, 17)))
+    outs = {}
+    for fmt in ('channels_first', 'channels_last'):
+        conv = Conv2D(filters=5, kernel_size=7, activation='tf.nn.leaky_relu', padding='valid', data_format=fmt, seed=3)
+        op = apply_advanced_padding_and_call_conv_layer('SYMMETRIC', conv)
+        y = op(x if fmt == 'channels_first' else xl, training=True)
+        dx = conv.backward(dy if fmt == 'channels_first' else np.ascontiguousarray(dy.transpose(0, 2, 3, 1)))
+        y, dx = y.cpu().numpy(), dx.cpu().numpy()
+        if fmt == 'channels_last':
+            y, dx = y.transpose(0, 3, 1, 2), dx.transpose(0, 3, 1, 2)
+        outs[fmt] = (y, dx, conv.gradients['conv/kernel'].cpu().numpy())
+    for a, b in zip(outs['channels_first'], outs['channels_last']):
+        np.testing.assert_array_equal(a, b)
+    r1, r2 = resnet(ndims=2, filters=6, kernel_size=3, seed=4), resnet(ndims=2, filters=6, kernel_size=3, data_format='channels_last', seed=4)
+    np.testing.assert_array_equal(r1(x).cpu().numpy(), r2(xl).cpu().numpy().transpose(0, 3, 1, 2))
+    d1 = deconvupscale(upsample_ratio=2, filters=4, kernel_size=2, seed=5)
+    d2 = deconvupscale(upsample_ratio=2, filters=4, kernel_size=2, data_format='channels_last', seed=5)
+    y1 = d1([x, np.array([2, 4, 41, 34], dtype=np.int32)])
+    y2 = d2([xl, np.array([2, 41, 34, 4], dtype=np.int32)])
+    assert tuple(y2.shape) == (2, 41, 34, 4)
+    np.testing.assert_array_equal(y1.cpu().numpy(), y2.cpu().numpy().transpose(0, 3, 1, 2))
+    with pytest.raises(ValueError):
+        Conv2D(filters=1, kernel_size=3, data_format='NCHW')

@@ -270,3 +270,27 @@ def test_two_stream_backward_is_bitwise_identical_to_one_stream():
             model.train_step(((rhs, dx), target))
         grads.append(model.store.flat_g.cpu().numpy().copy())
     assert np.array_equal(grads[0], grads[1]) and np.array_equal(grads[0], grads[2])
+
+
+def test_channels_last_model_api():
+    """Homogeneous_Poisson_NN_Legacy(data_format='channels_last'): (N,H,W,1) in, (N,H,W,1) out, identical numbers and an identical training
+    step (the boundary tensors have one channel, so the two formats are the same memory)."""
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    from poisson_cnn_amd.train import Adam
+    full = configs.hpnn_tiny()
+    rhs, dx = make_inputs(2, 40, 44, 8)
+    tgt = np.random.default_rng(1).standard_normal(rhs.shape).astype(np.float32) * 0.1
+    res = {}
+    for fmt in ('channels_first', 'channels_last'):
+        m = Homogeneous_Poisson_NN_Legacy(**dict(full['model'], data_format=fmt), seed=5)
+        m.compile(loss=loss_wrapper(global_batch_size=2, **full['training']['loss_parameters']), optimizer=Adam(learning_rate=1e-3))
+        r, t = (rhs, tgt) if fmt == 'channels_first' else (rhs.transpose(0, 2, 3, 1), tgt.transpose(0, 2, 3, 1))
+        y = m([r, dx])
+        assert tuple(y.shape) == ((2, 1, 40, 44) if fmt == 'channels_first' else (2, 40, 44, 1))
+        logs = m.train_step(((r, dx), t))
+        res[fmt] = (y.cpu().numpy().reshape(2, 40, 44), float(logs['loss']), m.store.flat_w.cpu().numpy().copy())
+    np.testing.assert_array_equal(res['channels_first'][0], res['channels_last'][0])
+    assert res['channels_first'][1] == res['channels_last'][1]
+    np.testing.assert_array_equal(res['channels_first'][2], res['channels_last'][2])
