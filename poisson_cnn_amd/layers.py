@@ -385,11 +385,16 @@ class _bottleneck_base:
         self.conv0 = self.stages[0] if (self.method == 'pool' and use_resnet) else None
         self.res = [st for st in self.stages if isinstance(st, resnet)]
 
-    def _down_and_convs(self, x, training):
+    def _down_and_convs(self, x, training, pooled=None):
+        """pooled: the already down-sampled input (the model's pooling pyramid, models.py) - its gradient is then RETURNED by
+        _backward_convs_and_down instead of being pooled back into d_in."""
         self.x = x if training else None
+        self._pooled_given = pooled is not None
         hint = None
         if self.down_conv is not None:
             o = self.down_conv.forward(x, training=training)
+        elif pooled is not None:
+            o = pooled
         else:
             o = ops.pool2d_fwd(x, self.f, self.pool)
         for st in self.stages:
@@ -401,12 +406,16 @@ class _bottleneck_base:
         d = dcoarse
         for st in reversed(self.stages):
             d = st.backward(d, inplace=True)
+        ret = None
         if self.down_conv is not None:
             dx = self.down_conv.backward(d, inplace=True)
             ops.axpby(1.0, dx, 1.0, d_in)
+        elif self._pooled_given:
+            ret = d
         else:
             ops.pool2d_bwd(self.x, d, self.f, self.pool, dx=d_in, accumulate=True)
         self.x = None
+        return ret
 
     def out_hw(self, H, W):
         return int((H / self.f) * self.up), int((W / self.f) * self.up)   # blocks/bottleneck_block.py:82,109
@@ -425,9 +434,9 @@ class bottleneck_block_deconvupsample(_bottleneck_base):
         if deconv_use_bias:
             store.add(name + '/deconv/bias', (self.filters,), 'glorot')
 
-    def forward_into(self, x, merged, alpha, beta, training=True):
+    def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
         N, H, W, _ = x.shape
-        o = self._down_and_convs(x, training)
+        o = self._down_and_convs(x, training, pooled)
         assert self.out_hw(H, W) == (H, W), 'deconv branch must restore the input resolution'
         self.coarse = o if training else None
         ops.deconv_fwd(o, self.store.w[self.name + '/deconv/kernel'], self.store.w[self.name + '/deconv/bias'] if self.deconv_use_bias else None,
@@ -441,7 +450,7 @@ class bottleneck_block_deconvupsample(_bottleneck_base):
         ops.deconv_bwd_filter(o, dmerged, self.up, alpha=alpha, dk=g[self.name + '/deconv/kernel'],
                               dbias=g[self.name + '/deconv/bias'] if self.deconv_use_bias else None, ws=self.ctx.ws, kernel_size=(self.dk, self.dk))
         dcoarse = ops.deconv_bwd_data(dmerged, k, (o.shape[1], o.shape[2]), self.up, alpha=alpha)
-        self._backward_convs_and_down(dcoarse, d_in)
+        return self._backward_convs_and_down(dcoarse, d_in)
 
 
 class bottleneck_block_multilinearupsample(_bottleneck_base):
@@ -453,16 +462,16 @@ class bottleneck_block_multilinearupsample(_bottleneck_base):
         if self.method not in ops.RESIZE:
             raise ValueError('unsupported resize method ' + resize_method)
 
-    def forward_into(self, x, merged, alpha, beta, training=True):
+    def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
         N, H, W, _ = x.shape
-        o = self._down_and_convs(x, training)
+        o = self._down_and_convs(x, training, pooled)
         self.coarse_hw = (o.shape[1], o.shape[2])
         assert self.out_hw(H, W) == (H, W)
         ops.resize_fwd(o, (H, W), self.method, alpha=alpha, beta=beta, out=merged)
 
     def backward_from(self, dmerged, alpha, d_in):
         dcoarse = ops.resize_bwd(dmerged, self.coarse_hw, self.method, alpha=alpha)
-        self._backward_convs_and_down(dcoarse, d_in)
+        return self._backward_convs_and_down(dcoarse, d_in)
 
 
 # ----------------------------------------------------------------------------- dense / scaling / jacobi

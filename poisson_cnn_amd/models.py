@@ -296,6 +296,20 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         self._acc = None
 
     # ------------------------------------------------------------------ forward
+    def _pool_pyramid(self, x, blocks):
+        """The eight branches average-pool the SAME tensor by 2, 3, 4, 8, ..., 128 (blocks/bottleneck_block.py:36-41): eight full-resolution
+        reads.  Where a factor f and an already pooled factor g | f both divide the image (no SAME padding), pool_f = pool_{f/g} o pool_g
+        exactly (equal-weight means of equal-size blocks), so only the factors without a divisor read the full tensor.  {f: (tensor, parent g)}"""
+        N, H, W, _ = x.shape
+        fs = sorted({b.f for b in blocks if b.down_conv is None and b.pool in ('average', 'avg') and H % b.f == 0 and W % b.f == 0})
+        if os.environ.get('PCNN_POOL_PYRAMID', '1') == '0':
+            fs = []
+        pyr = {}
+        for f in fs:
+            parent = max([g for g in pyr if f % g == 0], default=None)
+            pyr[f] = (ops.pool2d_fwd(x if parent is None else pyr[parent][0], f if parent is None else f // parent, 'average'), parent)
+        return pyr
+
     def call(self, inp, training=False):
         """reference :183-257.  inp = [rhs (N,1,H,W), dx (N,1)]; returns (N,1,H,W) (torch CUDA tensor)."""
         rhs, dx = inp
@@ -321,8 +335,10 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         merged = cat[..., F:]
         blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks
         alpha = 1.0 / float(len(blocks) * F)                     # :222
+        pyr = self._pool_pyramid(initial, blocks)
         for i, b in enumerate(blocks):
-            b.forward_into(initial, merged, alpha, 0.0 if i == 0 else 1.0, training=training)
+            b.forward_into(initial, merged, alpha, 0.0 if i == 0 else 1.0, training=training, pooled=pyr[b.f][0] if b.f in pyr else None)
+        self._pyr = pyr if training else None
         self.non_bottleneck_conv.forward(initial, out=cat[..., :F], training=training)
         x = self.post_merge_conv.forward(cat, training=training)
         x = self.post_merge_resnet.forward(x, training=training, x_absmax=self.post_merge_conv.out_absmax)
@@ -370,8 +386,20 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         dmerged = dcat[..., F:]
         blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks
         alpha = 1.0 / float(len(blocks) * F)
+        grads = {}
         for b in blocks:
-            b.backward_from(dmerged, alpha, d_initial)
+            g = b.backward_from(dmerged, alpha, d_initial)
+            if g is not None:
+                grads[b.f] = g if b.f not in grads else ops.axpby(1.0, g, 1.0, grads[b.f])
+        for f in sorted(grads, reverse=True):                      # the pyramid's adjoint: coarsest level first, each into its parent
+            parent = self._pyr[f][1]
+            if parent is None:
+                ops.pool2d_bwd(sv['initial'], grads[f], f, 'average', dx=d_initial, accumulate=True)
+            else:
+                if parent not in grads:
+                    grads[parent] = torch.zeros_like(self._pyr[parent][0])
+                ops.pool2d_bwd(self._pyr[parent][0], grads[f], f // parent, 'average', dx=grads[parent], accumulate=True)
+        self._pyr = None
         d = d_initial
         for i, c in enumerate(reversed(self.pre)):
             d = c.backward(d, need_dx=(i < len(self.pre) - 1), inplace=True)
