@@ -118,3 +118,69 @@ def test_fused_backward_shares_the_gradient_spectrum(k, Cin, Cout, mode):
     ref_dx, ref_dw = xt.grad.numpy(), wt.grad.numpy()
     assert np.linalg.norm(dx.cpu().numpy().transpose(0, 3, 1, 2) - ref_dx) / np.linalg.norm(ref_dx) < 3e-6
     assert np.linalg.norm(dw.cpu().numpy() - ref_dw) / np.linalg.norm(ref_dw) < 5e-6
+
+
+def test_random_narrow_shapes_through_the_packed_route():
+    """Twenty seeded random layers of <= 16 channels (2 / 4 / 8 tiles per work item): even and odd filters 4 ... 15, images from one tile
+    group up to a few, ragged last groups, every padding mode, N up to 3 - forward, data gradient and weight gradient of the fused backward
+    against fp64 autograd."""
+    from oracle import torch_twin
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(2024)
+    for case in range(20):
+        k = int(rng.integers(4, 16))
+        Cin, Cout = int(rng.integers(1, 17)), int(rng.integers(1, 17))
+        N, H, W = int(rng.integers(1, 4)), int(rng.integers(k + 3, 110)), int(rng.integers(k + 3, 130))
+        mode = ['CONSTANT', 'SYMMETRIC', 'REFLECT'][case % 3]
+        if k <= 5 and k in (3, 5):
+            continue                                       # the narrow vector-ALU kernels own 3x3 / 5x5 below 17 channels
+        x = rng.standard_normal((N, Cin, H, W)).astype(np.float32).astype(np.float64)
+        w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32).astype(np.float64)
+        dz = rng.standard_normal((N, Cout, H, W)).astype(np.float32).astype(np.float64)
+        xt, wt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True)
+        y = torch_twin.padded_conv2d(xt, wt, None, mode, 0.0, 'linear')
+        (y * torch.tensor(dz)).sum().backward()
+        pt, pb = np_ops.advanced_pad_amounts(k)
+        xd = torch.tensor(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), dtype=torch.float32, device='cuda')
+        dzd = torch.tensor(np.ascontiguousarray(dz.transpose(0, 2, 3, 1)), dtype=torch.float32, device='cuda')
+        wd = torch.tensor(w, dtype=torch.float32, device='cuda')
+        tag = 'case %d: k=%d %d->%d N=%d %dx%d %s' % (case, k, Cin, Cout, N, H, W, mode)
+        got = ops.conv2d_fwd(xd, wd, None, pad_top=pt, pad_left=pt, pad_mode=mode).cpu().numpy().transpose(0, 3, 1, 2)
+        ref = y.detach().numpy()
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-6, tag
+        dw = torch.empty_like(wd)
+        out = ops.conv2d_bwd_fused(xd, dzd, wd.shape, ops.flip_transpose_weights(wd), pad_top=pt, pad_left=pt, pad_mode=mode, dw=dw)
+        assert out is not None, tag
+        dx = out if mode == 'CONSTANT' else ops.pad_fold_bwd(out, (H, W), ((pt, pb), (pt, pb)), mode)
+        ref_dx, ref_dw = xt.grad.numpy(), wt.grad.numpy()
+        assert np.linalg.norm(dx.cpu().numpy().transpose(0, 3, 1, 2) - ref_dx) / np.linalg.norm(ref_dx) < 3e-6, tag
+        assert np.linalg.norm(dw.cpu().numpy() - ref_dw) / np.linalg.norm(ref_dw) < 5e-6, tag
+
+
+def test_random_wide_shapes():
+    """Twelve seeded random layers with 17 ... 64 input and 17 ... 32 output channels (one or two channel groups, ragged counts)."""
+    import torch.nn.functional as F
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(7)
+    for case in range(12):
+        k = int(rng.integers(2, 16))
+        Cin, Cout = int(rng.integers(17, 65)), int(rng.integers(17, 33))
+        N, H, W = int(rng.integers(1, 3)), int(rng.integers(k + 3, 90)), int(rng.integers(k + 3, 100))
+        x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+        w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+        dz = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
+        pt, pb = np_ops.advanced_pad_amounts(k)
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(F.pad(xt, (pt, pb, pt, pb)), wt.permute(3, 2, 0, 1))
+        (y * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+        xd = torch.tensor(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), device='cuda')
+        dzd = torch.tensor(np.ascontiguousarray(dz.transpose(0, 2, 3, 1)), device='cuda')
+        wd = torch.tensor(w, device='cuda')
+        tag = 'case %d: k=%d %d->%d N=%d %dx%d' % (case, k, Cin, Cout, N, H, W)
+        got = ops.conv2d_fwd(xd, wd, None, pad_top=pt, pad_left=pt).cpu().numpy().transpose(0, 3, 1, 2)
+        assert np.linalg.norm(got - y.detach().numpy()) / np.linalg.norm(y.detach().numpy()) < 2e-6, tag
+        dw = ops.conv2d_wgrad(xd, dzd, w.shape, pad_top=pt, pad_left=pt).cpu().numpy()
+        assert np.linalg.norm(dw - wt.grad.numpy()) / np.linalg.norm(wt.grad.numpy()) < 5e-6, tag
+        dx = ops.conv2d_fwd(dzd, ops.flip_transpose_weights(wd), None, pad_top=k - 1 - pt, pad_left=k - 1 - pt).cpu().numpy().transpose(0, 3, 1, 2)
+        assert np.linalg.norm(dx - xt.grad.numpy()) / np.linalg.norm(xt.grad.numpy()) < 2e-6, tag
