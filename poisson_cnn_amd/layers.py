@@ -228,7 +228,7 @@ class ConvUnit:
             return out
         need_a = training and (sc is not None or residual is not None)
         a = ops.empty((N, H, W, self.cout), x.device) if need_a else None
-        if training:
+        if training and ops.get_math_mode() == 'split_f16':       # only the split-mode weight gradient scales by max|x| / max|dz|
             self.out_absmax = ops.empty((1,), x.device)          # a fresh buffer per call: a layer may run several times per step
         ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
                        bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a, y_absmax=self.out_absmax)
@@ -258,7 +258,7 @@ class ConvUnit:
         if trivial and not self.use_bias:
             dz = dy
         else:
-            if not trivial:
+            if not trivial and ops.get_math_mode() == 'split_f16':
                 amax = ops.empty((1,), dy.device)             # fresh per call: read later by the side-stream weight gradient
             ops.epilogue_bwd(dy, a if (self.act != 'linear' or sc is not None) else None, act=self.act, bn_scale=sc, dz=None if trivial else dz,
                              dbias=g[self.name + '/bias'] if self.use_bias else None, s_dy_a=s1, s_dy=s2, ws=self.ctx.ws, dz_absmax=amax)
