@@ -167,12 +167,15 @@ __global__ void spp_max_bwd_kernel(int N, int64_t per, int nb, const int32_t* __
 
 // ---------------------------------------------------------------- loss
 // one workgroup per sample: out[n] = {sum|p-t|, sum (p-t)^2, sum G (p-t)^2, max|t|}
+// per-sample sums of |d|, d^2, G (t - p)^lp and max|t|: LOSS_SPLITS workgroups per sample, combined in a fixed order by a second launch
+constexpr int LOSS_SPLITS = 64;
 __global__ __launch_bounds__(1024) void loss_partials_kernel(int64_t hw, const float* __restrict__ pred, const float* __restrict__ tgt,
-                                                             const float* __restrict__ G, float lp, float* __restrict__ out) {
+                                                             const float* __restrict__ G, float lp, float* __restrict__ part) {
   __shared__ float red[4][1024];
-  const int n = blockIdx.x;
+  const int n = blockIdx.y, sp = blockIdx.x;
+  const int64_t per = (hw + LOSS_SPLITS - 1) / LOSS_SPLITS, q0 = sp * per, q1 = q0 + per < hw ? q0 + per : hw;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, mx = 0.f;
-  for (int64_t q = threadIdx.x; q < hw; q += blockDim.x) {
+  for (int64_t q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
     const float t = tgt[(int64_t)n * hw + q], d = pred[(int64_t)n * hw + q] - t;
     s0 += fabsf(d); s1 += d * d;
     if (G) s2 += G[q] * (lp == 2.0f ? d * d : powf(-d, lp));          // integral_loss.py:153: (y_true - y_pred) ** Lp_norm_power
@@ -187,7 +190,21 @@ __global__ __launch_bounds__(1024) void loss_partials_kernel(int64_t hw, const f
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[4 * n] = red[0][0]; out[4 * n + 1] = red[1][0]; out[4 * n + 2] = red[2][0]; out[4 * n + 3] = red[3][0]; }
+  if (threadIdx.x == 0) {
+    float* o = part + ((int64_t)n * LOSS_SPLITS + sp) * 4;
+    o[0] = red[0][0]; o[1] = red[1][0]; o[2] = red[2][0]; o[3] = red[3][0];
+  }
+}
+
+__global__ void loss_partials_final_kernel(const float* __restrict__ part, float* __restrict__ out) {
+  const int n = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, mx = 0.f;
+  for (int sp = 0; sp < LOSS_SPLITS; ++sp) {
+    const float* p = part + ((int64_t)n * LOSS_SPLITS + sp) * 4;
+    s0 += p[0]; s1 += p[1]; s2 += p[2]; mx = fmaxf(mx, p[3]);
+  }
+  out[4 * n] = s0; out[4 * n + 1] = s1; out[4 * n + 2] = s2; out[4 * n + 3] = mx;
 }
 
 __global__ void loss_bwd_kernel(int N, int64_t hw, const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ G,
@@ -372,7 +389,17 @@ extern "C" int pcnn_spp_max_bwd(pcnn_handle h, int N, int H, int W, int C, int n
 
 extern "C" int pcnn_loss_partials_p(pcnn_handle h, int N, int64_t hw, const float* pred, const float* target, const float* G, float lp_power, float* out) {
   PCNN_REQUIRE(h, h && pred && target && out, "pcnn_loss_partials: null argument");
-  hipLaunchKernelGGL(loss_partials_kernel, dim3(N), dim3(1024), 0, h->stream, hw, pred, target, G, lp_power, out);
+  // scratch for the split sums: N * 64 * 4 floats from the handle's filter scratch (stream-ordered with every other user of it)
+  const size_t need = (size_t)N * LOSS_SPLITS * 4 * sizeof(float);
+  if (h->scratch_bytes < need) {
+    if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+    const size_t cap = need < (4u << 20) ? (4u << 20) : need;
+    if (hipMalloc(&h->scratch, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_loss_partials: cannot allocate %zu B of scratch", cap);
+    h->scratch_bytes = cap;
+  }
+  float* part = static_cast<float*>(h->scratch);
+  hipLaunchKernelGGL(loss_partials_kernel, dim3(LOSS_SPLITS, N), dim3(1024), 0, h->stream, hw, pred, target, G, lp_power, part);
+  hipLaunchKernelGGL(loss_partials_final_kernel, dim3(N), dim3(64), 0, h->stream, part, out);
   PCNN_CHECK_LAUNCH(h, "pcnn_loss_partials");
   return 0;
 }
