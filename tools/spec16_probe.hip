@@ -2,7 +2,7 @@
 // index in a 16-wide N dimension (v_mfma_f32_16x16x4_f32) instead of 32 lanes.  The intermediate U[y][s][c] of a 32 x 32 tile is then 64 KB,
 // so TWO workgroups fit a CU and one workgroup's barrier / transition gaps are filled by the other's MFMAs - the structural limit
 // DESIGN.md section 4.1 measures (matrix pipes busy 48 % with one 128 KB workgroup per CU).
-//   hipcc -O3 --offload-arch=gfx950 tools/spec16_probe.hip -o tools/spec16_probe && tools/spec16_probe [waves_per_wg=4] [wgs_per_cu=2]
+//   hipcc -O3 --offload-arch=gfx950 tools/spec16_probe.hip -o tools/spec16_probe && tools/spec16_probe [waves_per_wg=4] [wgs_per_cu=2] [pipeline=1] [wide_loads=1]
 // Prints the time per 8 192 tiles x 32 channels (the library's spec_fwd_kernel: 0.44 ms) and checks one tile against a host DFT.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -17,10 +17,20 @@ constexpr int TAB_G = 0, TAB_F2 = 1024, TAB_FLOATS = 3072;
 struct P { const float* x; float* sp; const float* tab; int H, W, ld, tiles_x, tiles_y, V, ntile, cgroups; };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+// 4 x 4 transpose inside every quad of lanes: register k of lane 4j + i holds M[k][i] before, M[i][k] after
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int lane) {
+  const bool i1 = lane & 2, i0 = lane & 1;
+  { const float y = dpp_quad<0x4E>(i1 ? v0 : v2); v0 = i1 ? y : v0; v2 = i1 ? v2 : y; }
+  { const float y = dpp_quad<0x4E>(i1 ? v1 : v3); v1 = i1 ? y : v1; v3 = i1 ? v3 : y; }
+  { const float y = dpp_quad<0xB1>(i0 ? v0 : v1); v0 = i0 ? y : v0; v1 = i0 ? v1 : y; }
+  { const float y = dpp_quad<0xB1>(i0 ? v2 : v3); v2 = i0 ? y : v2; v3 = i0 ? v3 : y; }
+}
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // NW waves per workgroup; lane = (q = lane / 16: K sub-index, n = lane % 16: A row / B column = channel)
-template <int NW>
+template <int NW, bool PIPE, bool WIDE>
 __global__ __launch_bounds__(64 * NW, 2) void fwd16_kernel(P p) {
   extern __shared__ __attribute__((aligned(16))) float U[];                  // U[(y*32 + s)*16 + c]
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
@@ -45,21 +55,43 @@ __global__ __launch_bounds__(64 * NW, 2) void fwd16_kernel(P p) {
     const int nimg = t / p.tiles_y;
     const float* img = p.x + (int64_t)nimg * p.H * p.W * p.ld + 16 * g + n;
     const int wy0 = ty * p.V, wx0 = tx * p.V;
+    // WIDE: one dwordx4 per lane fetches four channels of ONE pixel; an in-quad 4 x 4 transpose turns four such loads (the quad's lanes
+    // take four different pixels = K steps) into the MFMA operand layout (lane = channel, register = K step): 2 loads instead of 8 per row
     unsigned off[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) off[ks] = (unsigned)(min(wx0 + 4 * ks + kq, p.W - 1) * p.ld);
+    unsigned offw[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) offw[m] = (unsigned)(min(wx0 + 4 * (4 * m + (n & 3)) + kq, p.W - 1) * p.ld);
+    const float* imgw = p.x + (int64_t)nimg * p.H * p.W * p.ld + 16 * g + (n & ~3);
     // ---- x axis: two 16-row blocks of the real -> half-complex matrix, K = 32 pixels in 8 steps of 4
     float v[2][8];
     auto load_row = [&](int y, float (&d)[8]) {
-      const float* row = img + (int64_t)min(wy0 + y, p.H - 1) * p.W * p.ld;
+      if (WIDE) {
+        const float* row = imgw + (int64_t)min(wy0 + y, p.H - 1) * p.W * p.ld;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) d[ks] = row[off[ks]];
+        for (int m = 0; m < 2; ++m) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(row + offw[m]);
+          d[4 * m] = q[0]; d[4 * m + 1] = q[1]; d[4 * m + 2] = q[2]; d[4 * m + 3] = q[3];
+        }
+      } else {
+        const float* row = img + (int64_t)min(wy0 + y, p.H - 1) * p.W * p.ld;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) d[ks] = row[off[ks]];
+      }
+    };
+    auto fix_row = [&](float (&d)[8]) {                                        // after the loads have landed: the two quad transposes
+      if (WIDE) {
+        quad_transpose(d[0], d[1], d[2], d[3], lane);
+        quad_transpose(d[4], d[5], d[6], d[7], lane);
+      }
     };
     load_row(wave, v[0]);
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
       const int y = wave + NW * j;
       if (j + 1 < RPW) load_row(y + NW, v[(j + 1) & 1]);
+      fix_row(v[j & 1]);
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
@@ -76,32 +108,51 @@ __global__ __launch_bounds__(64 * NW, 2) void fwd16_kernel(P p) {
     // ---- y axis: wave (qq, par) takes complex columns fx = 1 + qq, 1 + qq + NQ, ... for its parity; the last column set also takes one
     // real column (0 for par = 0, 16 for par = 1)
     float* out = p.sp + (int64_t)item * ROWS * 16;
-#pragma unroll 1
-    for (int fx = 1 + qq; fx <= 15; fx += NQ) {
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      float b[8];
+    auto load_col = [&](int fx, float (&b)[8]) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int k = 4 * ks + kq, y = k & 15, sc = k < 16 ? fx : 16 + fx;
         const float lo = U[(y * 32 + sc) * 16 + n], hi = U[((y + 16) * 32 + sc) * 16 + n];
         b[ks] = par ? lo - hi : lo + hi;
       }
+    };
+    // two accumulator sets: the chain of column c + 1 is queued BEFORE the stores of column c are issued, so the matrix pipe keeps running
+    // while this wave waits for column c's results and writes them (PIPE); without PIPE: read, multiply, store, one column at a time
+    auto chain = [&](const float (&b)[8], f32x4& a0, f32x4& a1) {
+      a0 = (f32x4){0.f, 0.f, 0.f, 0.f}; a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         a0 = mfma16(freg[0][ks], b[ks], a0);
         a1 = mfma16(freg[1][ks], b[ks], a1);
       }
+    };
+    auto store_col = [&](int fx, const f32x4& a0, const f32x4& a1) {
       float* o = out + (int64_t)(64 + 64 * (fx - 1) + par) * 16 + n;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {                                            // accumulator row 16 part + m -> spectrum row 32 part + 2 m + par
         o[(2 * (4 * kq + r)) * 16] = a0[r];
         o[(32 + 2 * (4 * kq + r)) * 16] = a1[r];
       }
+    };
+    float b[8];
+    f32x4 p0, p1, c0, c1;
+    load_col(1 + qq, b);
+    chain(b, p0, p1);
+#pragma unroll 1
+    for (int fx = 1 + qq; fx <= 15; fx += NQ) {
+      const bool more = fx + NQ <= 15;
+      if (PIPE) {
+        if (more) { load_col(fx + NQ, b); chain(b, c0, c1); }
+        store_col(fx, p0, p1);
+        p0 = c0; p1 = c1;
+      } else {
+        store_col(fx, p0, p1);
+        if (more) { load_col(fx + NQ, b); chain(b, p0, p1); }
+      }
     }
     if (qq == NQ - 1) {
       const int col = par ? 16 : 0;
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      float b[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) b[ks] = U[((4 * ks + kq) * 32 + col) * 16 + n];
 #pragma unroll
@@ -156,11 +207,13 @@ int main(int argc, char** argv) {
   (void)ntile_all;
   const size_t lds = (size_t)T * T * 16 * 4;
   const int grid = 256 * per_cu;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fwd16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fwd16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool pipe = argc > 3 ? atoi(argv[3]) != 0 : true, wide = argc > 4 ? atoi(argv[4]) != 0 : true;
+#define VARIANT(NWv, Pv, Wv) if (NW == NWv && pipe == Pv && wide == Wv) { \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fwd16_kernel<NWv, Pv, Wv>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((fwd16_kernel<NWv, Pv, Wv>), dim3(grid), dim3(64 * NWv), lds, 0, p); }
   auto launch = [&]() {
-    if (NW == 4) hipLaunchKernelGGL(fwd16_kernel<4>, dim3(grid), dim3(256), lds, 0, p);
-    else hipLaunchKernelGGL(fwd16_kernel<8>, dim3(grid), dim3(512), lds, 0, p);
+    VARIANT(4, true, true) VARIANT(4, true, false) VARIANT(4, false, true) VARIANT(4, false, false)
+    VARIANT(8, true, true) VARIANT(8, true, false) VARIANT(8, false, true) VARIANT(8, false, false)
   };
   launch();
   CK(hipDeviceSynchronize());
@@ -172,7 +225,7 @@ int main(int argc, char** argv) {
   CK(hipEventSynchronize(e1));
   float ms = 0.f;
   CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("fwd16 (%d waves / workgroup, %d workgroups / CU, 64 KB LDS each): %.3f ms per 8192 tiles x 32 channels (library spec_fwd_kernel: 0.44 ms)\n", NW, per_cu, ms / 10);
+  printf("fwd16 (%d waves / workgroup, %d workgroups / CU, 64 KB LDS each, y-axis pipelining %s, wide loads %s): %.3f ms per 8192 tiles x 32 channels (library spec_fwd_kernel: 0.44 ms)\n", NW, per_cu, pipe ? "on" : "off", wide ? "on" : "off", ms / 10);
   // ---- check item 5 (tile 2, channel group 1) against a host DFT
   const int item = 5, g = item % 2, t = item / 2, tx = t % tiles, ty = (t / tiles) % tiles;
   std::vector<float> hs((size_t)ROWS * 16);
