@@ -115,3 +115,25 @@ def test_dataset_host_samplers():
     assert n == {'rhs_max_magnitude': 1.0, 'max_domain_size_squared': True, 'soln_max_magnitude': False}
     with pytest.raises(AssertionError):
         ds._range2([3, 1], 2)
+
+
+def test_channels_last_views_of_one_channel_tensors():
+    """data_format='channels_last' at the model API is a reshape: (N,H,W,1) <-> (N,1,H,W), (N,L,1) <-> (N,1,L); dx arrays pass through."""
+    import numpy as np
+    import torch
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    m = Homogeneous_Poisson_NN_Legacy(**dict(configs.hpnn_tiny()['model'], data_format='channels_last'), device='cpu')
+    x = torch.arange(2 * 5 * 7, dtype=torch.float32).reshape(2, 5, 7, 1)
+    cf = m._cf(x)
+    assert tuple(cf.shape) == (2, 1, 5, 7) and cf.data_ptr() == x.data_ptr()           # the same memory
+    assert torch.equal(m._cl(cf), x)
+    assert tuple(m._cf(np.zeros((3, 9, 1), dtype=np.float32)).shape) == (3, 1, 9)
+    dx = torch.ones(2, 1)
+    assert m._cf(dx) is dx
+    with pytest.raises(ValueError):
+        m._cf(torch.zeros(2, 5, 7, 3))
+    m2 = Homogeneous_Poisson_NN_Legacy(**configs.hpnn_tiny()['model'], device='cpu')
+    assert m2._cf(x) is x                                                                # channels_first: untouched
+    with pytest.raises(ValueError):
+        Homogeneous_Poisson_NN_Legacy(**dict(configs.hpnn_tiny()['model'], data_format='NHWC'), device='cpu')
