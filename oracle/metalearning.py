@@ -61,10 +61,11 @@ def mresnet(p, name, x, d, k, c, acts, use_bn, **ckw):
     return mconv(p, name + '/conv2', x + o, d, k, c, c, acts, **ckw)
 
 
-def mbottleneck(p, name, x, d, *, kind, f, up, filters, k, n_convs, acts, mode, value, act, method, pool, use_resnet, use_bn, kdown=None, kdeconv=None, dacts=None):
+def mbottleneck(p, name, x, d, *, kind, f, up, filters, k, n_convs, acts, mode, value, act, method, pool, use_resnet, use_bn, kdown=None, kdeconv=None, dacts=None,
+                use_bias=True, deconv_use_bias=True):
     H, W = x.shape[2], x.shape[3]
     cin = x.shape[1]
-    ckw = dict(same=True, mode=mode, value=value, act=act)
+    ckw = dict(same=True, mode=mode, value=value, act=act, use_bias=use_bias)
     n_layers = 0
     if method == 'conv':
         o = mconv(p, name + '/downsample', x, d, kdown if kdown is not None else k, cin, filters, acts, stride=f, **ckw)
@@ -86,6 +87,6 @@ def mbottleneck(p, name, x, d, *, kind, f, up, filters, k, n_convs, acts, mode, 
         i += 1
     out_hw = (int((H / f) * up), int((W / f) * up))
     if kind == 'deconv':
-        o = mdeconv(p, name + '/deconv', o, d, kdeconv, filters, filters, dacts, out_hw)
+        o = mdeconv(p, name + '/deconv', o, d, kdeconv, filters, filters, dacts, out_hw, use_bias=deconv_use_bias)
         return _bn(p, name + '/bn', o) if use_bn else o
     return T.resize2d(o, out_hw, 'bilinear')

@@ -137,3 +137,53 @@ def pcnn_end_to_end_tiny():
     cfg['dataset'].update(batch_size=2, batches_per_epoch=2, random_output_shape_range=[[40, 56], [40, 56]])
     cfg['training']['loss_parameters']['integral_loss_config']['n_quadpts'] = 11
     return cfg
+
+
+def hpnn_metalearning():
+    """train/hpnn_train.py layout (the model section carries model_type) for Homogeneous_Poisson_NN_Metalearning.  No experiments/*.json ships
+    for that script; the hyper-parameters are those of the model file's own example (models/Homogeneous_Poisson_NN_Metalearning.py:334-377),
+    training and dataset sections are hpnn.json's (the script draws reverse_poisson_dataset_generator samples, hpnn_train.py:33)."""
+    dense = ['tf.nn.tanh', 'tf.nn.tanh', 'linear']
+    model = {
+        'model_type': 'cnn_metalearning', 'ndims': 2, 'use_batchnorm': True, 'bottleneck_upsampling': 'multilinear',
+        'input_normalization': {'rhs_max_magnitude': True}, 'output_scaling': {'max_domain_size_squared': True},
+        'pre_bottleneck_convolutions_config': {
+            'filters': [4, 6, 8], 'kernel_sizes': [19, 17, 15], 'padding_mode': 'CONSTANT', 'conv_activation': 'tf.nn.leaky_relu',
+            'dense_activations': dense, 'use_bias': False, 'bias_initializer': 'zeros', 'pre_output_dense_units': [8, 16]},
+        'bottleneck_config': {
+            'downsampling_factors': [1, 2, 3, 4], 'upsampling_factors': [1, 2, 3, 4], 'filters': 8, 'conv_kernel_sizes': [13, 13, 13, 13], 'n_convs': [2, 2, 2, 2],
+            'conv_padding_mode': 'CONSTANT', 'conv_conv_activation': 'tf.nn.leaky_relu', 'conv_dense_activation': dense, 'conv_pre_output_dense_units': [8, 16],
+            'conv_use_bias': False, 'use_resnet': True, 'conv_downsampling_kernel_sizes': [3, 2, 3, 4]},
+        'final_convolutions_config': {
+            'filters': [8, 6, 4, 3, 2, 1], 'kernel_sizes': [11, 7, 5, 5, 3, 3], 'padding_mode': 'CONSTANT', 'conv_activation': 'tf.nn.tanh',
+            'dense_activations': dense, 'use_bias': False, 'pre_output_dense_units': [8, 16], 'bias_initializer': 'zeros', 'final_regular_conv_stages': 4},
+    }
+    base = hpnn()
+    return {'model': model, 'dataset': base['dataset'], 'training': base['training']}
+
+
+def hpnn_metalearning_tiny():
+    cfg = hpnn_metalearning()
+    m = cfg['model']
+    m['pre_bottleneck_convolutions_config'].update(filters=[4, 6], kernel_sizes=[5, 3], pre_output_dense_units=[6, 8])
+    m['bottleneck_config'].update(downsampling_factors=[1, 2, 3], upsampling_factors=[1, 2, 3], filters=5, conv_kernel_sizes=[3, 3, 3], n_convs=[2, 2, 2],
+                                  conv_pre_output_dense_units=[6, 8], conv_downsampling_kernel_sizes=[3, 2, 3])
+    m['final_convolutions_config'].update(filters=[6, 4, 2, 1], kernel_sizes=[3, 3, 3, 3], pre_output_dense_units=[6, 8], final_regular_conv_stages=2)
+    cfg['dataset'].update(batch_size=3, batches_per_epoch=2, random_output_shape_range=[[40, 56], [40, 56]])
+    cfg['training']['loss_parameters']['integral_loss_config']['n_quadpts'] = 11
+    return cfg
+
+
+def hpnn_plain_tiny():
+    """train/hpnn_train.py with model_type 'cnn': Homogeneous_Poisson_NN (plain convolutions, the same chained-bottleneck graph)."""
+    cfg = hpnn_metalearning_tiny()
+    cfg['model'] = {
+        'model_type': 'cnn', 'ndims': 2, 'use_batchnorm': True, 'bottleneck_upsampling': 'deconv', 'output_scaling': {'max_domain_size_squared': True},
+        'pre_bottleneck_convolutions_config': {'filters': [4, 6], 'kernel_sizes': [5, 3], 'padding_mode': 'SYMMETRIC', 'activation': 'tf.nn.leaky_relu', 'use_bias': True},
+        'bottleneck_config': {'downsampling_factors': [1, 2, 4], 'upsampling_factors': [1, 2, 4], 'filters': 5, 'conv_kernel_sizes': [3, 3, 3], 'n_convs': [2, 2, 2],
+                              'deconv_kernel_sizes': [1, 2, 4], 'padding_mode': 'SYMMETRIC', 'conv_activation': 'tf.nn.leaky_relu', 'conv_use_bias': True,
+                              'use_resnet': True, 'downsampling_method': 'pool', 'pool_downsampling_method': 'average'},
+        'final_convolutions_config': {'filters': [6, 3, 1], 'kernel_sizes': [3, 3, 3], 'padding_mode': 'CONSTANT', 'activation': 'tf.nn.tanh', 'use_bias': True},
+    }
+    cfg['dataset'].update(random_output_shape_range=[[40, 56], [40, 56]])
+    return cfg

@@ -190,7 +190,8 @@ def main(argv=None):
     p.add_argument('--learning_rate', type=str, default=None)
     p.add_argument('--epochs', type=int, default=None)
     p.add_argument('--model', type=lambda x: str(x).lower(), default='hpnn', choices=['hpnn', 'dbcnn', 'pcnn'],
-                   help='hpnn: train/hpnn_legacy_train.py; dbcnn: train/dbcnn_legacy_train.py; pcnn: train/pcnn_end_to_end.py')
+                   help='hpnn: train/hpnn_legacy_train.py (train/hpnn_train.py when the model section carries model_type); dbcnn: train/dbcnn_legacy_train.py; '
+                        'pcnn: train/pcnn_end_to_end.py')
     args = p.parse_args(argv)
     if args.dataset_type not in ('numerical', 'analytical'):
         raise ValueError('Invalid dataset type. Received: ' + args.dataset_type)
@@ -210,6 +211,15 @@ def main(argv=None):
         dataset = numerical_dataset_generator(randomize_boundary_smoothness=True, exclude_zero_boundaries=False, nonzero_boundaries=['left', 'right', 'top', 'bottom'],
                                               rhses='random', return_boundaries=True, return_dx=True, return_rhs=True, **dcfg)
         model = Poisson_CNN_Legacy(Homogeneous_Poisson_NN_Legacy(**config['hpnn_model']), Dirichlet_BC_NN_Legacy_2(**config['dbcnn_model']))
+    elif 'model_type' in config['model']:      # train/hpnn_train.py:23-33: the config names the model class; analytic (reverse) dataset
+        from .hpnn_models import Homogeneous_Poisson_NN, Homogeneous_Poisson_NN_Metalearning
+        mcfg = dict(config['model'])
+        model_type = mcfg.pop('model_type')
+        classes = {'cnn_metalearning': Homogeneous_Poisson_NN_Metalearning, 'cnn': Homogeneous_Poisson_NN}
+        if model_type not in classes:
+            raise NotImplementedError('model_type %r (built: %s)' % (model_type, sorted(classes)))
+        dataset = reverse_poisson_dataset_generator(**dcfg)
+        model = classes[model_type](**mcfg)
     else:
         neumann = config['model'].get('bc_type', 'dirichlet').lower() == 'neumann'
         if args.dataset_type == 'numerical':

@@ -137,3 +137,35 @@ def test_channels_last_views_of_one_channel_tensors():
     assert m2._cf(x) is x                                                                # channels_first: untouched
     with pytest.raises(ValueError):
         Homogeneous_Poisson_NN_Legacy(**dict(configs.hpnn_tiny()['model'], data_format='NHWC'), device='cpu')
+
+
+def test_chain_models_structure_and_oracle_names():
+    """Homogeneous_Poisson_NN_Metalearning / Homogeneous_Poisson_NN (hpnn_models.py): the parameter structure builds on the CPU from the
+    train/hpnn_train.py-style configs, the oracle restatement consumes exactly those names (every trainable one reaches the output), and the
+    constructor errors are the reference's."""
+    import copy
+    import pytest
+    import torch
+    from oracle import hpnn_chain as och
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.hpnn_models import Homogeneous_Poisson_NN, Homogeneous_Poisson_NN_Metalearning
+    rng = np.random.default_rng(0)
+    for cfg, cls, fn in ((configs.hpnn_metalearning_tiny(), Homogeneous_Poisson_NN_Metalearning, och.metalearning_forward),
+                         (configs.hpnn_plain_tiny(), Homogeneous_Poisson_NN, och.plain_forward)):
+        kw = dict(cfg['model'])
+        kw.pop('model_type')
+        model = cls(**copy.deepcopy(kw), device='cpu')
+        blocks = [b.f for b in model.bottleneck_blocks]
+        assert blocks == sorted(blocks, reverse=True)
+        p = {n: torch.tensor(model.store.w[n].numpy().astype(np.float64) * 1.3 + (0.1 if n.endswith('variance') else 0.0),
+                             requires_grad=not n.endswith(('moving_mean', 'moving_variance'))) for n in model.store.names}
+        rhs, dx = torch.tensor(rng.uniform(-1, 1, (2, 1, 24, 24))), torch.tensor(rng.uniform(5e-3, 5e-2, (2, 2)))
+        y = fn(p, kw, rhs, dx)
+        assert tuple(y.shape) == (2, 1, 24, 24)
+        y.sum().backward()
+        assert [n for n in model.store.trainable_names() if p[n].grad is None] == []
+        with pytest.raises(ValueError):
+            cls(**{**copy.deepcopy(kw), 'bottleneck_config': None}, device='cpu')
+        with pytest.raises(ValueError):
+            cls(**{**copy.deepcopy(kw), 'bottleneck_upsampling': 'bicubic'}, device='cpu')
+    assert Homogeneous_Poisson_NN_Metalearning(**{k: v for k, v in configs.hpnn_metalearning()['model'].items() if k != 'model_type'}, device='cpu').count_params() == 5650048
