@@ -32,6 +32,14 @@ struct SmallParams {
   int ld_res, ld_act, tiles_x, tiles_y, vec_in, vec_out;
 };
 
+// tf.pad index map without control flow (selects only): a load whose address depends on it can be issued unconditionally, so that the
+// loads of an unrolled staging loop are all in flight together (with branches every load sits in its own block behind an s_waitcnt vmcnt(0))
+__device__ __forceinline__ int pad_index_sel(int i, int n, int mode) {
+  const int refl = mode == PCNN_PAD_SYMMETRIC ? (i < 0 ? -i - 1 : 2 * n - 1 - i) : (i < 0 ? -i : 2 * n - 2 - i);
+  const int rc = min(max(refl, 0), n - 1);
+  return (unsigned)i < (unsigned)n ? i : (mode == PCNN_PAD_CONSTANT ? -1 : rc);
+}
+
 // stages the (STH + K - 1) x (STW + K - 1) halo tile of image n as [pixel][CI (stride CIS)] floats, padding applied
 template <int K, int CI, int CIS = lds_stride(CI)>
 __device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float* __restrict__ xin, int H, int W, int Cin, int ldx, int y0, int x0, int pt, int pl,
@@ -58,6 +66,32 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float*
   }
 }
 
+// The same tile, for whole 16-byte pieces (vec_in, Cin % 4 == 0), with ALL of a thread's loads in flight together: addresses are formed without
+// control flow (pad_index_sel; padding pieces read a dummy address and are replaced when written to LDS).  The loop above compiles to one
+// load per thread in flight - load, s_waitcnt vmcnt(0), ds_write, next - i.e. the tile's HBM latency is paid ceil(pieces / 256) times.
+template <int K, int CI, int CIS = lds_stride(CI)>
+__device__ __forceinline__ void stage_tile_batched(float* __restrict__ lds, const float* __restrict__ xin, int H, int W, int ldx, int y0, int x0, int pt, int pl,
+                                                   int pad_mode, float pad_value) {
+  constexpr int TR = STH + K - 1, TC = STW + K - 1, Q = CI / 4, TOTAL = TR * TC * Q, NX = (TOTAL + 255) / 256;
+  f32x4 v[NX];
+  unsigned okm = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int u = threadIdx.x + i * 256, q = u % Q, pix = u / Q, r = pix / TC, c = pix - r * TC;
+    const int sy = pad_index_sel(y0 + r - pt, H, pad_mode), sx = pad_index_sel(x0 + c - pl, W, pad_mode);
+    const bool ok = u < TOTAL && sy >= 0 && sx >= 0;
+    const int64_t idx = ok ? ((int64_t)sy * W + sx) * ldx + 4 * q : 0;
+    v[i] = *reinterpret_cast<const f32x4*>(xin + idx);
+    okm |= ok ? (1u << i) : 0u;
+  }
+  const f32x4 padv = {pad_value, pad_value, pad_value, pad_value};
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int u = threadIdx.x + i * 256;
+    if (u < TOTAL) *reinterpret_cast<f32x4*>(lds + (u / Q) * CIS + 4 * (u % Q)) = ((okm >> i) & 1u) ? v[i] : padv;
+  }
+}
+
 // launch bound: the HBM-bound shapes (CI * CO <= 64) are compiled for 8 waves per SIMD (<= 64 VGPRs) - what hides the load -> compute ->
 // store latency chain of a tile is the number of resident workgroups, not instruction-level tricks (a persistent variant with register
 // prefetch of the next tile and a 4-rows-per-thread variant were measured: 2.3x and 1.1x SLOWER)
@@ -70,7 +104,8 @@ __global__ __launch_bounds__(256, (CI * CO <= 64 ? 8 : 4)) void conv_small_fwd_k
   const int ty = tile % p.tiles_y;
   const int n = tile / p.tiles_y;
   const int y0 = ty * STH, x0 = tx * STW;
-  stage_tile<K, CI>(lds, p.x + (int64_t)n * p.H * p.W * p.ldx, p.H, p.W, p.Cin, p.ldx, y0, x0, p.pt, p.pl, p.pad_mode, p.pad_value, p.vec_in);
+  if (p.vec_in && (p.Cin & 3) == 0) stage_tile_batched<K, CI>(lds, p.x + (int64_t)n * p.H * p.W * p.ldx, p.H, p.W, p.ldx, y0, x0, p.pt, p.pl, p.pad_mode, p.pad_value);
+  else stage_tile<K, CI>(lds, p.x + (int64_t)n * p.H * p.W * p.ldx, p.H, p.W, p.Cin, p.ldx, y0, x0, p.pt, p.pl, p.pad_mode, p.pad_value, p.vec_in);
   __syncthreads();
   const int r = threadIdx.x >> 5, c = threadIdx.x & 31;
   float acc[CO];
@@ -215,6 +250,9 @@ __global__ __launch_bounds__(64 * K) void conv_small_wgrad_kernel(SmallWgradPara
   const bool b_ok = ch < CO;
   // this thread's staging items: NX 16-byte pieces of the input halo tile, NZ of the dz tile (tile-independent coordinates)
   f32x4 xr[NX], zr[NZ];
+  unsigned xok = ~0u, zok = ~0u;                            // fast path: bit i clear = piece i is padding / outside the image (its load read a dummy address)
+  const bool fast = p.vec_in && p.vec_dz && (p.Cin & 3) == 0 && (p.Cout & 3) == 0;
+  const f32x4 padv = {p.pad_value, p.pad_value, p.pad_value, p.pad_value}, zero4 = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int tile) {                              // global -> registers; the loads stay in flight under the previous tile's MFMAs
     int tt = tile;
     const int tx = tt % p.tiles_x; tt /= p.tiles_x;
@@ -223,6 +261,24 @@ __global__ __launch_bounds__(64 * K) void conv_small_wgrad_kernel(SmallWgradPara
     const int y0 = ty * STH, x0 = tx * STW;
     const float* xin = p.x + (int64_t)n * p.H * p.W * p.ldx;
     const float* zin = p.dz + (int64_t)n * p.Ho * p.Wo * p.lddz;
+    if (fast) {                                             // whole 16-byte pieces: branch-free addresses, every load of the tile in flight at once
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int u = tid + i * NT, q = u % QX, pix = u / QX, r = pix / TC, c = pix - r * TC;
+        const int sy = pad_index_sel(y0 + r - p.pt, p.H, p.pad_mode), sx = pad_index_sel(x0 + c - p.pl, p.W, p.pad_mode);
+        const bool ok = u < TR * TC * QX && sy >= 0 && sx >= 0;
+        xr[i] = *reinterpret_cast<const f32x4*>(xin + (ok ? ((int64_t)sy * p.W + sx) * p.ldx + 4 * q : 0));
+        xok = ok ? (xok | (1u << i)) : (xok & ~(1u << i));
+      }
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) {
+        const int u = tid + i * NT, q = u % QZ, pix = u / QZ, r = pix / STW, c = pix - r * STW;
+        const bool ok = u < STH * STW * QZ && y0 + r < p.Ho && x0 + c < p.Wo;
+        zr[i] = *reinterpret_cast<const f32x4*>(zin + (ok ? ((int64_t)(y0 + r) * p.Wo + x0 + c) * p.lddz + 4 * q : 0));
+        zok = ok ? (zok | (1u << i)) : (zok & ~(1u << i));
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int u = tid + i * NT, q = u % QX, pix = u / QX, r = pix / TC, c = pix - r * TC;
@@ -266,12 +322,12 @@ __global__ __launch_bounds__(64 * K) void conv_small_wgrad_kernel(SmallWgradPara
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int u = tid + i * NT;
-      if (u < TR * TC * QX) *reinterpret_cast<f32x4*>(xs + (u / QX) * CIS + 4 * (u % QX)) = xr[i];
+      if (u < TR * TC * QX) *reinterpret_cast<f32x4*>(xs + (u / QX) * CIS + 4 * (u % QX)) = ((xok >> i) & 1u) ? xr[i] : padv;
     }
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
       const int u = tid + i * NT;
-      if (u < STH * STW * QZ) *reinterpret_cast<f32x4*>(zs + (u / QZ) * COS + 4 * (u % QZ)) = zr[i];
+      if (u < STH * STW * QZ) *reinterpret_cast<f32x4*>(zs + (u / QZ) * COS + 4 * (u % QZ)) = ((zok >> i) & 1u) ? zr[i] : zero4;
     }
     __syncthreads();
     if (tile + p.S < p.ntiles) fetch(tile + p.S);

@@ -127,6 +127,18 @@ __global__ __launch_bounds__(64 * NW, 2) void fwd16_kernel(P p) {
       }
     };
     auto store_col = [&](int fx, const f32x4& a0, const f32x4& a1) {
+#ifdef ST16
+      // 16-byte stores: an in-quad transpose gives lane (kq, n = 4 j + i) accumulator row 4 kq + i with channels 4 j .. 4 j + 3 - two stores per
+      // column and lane instead of eight.  Together with the wide loads a wave then has ~34 vector-memory operations per item in flight:
+      // below the 63 that the 6-bit vmcnt counter of gfx9 can tell apart
+      float t0[4] = {a0[0], a0[1], a0[2], a0[3]}, t1[4] = {a1[0], a1[1], a1[2], a1[3]};
+      quad_transpose(t0[0], t0[1], t0[2], t0[3], lane);
+      quad_transpose(t1[0], t1[1], t1[2], t1[3], lane);
+      float* o4 = out + (int64_t)(64 + 64 * (fx - 1) + par) * 16 + (n & ~3);
+      *reinterpret_cast<f32x4*>(o4 + (2 * (4 * kq + (n & 3))) * 16) = (f32x4){t0[0], t0[1], t0[2], t0[3]};
+      *reinterpret_cast<f32x4*>(o4 + (32 + 2 * (4 * kq + (n & 3))) * 16) = (f32x4){t1[0], t1[1], t1[2], t1[3]};
+      return;
+#endif
       float* o = out + (int64_t)(64 + 64 * (fx - 1) + par) * 16 + n;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {                                            // accumulator row 16 part + m -> spectrum row 32 part + 2 m + par
