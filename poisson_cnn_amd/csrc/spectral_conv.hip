@@ -170,10 +170,8 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
   float v[4][16];
 #pragma unroll
   for (int j = 0; j < 4; ++j) fwd_load_row<MASKED>(p, cur, wave + 8 * j, v[j]);
-  for (;;) {
-    const int next = item + gridDim.x;
-    // ---- x axis: D_y[s][c] = sum_x G[s][x] xw[y][x][c]; A = G (lane = s), B = the pixel's channel row (lane = c), two x per MFMA
-    const int ylim = cur.ylim;                                       // `cur` will describe the NEXT item by the time the y axis runs
+  // ---- x axis: D_y[s][c] = sum_x G[s][x] xw[y][x][c]; A = G (lane = s), B = the pixel's channel row (lane = c), two x per MFMA
+  auto x_phase = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int y = wave + 8 * j;
@@ -181,53 +179,67 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) U[(y * 32 + acc_row(r, half)) * 32 + c] = acc[r];
     }
-    if (next < total) {                                              // `cur` now describes the next item
+  };
+  // The first item's x phase stands OUTSIDE the loop and the y phase is unrolled over its four units: every x phase inside the loop then
+  // meets the same, statically known memory-counter state (the next item's loads, then the current item's stores), so the s_waitcnt vmcnt
+  // values the compiler derives for it do not have to be the ones of a first pass that has no stores pending.
+  x_phase();
+  for (;;) {
+    const int next = item + gridDim.x;
+    const int ylim = cur.ylim;                                       // `cur` describes the NEXT item from here on
+    if (next < total) {
       fwd_item(p, next, half, c, cur);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fwd_load_row<MASKED>(p, cur, wave + 8 * j, v[j]);
     }
-    lds_barrier();  
-    // ---- y axis.  Wave (q, h): complex columns fx = 1 + q, 5 + q, ...; h = parity of the output frequencies fy it produces.
+    lds_barrier();
+    // ---- y axis.  Wave (q, h), unit u: complex column fx = 1 + q + 4 u, or - q == 3, u == 3 - the real column 0 (h = 0) / 16 (h = 1);
+    // h = parity of the output frequencies fy the wave produces.
     float* out = p.sp + sp_item(item);
-#pragma unroll 1
-    for (int fx = 1 + q; fx <= 15; fx += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool realcol = q == 3 && u == 3;                         // uniform
+      int fx = 1 + q + 4 * u;
+      asm volatile("" : "+s"(fx));                                   // opaque: the unit's LDS / store offsets are formed here, from this scalar, and
+                                                                     // not hoisted out of the item loop for all four units at once (registers)
       float bu[16];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {                              // K step ks: k = 2 ks + half = 16 part + y, y < 16
-        const int y = 2 * (ks & 7) + half, sc = ks < 8 ? fx : 16 + fx;
-        const float lo = U[(y * 32 + sc) * 32 + c];
-        const float hi = (!MASKED || 16 + 2 * (ks & 7) < ylim) ? U[((y + 16) * 32 + sc) * 32 + c] : 0.f;     // rows beyond ylim are zero (uniform test)
-        bu[ks] = h ? lo - hi : lo + hi;
-      }
-      if (FENCE) lds_fence();
       f32x16 acc = zero16();
+      float* o;
+      if (!realcol) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) acc = mfma(freg[ks], bu[ks], acc);
-      float* o = out + (64 + 64 * (fx - 1) + h) * RS;                // accumulator row 16 part + m  ->  spectrum row 32 part + 2 m + h
+        for (int ks = 0; ks < 16; ++ks) {                            // K step ks: k = 2 ks + half = 16 part + y, y < 16
+          const int y = 2 * (ks & 7) + half, sc = ks < 8 ? fx : 16 + fx;
+          const float lo = U[(y * 32 + sc) * 32 + c];
+          const float hi = (!MASKED || 16 + 2 * (ks & 7) < ylim) ? U[((y + 16) * 32 + sc) * 32 + c] : 0.f;     // rows beyond ylim are zero (uniform test)
+          bu[ks] = h ? lo - hi : lo + hi;
+        }
+        if (FENCE) lds_fence();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(freg[ks], bu[ks], acc);
+        o = out + (64 + 64 * (fx - 1) + h) * RS;                     // accumulator row 16 part + m  ->  spectrum row 32 part + 2 m + h
+      } else {
+        const int col = h ? 16 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          if (!MASKED || 2 * ks < ylim) bu[ks] = U[((2 * ks + half) * 32 + col) * 32 + c];
+        if (FENCE) lds_fence();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          if (!MASKED || 2 * ks < ylim) acc = mfma(greg[ks], bu[ks], acc);
+        o = out + (h ? 32 : 0) * RS;
+      }
+      // spectrum row of accumulator row `row`: complex columns interleave the parities, the real column stores its 32 entries in order
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, half);
-        o[(unsigned)((32 * (row >> 4) + 2 * (row & 15)) * RS + c)] = acc[r];
+        const int srow = realcol ? row : 32 * (row >> 4) + 2 * (row & 15);
+        o[(unsigned)(srow * RS + c)] = acc[r];
       }
-    }
-    if (q == 3) {                                                        // the two real columns: fx = 0 (wave 6), fx = 16 (wave 7)
-      const int col = h ? 16 : 0;
-      float bu[16];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
-        if (!MASKED || 2 * ks < ylim) bu[ks] = U[((2 * ks + half) * 32 + col) * 32 + c];
-      if (FENCE) lds_fence();
-      f32x16 acc = zero16();
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
-        if (!MASKED || 2 * ks < ylim) acc = mfma(greg[ks], bu[ks], acc);
-      float* o = out + (h ? 32 : 0) * RS;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[(unsigned)(acc_row(r, half) * RS + c)] = acc[r];
     }
     if (next >= total) break;
     item = next;
     lds_barrier();                                                       // U is free for the next item
+    x_phase();
   }
 }
 
