@@ -70,8 +70,22 @@ __global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
   const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
   const f32x4* wl = reinterpret_cast<const f32x4*>(p.wp) + half * 32 + col;
   {
+    const bool rmw = p.beta != 0.f;                              // uniform
+    const int64_t rowbase = (((int64_t)n * p.H + Y) * p.W) * p.ldy + col;
     for (int tx = 0; tx < p.f; ++tx) {
       const int tap = ty * p.f + tx;
+      // accumulate mode: this tap's sixteen old values as ONE burst of unconditional loads, issued before the MFMAs (a load between the
+      // stores is waited for with vmcnt(0) each: sixteen exposed latencies per tap - the read-modify-write ran at 27 % of the HBM peak)
+      float old[16];
+      if (rmw) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
+          const int X = xc * p.f + tx - p.px;
+          const bool ok = col < p.Cout && xc < p.wc && X >= 0 && X < p.W;
+          old[i] = p.y[ok ? rowbase + (int64_t)X * p.ldy : rowbase - col];       // !ok: the row's first float
+        }
+      }
       f32x16 acc;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -89,9 +103,8 @@ __global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
           const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
           const int X = xc * p.f + tx - p.px;
           if (xc < p.wc && X >= 0 && X < p.W) {
-            float* dst = p.y + (((int64_t)n * p.H + Y) * p.W + X) * p.ldy + col;
             const float v = p.alpha * (acc[i] + bias);
-            *dst = p.beta == 0.f ? v : p.beta * *dst + v;
+            p.y[rowbase + (int64_t)X * p.ldy] = rmw ? p.beta * old[i] + v : v;
           }
         }
       }

@@ -273,7 +273,7 @@ __device__ __forceinline__ void inv_load_unit(const float* in, int q, int h, uns
 // reads its operands.  LDS: E[(y*32 + s)*32 + c] in the first 64 KB, O in the second.
 // TANH = false: linear / relu / leaky-relu as one select with the negative-side slope in p.alpha (1 / 0 / alpha) - sixteen inlined
 // tanhf bodies would otherwise cost every layer ~90 registers and spills
-template <bool TANH>
+template <bool TANH, bool RES>
 __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   extern __shared__ __attribute__((aligned(16))) float U[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
@@ -359,24 +359,38 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
         const int xsgn = p.flip ? -1 : 1;
         float* yrow = p.y + rowpix * p.ldy;
         float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
-        const float* rrow = p.res ? p.res + rowpix * p.ld_res : nullptr;
+        const float* rrow = RES ? p.res + rowpix * p.ld_res : nullptr;
         // the per-pixel offsets below are invariant across rows and items: left alone, the compiler hoists all 48 of them out of the
         // persistent loop and keeps them in registers (256 VGPRs + spills); an opaque channel index makes it recompute them (one v_mad each)
         unsigned chv = (unsigned)chan;
         asm volatile("" : "+v"(chv));
         if (cok) {
+          // the row's residual values first, as one burst of unconditional loads (columns beyond vx read the row's first pixel): a load placed
+          // between the stores is waited for with vmcnt(0) each - sixteen exposed memory latencies per row (measured: + 1.2 ms per convolution
+          // of 8 x 1024^2 x 32 with a residual, for 0.25 ms worth of extra traffic)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int xx = acc_row(r, half);
-            if (xx < vx) {
-              float v = acc[r] + bias;
-              v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
-              const int xo = xsgn * xx + subx;
-              if (arow) arow[(int)(xo * p.ld_act) + (int)chv] = v;
-              v = v * sc + sh;
-              if (rrow) v += rrow[(int)(xo * p.ld_res) + (int)chv];
-              yrow[(int)(xo * p.ldy) + (int)chv] = v;
-              ymax = fmaxf(ymax, fabsf(v));
+          for (int r0 = 0; r0 < 16; r0 += 8) {                       // two bursts of eight (sixteen values at once do not fit the register file)
+            float rv[8];
+            if (RES) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const int xx = acc_row(r0 + r, half);
+                rv[r] = rrow[xx < vx ? (int)((xsgn * xx + subx) * p.ld_res) + (int)chv : (int)chv];
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int xx = acc_row(r0 + r, half);
+              if (xx < vx) {
+                float v = acc[r0 + r] + bias;
+                v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+                const int xo = xsgn * xx + subx;
+                if (arow) arow[(int)(xo * p.ld_act) + (int)chv] = v;
+                v = v * sc + sh;
+                if (RES) v += rv[r];
+                yrow[(int)(xo * p.ldy) + (int)chv] = v;
+                ymax = fmaxf(ymax, fabsf(v));
+              }
             }
           }
         }
@@ -672,16 +686,19 @@ void launch_fwd(pcnn_handle h, FwdParams p, int ntile) {
   if (masked) { if (fence) launch_fwd_t<true, true>(h, p, ntile); else launch_fwd_t<true, false>(h, p, ntile); }
   else { if (fence) launch_fwd_t<false, true>(h, p, ntile); else launch_fwd_t<false, false>(h, p, ntile); }
 }
+template <bool TANH, bool RES>
+void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
+  set_lds(spec_inv_kernel<TANH, RES>);
+  hipLaunchKernelGGL((spec_inv_kernel<TANH, RES>), grid, dim3(512), LDS_U, h->stream, p);
+}
 void launch_inv(pcnn_handle h, InvParams p, int ntile) {
   p.ntile = ntile;
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.act == PCNN_ACT_TANH) {
-    set_lds(spec_inv_kernel<true>);
-    hipLaunchKernelGGL(spec_inv_kernel<true>, grid, dim3(512), LDS_U, h->stream, p);
+    if (p.res) launch_inv_t<true, true>(h, p, grid); else launch_inv_t<true, false>(h, p, grid);
   } else {
     p.alpha = p.act == PCNN_ACT_LINEAR ? 1.f : (p.act == PCNN_ACT_RELU ? 0.f : p.alpha);     // slope of the negative side
-    set_lds(spec_inv_kernel<false>);
-    hipLaunchKernelGGL(spec_inv_kernel<false>, grid, dim3(512), LDS_U, h->stream, p);
+    if (p.res) launch_inv_t<false, true>(h, p, grid); else launch_inv_t<false, false>(h, p, grid);
   }
 }
 
