@@ -444,8 +444,9 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   };
   f32x4 a[2][4], an[2][4];
   int mt = blockIdx.y * 4 + wave;
-  if (mt < nMt) load_a(mt, 0, a);
-  for (; mt < nMt; mt += mstride) {
+  if (mt >= nMt) return;
+  load_a(mt, 0, a);
+  auto m_tile = [&](int mt) {
     f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll
     for (int gi = 0; gi < GIN; ++gi) {
@@ -470,10 +471,14 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int trow = mt * 32 + acc_row(r, half);
-        if (trow < p.ntile) p.ys[sp_item((int64_t)trow * p.gout + go) + row * RS + c] = acc[nt][r];
+        p.ys[sp_item((int64_t)trow * p.gout + go) + row * RS + c] = acc[nt][r];            // rows >= ntile: padding of the buffer (pad32)
       }
     }
-  }
+  };
+  // first M-tile outside the loop: every pass inside it then starts from the same memory-counter state (operand loads, then the previous
+  // tile's stores), so the waits for its operands do not have to cover a first pass that has no stores pending
+  m_tile(mt);
+  for (mt += mstride; mt < nMt; mt += mstride) m_tile(mt);
 }
 
 // M_f from the filter spectrum Wsp[ci * gout + go][row][co % 32] (conj: correlation).
@@ -629,6 +634,9 @@ struct Workspace {           // carved out of the handle's spectral workspace
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// the channel-mixing kernel writes whole 32-tile M-tiles (unconditional stores: their number per pass is then static): its output spectra are
+// allocated for a multiple of 32 tiles; the rows of tiles that do not exist are never read
+int pad32(int tiles) { return (tiles + 31) & ~31; }
 
 int chunk_tiles() {
   static const int v = getenv("PCNN_SPEC_CHUNK") ? atoi(getenv("PCNN_SPEC_CHUNK")) : 8192;
@@ -656,7 +664,7 @@ int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, in
   ws.slots = reinterpret_cast<int4*>(b + o_slots);
   char* r = b + o_rest;
   const size_t wsp_b = align256(sp_bytes((size_t)cin * gout)), M_b = align256((size_t)NSLOT * gin * gout * 64 * 64 * 4);
-  const size_t xs_b = align256(sp_bytes((size_t)chunk * gin)), ys_b = align256(sp_bytes((size_t)chunk * gout));
+  const size_t xs_b = align256(sp_bytes((size_t)chunk * gin)), ys_b = align256(sp_bytes((size_t)pad32(chunk) * gout));
   ws.wsp = reinterpret_cast<float*>(r); r += wsp_b;                        // filter spectrum (forward) / C^ (weight gradient)
   ws.M = reinterpret_cast<float*>(r); r += M_b;
   ws.xs = reinterpret_cast<float*>(r); r += xs_b;
@@ -668,7 +676,7 @@ int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, in
 
 size_t workspace_bytes(int gin, int gout, int cin, int chunk, bool wgrad) {
   size_t b = align256(sp_bytes((size_t)cin * gout)) + align256((size_t)NSLOT * gin * gout * 64 * 64 * 4) +
-             align256(sp_bytes((size_t)chunk * gin)) + align256(sp_bytes((size_t)chunk * gout));
+             align256(sp_bytes((size_t)chunk * gin)) + align256(sp_bytes((size_t)pad32(chunk) * gout));
   if (wgrad) b += align256((size_t)wgrad_splits() * NSLOT * gin * 4 * 1024 * 4);
   return b;
 }
@@ -865,7 +873,7 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   const int chunk = (int)std::min<int64_t>(chunk_tiles() / gx, ntile);
   // workspace: [filter spectrum | M | dz spectra (gz) | dx spectra (gx) | x-tile spectra (gx) | partial sums]; C^ reuses the filter-spectrum slot
   const size_t wsp_b = align256(sp_bytes((size_t)std::max(dg->Cin * gx, d->Cin))), M_b = align256((size_t)NSLOT * gz * gx * 64 * 64 * 4);
-  const size_t zs_b = align256(sp_bytes((size_t)chunk * gz)), ys_b = align256(sp_bytes((size_t)chunk * gx));
+  const size_t zs_b = align256(sp_bytes((size_t)chunk * gz)), ys_b = align256(sp_bytes((size_t)pad32(chunk) * gx));
   const size_t part_b = align256((size_t)S * NSLOT * gx * 4 * 1024 * 4);
   Workspace ws;
   if (int rc = ensure_workspace(h, wsp_b + M_b + zs_b + 2 * ys_b + part_b + 4096, ws, 1, 1, 1, 1)) return rc;
