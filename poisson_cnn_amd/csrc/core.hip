@@ -20,6 +20,7 @@ extern "C" int pcnn_create(int device, void* hip_stream, pcnn_handle* out) {
 extern "C" int pcnn_destroy(pcnn_handle h) {
   if (h && h->scratch) (void)hipFree(h->scratch);
   if (h && h->spec_ws) (void)hipFree(h->spec_ws);
+  if (h && h->aux_ws) (void)hipFree(h->aux_ws);
   if (h && h->comm) pcnn_comm_release(h);
   delete h;
   return 0;

@@ -169,6 +169,71 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(int N, int hc, int wc, 
   }
 }
 
+// y pass of the two-pass float4 form (the x pass - resize_x_kernel below - has interpolated the hc coarse rows to the output width): output row
+// index uniform per workgroup, thread = (output column, channel quad), a loop over RPB rows whose 4 row taps are scalar loads; two rows per
+// pass, all of a pass's loads (2 x 4 taps + the two old values of the accumulate mode) issued before its two stores (a load between stores
+// is waited for with vmcnt(0)).  Zero-weight taps carry index 0: fetched, unused.
+constexpr int RESIZE_RPB = 8;
+__global__ __launch_bounds__(256) void resize_fwd_y_kernel(int N, int hc, int C, int Ho, int Wo, const float* __restrict__ t, const int32_t* __restrict__ iy,
+                                                           const float* __restrict__ wy, float alpha, float beta, float* __restrict__ y, int ldy) {
+  const int CV = C >> 2;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= Wo * CV) return;
+  const int c = (u % CV) << 2, ox = u / CV;
+  const int chunks = (Ho + RESIZE_RPB - 1) / RESIZE_RPB;
+  const int n = blockIdx.y / chunks, oy0 = (blockIdx.y % chunks) * RESIZE_RPB;
+  const float* tn = t + ((int64_t)n * hc * Wo + ox) * C + c;
+  const bool rmw = beta != 0.f;
+  for (int oy = oy0; oy < oy0 + RESIZE_RPB && oy < Ho; oy += 2) {
+    const int oyb = oy + 1 < Ho ? oy + 1 : oy;                 // odd Ho: the second row of the last pass repeats the first (not stored)
+    float4 q[2][4], old[2];
+    float wya[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = rr ? oyb : oy;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        wya[rr][a] = wy[row * 4 + a];
+        q[rr][a] = *reinterpret_cast<const float4*>(tn + (int64_t)iy[row * 4 + a] * Wo * C);
+      }
+    }
+    float* dst[2] = {y + (((int64_t)n * Ho + oy) * Wo + ox) * ldy + c, y + (((int64_t)n * Ho + oyb) * Wo + ox) * ldy + c};
+    if (rmw) { old[0] = *reinterpret_cast<const float4*>(dst[0]); old[1] = *reinterpret_cast<const float4*>(dst[1]); }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[0] += wya[rr][a] * q[rr][a].x; acc[1] += wya[rr][a] * q[rr][a].y; acc[2] += wya[rr][a] * q[rr][a].z; acc[3] += wya[rr][a] * q[rr][a].w;
+      }
+      float4 o;
+      if (rmw) o = make_float4(beta * old[rr].x + alpha * acc[0], beta * old[rr].y + alpha * acc[1], beta * old[rr].z + alpha * acc[2], beta * old[rr].w + alpha * acc[3]);
+      else o = make_float4(alpha * acc[0], alpha * acc[1], alpha * acc[2], alpha * acc[3]);
+      if (rr == 0 || oyb != oy) *reinterpret_cast<float4*>(dst[rr]) = o;
+    }
+  }
+}
+
+// x pass of the two-pass form: t[n, yc, ox, c] = sum_b wx[ox][b] x[n, yc, ix[ox][b], c] on the COARSE rows only (hc of them); the row-uniform
+// kernel above then needs 4 row taps per output instead of 16 taps - it was bound by the texture path (16 cache-resident loads per 16 bytes
+// written), not by HBM
+__global__ __launch_bounds__(256) void resize_x_kernel(int64_t rows, int wc, int C, int Wo, const float* __restrict__ x, int ldx, const int32_t* __restrict__ ix,
+                                                       const float* __restrict__ wx, float* __restrict__ t) {
+  const int CV = C >> 2;
+  const int64_t total = rows * Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) << 2; int64_t r = i / CV; const int ox = (int)(r % Wo); const int64_t row = r / Wo;
+    const float* src = x + row * wc * ldx + c;
+    float4 q[4]; float w[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { w[b] = wx[ox * 4 + b]; q[b] = *reinterpret_cast<const float4*>(src + (int64_t)ix[ox * 4 + b] * ldx); }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { o.x += w[b] * q[b].x; o.y += w[b] * q[b].y; o.z += w[b] * q[b].z; o.w += w[b] * q[b].w; }
+    *reinterpret_cast<float4*>(t + (row * Wo + ox) * C + c) = o;
+  }
+}
+
 // pass 1 of the adjoint: tmp[n, yc, X, c] = sum_Y Ry[Y, yc] dy[n, Y, X, c]
 template <int V>
 __global__ __launch_bounds__(256) void resize_bwd_rows_kernel(int N, int hc, int C, int Ho, int Wo, const float* __restrict__ dy, int lddy,
@@ -365,7 +430,20 @@ extern "C" int pcnn_resize_tables(int method, int n_in, int n_out, int32_t* idx,
 extern "C" int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* x, int ldx, const int32_t* idx_y,
                                const float* wt_y, const int32_t* idx_x, const float* wt_x, float alpha, float beta, float* y, int ldy) {
   PCNN_REQUIRE(h, h && x && y && idx_y && wt_y && idx_x && wt_x, "pcnn_resize_fwd: null argument");
-  if (vec4_ok(C, x, ldx, y, ldy))
+  if (vec4_ok(C, x, ldx, y, ldy) && (int64_t)N * ((Ho + RESIZE_RPB - 1) / RESIZE_RPB) < 65536) {
+    // two passes: x interpolation of the hc coarse rows into the handle's scratch, then the row-uniform y pass
+    const size_t need = (size_t)N * hc * Wo * C * sizeof(float);
+    if (h->aux_ws_bytes < need) {
+      if (h->aux_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
+      if (hipMalloc(&h->aux_ws, need) != hipSuccess) PCNN_FAIL(h, "pcnn_resize_fwd: cannot allocate %zu B of scratch", need);
+      h->aux_ws_bytes = need;
+    }
+    float* t = static_cast<float*>(h->aux_ws);
+    hipLaunchKernelGGL(resize_x_kernel, grid1d((int64_t)N * hc * Wo * (C / 4)), dim3(256), 0, h->stream, (int64_t)N * hc, wc, C, Wo, x, ldx, idx_x, wt_x, t);
+    hipLaunchKernelGGL(resize_fwd_y_kernel, dim3((unsigned)((Wo * (C / 4) + 255) / 256), (unsigned)(N * ((Ho + RESIZE_RPB - 1) / RESIZE_RPB))), dim3(256), 0, h->stream,
+                       N, hc, C, Ho, Wo, t, idx_y, wt_y, alpha, beta, y, ldy);
+  }
+  else if (vec4_ok(C, x, ldx, y, ldy))
     hipLaunchKernelGGL(resize_fwd_kernel<4>, grid1d((int64_t)N * Ho * Wo * (C / 4)), dim3(256), 0, h->stream, N, hc, wc, C, Ho, Wo, x, ldx, idx_y, wt_y, idx_x,
                        wt_x, alpha, beta, y, ldy);
   else
