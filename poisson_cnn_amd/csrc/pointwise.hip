@@ -148,6 +148,39 @@ __global__ void pad_fold_kernel(int N, int H, int W, int C, int pt, int pb, int 
   }
 }
 
+// float4 form (C, the channel strides and the base pointers multiples of 4 floats): a quarter of the index arithmetic and memory instructions
+__global__ void pad_fold_vec4_kernel(int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode, const float* __restrict__ gp, int ldgp,
+                                     float* __restrict__ gx, int ldgx, int accumulate) {
+  const int Hp = H + pt + pb, Wp = W + pl + pr, CV = C >> 2;
+  const int64_t total = (int64_t)N * H * W * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) << 2; int64_t r = i / CV; const int x = r % W; r /= W; const int y = r % H; const int n = r / H;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y + pt;
+    xs[nx++] = x + pl;
+    if (mode == PCNN_PAD_SYMMETRIC) {
+      if (y < pt) ys[ny++] = pt - 1 - y;
+      if (H - 1 - y < pb) ys[ny++] = pt + H + (H - 1 - y);
+      if (x < pl) xs[nx++] = pl - 1 - x;
+      if (W - 1 - x < pr) xs[nx++] = pl + W + (W - 1 - x);
+    } else if (mode == PCNN_PAD_REFLECT) {
+      if (y >= 1 && y <= pt) ys[ny++] = pt - y;
+      if (H - 2 - y >= 0 && H - 2 - y < pb) ys[ny++] = pt + H + (H - 2 - y);
+      if (x >= 1 && x <= pl) xs[nx++] = pl - x;
+      if (W - 2 - x >= 0 && W - 2 - x < pr) xs[nx++] = pl + W + (W - 2 - x);
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        const float4 q = *reinterpret_cast<const float4*>(gp + (((int64_t)n * Hp + ys[a]) * Wp + xs[b]) * ldgp + c);
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      }
+    float4* dst = reinterpret_cast<float4*>(gx + (((int64_t)n * H + y) * W + x) * ldgx + c);
+    if (accumulate) { const float4 o = *dst; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *dst = s;
+  }
+}
+
 // ---------------------------------------------------------------- simple elementwise kernels
 __global__ void axpby_kernel(int64_t npix, int C, float alpha, const float* __restrict__ x, int ldx, float beta, float* __restrict__ y, int ldy) {
   const int64_t total = npix * C;
@@ -225,13 +258,17 @@ __global__ void sample_scale_fwd_kernel(int N, int64_t per, const float* __restr
 }
 
 // one block per sample: dx = dy*(1+g), dg = sum dy*x
-__global__ __launch_bounds__(1024) void sample_scale_bwd_kernel(int64_t per, const float* __restrict__ x, const float* __restrict__ g,
-                                                                const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ dg) {
-  __shared__ float red[1024];
-  const int n = blockIdx.x;
+// dx = dy (1 + g[n]), dg[n] = sum dy x: SS_SPLIT workgroups per sample (a sample per workgroup left 8 of 256 CUs busy at 8 x 1024^2), each
+// over one contiguous piece; partial sums in part[n][split], combined in a fixed order by sample_scale_final_kernel
+constexpr int SS_SPLIT = 64;
+__global__ __launch_bounds__(256) void sample_scale_bwd_kernel(int64_t per, const float* __restrict__ x, const float* __restrict__ g,
+                                                               const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ part) {
+  __shared__ float red[256];
+  const int n = blockIdx.y, sp = blockIdx.x;
   const float gv = 1.0f + g[n];
+  const int64_t piece = (per + SS_SPLIT - 1) / SS_SPLIT, q0 = (int64_t)sp * piece, q1 = q0 + piece < per ? q0 + piece : per;
   float acc = 0.f;
-  for (int64_t q = threadIdx.x; q < per; q += blockDim.x) {
+  for (int64_t q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
     const int64_t i = (int64_t)n * per + q;
     const float d = dy[i];
     acc += d * x[i];
@@ -243,7 +280,14 @@ __global__ __launch_bounds__(1024) void sample_scale_bwd_kernel(int64_t per, con
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) dg[n] = red[0];
+  if (threadIdx.x == 0) part[n * SS_SPLIT + sp] = red[0];
+}
+__global__ void sample_scale_final_kernel(int N, const float* __restrict__ part, float* __restrict__ dg) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < SS_SPLIT; ++k) s += part[n * SS_SPLIT + k];
+  dg[n] = s;
 }
 
 __global__ void bc_ring_fwd_kernel(int N, int H, int W, int neumann, const float* __restrict__ x, float* __restrict__ y) {
@@ -413,8 +457,12 @@ extern "C" int pcnn_pad_fold_bwd(pcnn_handle h, int N, int H, int W, int C, int 
                                  int ldgp, float* gx, int ldgx, int accumulate) {
   PCNN_REQUIRE(h, h && gp && gx, "pcnn_pad_fold_bwd: null argument");
   PCNN_REQUIRE(h, pad_mode >= 0 && pad_mode <= 2 && pt >= 0 && pb >= 0 && pl >= 0 && pr >= 0, "pcnn_pad_fold_bwd: bad padding");
-  hipLaunchKernelGGL(pad_fold_kernel, grid1d((int64_t)N * H * W * C), dim3(256), 0, h->stream, N, H, W, C, pt, pb, pl, pr, pad_mode, gp, ldgp,
-                     gx, ldgx, accumulate);
+  if (C % 4 == 0 && ldgp % 4 == 0 && ldgx % 4 == 0 && ((reinterpret_cast<uintptr_t>(gp) | reinterpret_cast<uintptr_t>(gx)) & 15) == 0)
+    hipLaunchKernelGGL(pad_fold_vec4_kernel, grid1d((int64_t)N * H * W * (C / 4)), dim3(256), 0, h->stream, N, H, W, C, pt, pb, pl, pr, pad_mode, gp, ldgp, gx, ldgx,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(pad_fold_kernel, grid1d((int64_t)N * H * W * C), dim3(256), 0, h->stream, N, H, W, C, pt, pb, pl, pr, pad_mode, gp, ldgp,
+                       gx, ldgx, accumulate);
   PCNN_CHECK_LAUNCH(h, "pcnn_pad_fold_bwd");
   return 0;
 }
@@ -501,7 +549,16 @@ extern "C" int pcnn_sample_scale_fwd(pcnn_handle h, int N, int64_t per, const fl
 
 extern "C" int pcnn_sample_scale_bwd(pcnn_handle h, int N, int64_t per, const float* x, const float* g, const float* dy, float* dx, float* dg) {
   PCNN_REQUIRE(h, h && x && g && dy && dx && dg, "pcnn_sample_scale_bwd: null argument");
-  hipLaunchKernelGGL(sample_scale_bwd_kernel, dim3(N), dim3(1024), 0, h->stream, per, x, g, dy, dx, dg);
+  const size_t need = (size_t)N * SS_SPLIT * sizeof(float);
+  if (h->aux_ws_bytes < need) {                              // handle-owned scratch (shared with the two-pass resize; one stream per handle)
+    if (h->aux_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
+    const size_t cap = need < (1u << 20) ? (1u << 20) : need;
+    if (hipMalloc(&h->aux_ws, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_sample_scale_bwd: cannot allocate %zu B of scratch", cap);
+    h->aux_ws_bytes = cap;
+  }
+  float* part = static_cast<float*>(h->aux_ws);
+  hipLaunchKernelGGL(sample_scale_bwd_kernel, dim3(SS_SPLIT, N), dim3(256), 0, h->stream, per, x, g, dy, dx, part);
+  hipLaunchKernelGGL(sample_scale_final_kernel, dim3((N + 63) / 64), dim3(64), 0, h->stream, N, part, dg);
   PCNN_CHECK_LAUNCH(h, "pcnn_sample_scale_bwd");
   return 0;
 }
