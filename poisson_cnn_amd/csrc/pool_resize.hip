@@ -12,6 +12,9 @@ __device__ __forceinline__ void win(int o, int f, int pb, int n, int& a, int& b)
 }
 
 // small windows: one thread per output element
+// float4 form of the small-window forward (C, the channel strides and the base pointers multiples of 4 floats)
+__global__ void pool_fwd_small_vec4_kernel(int kind, int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx,
+                                           const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy);
 __global__ void pool_fwd_small_kernel(int kind, int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx,
                                       const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy) {
   const int64_t total = (int64_t)N * Ho * Wo * C;
@@ -27,6 +30,26 @@ __global__ void pool_fwd_small_kernel(int kind, int N, int H, int W, int C, int 
       }
     if (kind == PCNN_POOL_AVERAGE) acc /= (float)((y1 - y0) * (x1 - x0));
     y[(((int64_t)n * Ho + oy) * Wo + ox) * ldy + c] = acc;
+  }
+}
+__global__ void pool_fwd_small_vec4_kernel(int kind, int N, int H, int W, int C, int f, int Ho, int Wo, int pby, int pbx,
+                                           const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy) {
+  const int CV = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) << 2; int64_t r = i / CV; const int ox = r % Wo; r /= Wo; const int oy = r % Ho; const int n = r / Ho;
+    int y0, y1, x0, x1;
+    win(oy, f, pby, H, y0, y1); win(ox, f, pbx, W, x0, x1);
+    const float init = kind == PCNN_POOL_MAX ? -INFINITY : 0.f;
+    float4 acc = make_float4(init, init, init, init);
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (((int64_t)n * H + yy) * W + xx) * ldx + c);
+        if (kind == PCNN_POOL_MAX) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      }
+    if (kind == PCNN_POOL_AVERAGE) { const float d = (float)((y1 - y0) * (x1 - x0)); acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d; }
+    *reinterpret_cast<float4*>(y + (((int64_t)n * Ho + oy) * Wo + ox) * ldy + c) = acc;
   }
 }
 
@@ -317,7 +340,10 @@ extern "C" int pcnn_pool2d_fwd(pcnn_handle h, int kind, int N, int H, int W, int
   PCNN_REQUIRE(h, h && x && y && f >= 1 && (kind == 0 || kind == 1), "pcnn_pool2d_fwd: bad argument");
   const int Ho = pcnn_cdiv(H, f), Wo = pcnn_cdiv(W, f), pby = (Ho * f - H) / 2, pbx = (Wo * f - W) / 2;
   if (f * f <= 16 || C > 256) {
-    hipLaunchKernelGGL(pool_fwd_small_kernel, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, kind, N, H, W, C, f, Ho, Wo, pby, pbx, x, ldx, y, ldy);
+    if (vec4_ok(C, x, ldx, y, ldy))
+      hipLaunchKernelGGL(pool_fwd_small_vec4_kernel, grid1d((int64_t)N * Ho * Wo * (C / 4)), dim3(256), 0, h->stream, kind, N, H, W, C, f, Ho, Wo, pby, pbx, x, ldx, y, ldy);
+    else
+      hipLaunchKernelGGL(pool_fwd_small_kernel, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, kind, N, H, W, C, f, Ho, Wo, pby, pbx, x, ldx, y, ldy);
   } else {
     hipLaunchKernelGGL(pool_fwd_large_kernel, dim3((unsigned)((int64_t)N * Ho * Wo)), dim3(256), 0, h->stream, kind, N, H, W, C, pow2_ge(C), f, Ho,
                        Wo, pby, pbx, x, ldx, y, ldy);
