@@ -290,6 +290,53 @@ __global__ __launch_bounds__(256) void resize_bwd_rows_kernel(int N, int hc, int
   }
 }
 
+// float4 form of pass 1, streaming: a workgroup owns RB consecutive coarse rows (uniform), thread = (output column X, channel quad) with RB
+// accumulators; it walks the fine rows that can reach those coarse rows ONCE, every row one coalesced 16-byte load per thread (two rows in
+// flight), the row's four taps being scalar data: w_k = sum_a [iy[Y][a] == yc0 + k] wy[Y][a].  (The per-coarse-row form above walks the
+// same window once per coarse row, a chain of dependent, branch-guarded loads: 0.98 ms for 1 GB at 8 x 1024^2.)
+template <int RESIZE_RB>
+__global__ __launch_bounds__(256) void resize_bwd_rows_block_kernel(int N, int hc, int C, int Ho, int Wo, const float* __restrict__ dy, int lddy,
+                                                                    const int32_t* __restrict__ iy, const float* __restrict__ wy, float* __restrict__ tmp) {
+  const int CV = C >> 2;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= Wo * CV) return;
+  const int c = (u % CV) << 2, X = u / CV;
+  const int groups = (hc + RESIZE_RB - 1) / RESIZE_RB;
+  const int n = blockIdx.y / groups, yc0 = (blockIdx.y % groups) * RESIZE_RB;
+  const float sc = (float)Ho / (float)hc;
+  int Ya = (int)floorf(((float)yc0 - 2.5f) * sc) - 1, Yb = (int)ceilf(((float)(yc0 + RESIZE_RB - 1) + 3.5f) * sc) + 2;
+  if (Ya < 0) Ya = 0;
+  if (Yb > Ho) Yb = Ho;
+  float4 acc[RESIZE_RB];
+#pragma unroll
+  for (int k = 0; k < RESIZE_RB; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* src = dy + ((int64_t)n * Ho * Wo + X) * lddy + c;
+  for (int Y = Ya; Y < Yb; Y += 2) {
+    const int Y1 = Y + 1 < Yb ? Y + 1 : Y;
+    const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)Y * Wo * lddy);
+    const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)Y1 * Wo * lddy);
+    float w0[RESIZE_RB], w1[RESIZE_RB];
+#pragma unroll
+    for (int k = 0; k < RESIZE_RB; ++k) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        s0 += (iy[Y * 4 + a] == yc0 + k) ? wy[Y * 4 + a] : 0.f;
+        s1 += (iy[Y1 * 4 + a] == yc0 + k) ? wy[Y1 * 4 + a] : 0.f;
+      }
+      w0[k] = s0; w1[k] = Y1 != Y ? s1 : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RESIZE_RB; ++k) {
+      acc[k].x += w0[k] * v0.x; acc[k].y += w0[k] * v0.y; acc[k].z += w0[k] * v0.z; acc[k].w += w0[k] * v0.w;
+      acc[k].x += w1[k] * v1.x; acc[k].y += w1[k] * v1.y; acc[k].z += w1[k] * v1.z; acc[k].w += w1[k] * v1.w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RESIZE_RB; ++k)
+    if (yc0 + k < hc) *reinterpret_cast<float4*>(tmp + (((int64_t)n * hc + yc0 + k) * Wo + X) * C + c) = acc[k];
+}
+
 // pass 2: dx[n, yc, xc, c] = alpha * sum_X Rx[X, xc] tmp[n, yc, X, c]
 template <int V>
 __global__ __launch_bounds__(256) void resize_bwd_cols_kernel(int N, int hc, int wc, int C, int Wo, const float* __restrict__ tmp, const int32_t* __restrict__ ix,
@@ -482,7 +529,13 @@ extern "C" int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int 
 extern "C" int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* dy, int lddy, const int32_t* idx_y,
                                const float* wt_y, const int32_t* idx_x, const float* wt_x, float alpha, float* tmp, float* dx, int lddx) {
   PCNN_REQUIRE(h, h && dy && dx && tmp && idx_y && wt_y && idx_x && wt_x, "pcnn_resize_bwd: null argument");
-  if (vec4_ok(C, dy, lddy, tmp, 4))
+  // coarse rows per workgroup: 8 where there are many (the window's margins - 3 coarse rows on either side - are re-read less), 4 otherwise
+  const int rb = hc >= 32 ? 8 : 4;
+  if (vec4_ok(C, dy, lddy, tmp, 4) && (int64_t)N * ((hc + rb - 1) / rb) < 65536) {
+    const dim3 grid((unsigned)((Wo * (C / 4) + 255) / 256), (unsigned)(N * ((hc + rb - 1) / rb)));
+    if (rb == 8) hipLaunchKernelGGL(resize_bwd_rows_block_kernel<8>, grid, dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
+    else hipLaunchKernelGGL(resize_bwd_rows_block_kernel<4>, grid, dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
+  } else if (vec4_ok(C, dy, lddy, tmp, 4))
     hipLaunchKernelGGL(resize_bwd_rows_kernel<4>, grid1d((int64_t)N * hc * Wo * (C / 4)), dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
   else
     hipLaunchKernelGGL(resize_bwd_rows_kernel<1>, grid1d((int64_t)N * hc * Wo * C), dim3(256), 0, h->stream, N, hc, C, Ho, Wo, dy, lddy, idx_y, wt_y, tmp);
