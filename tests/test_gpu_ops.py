@@ -64,6 +64,36 @@ def test_conv_backward_matches_autograd(k, Cin, Cout, H, W, mode):
     assert rel(nchw(dx), xt.grad.numpy()) < TOL
 
 
+@pytest.mark.parametrize('mode', ['SYMMETRIC', 'REFLECT', 'CONSTANT'])
+@pytest.mark.parametrize('C', [8, 6])
+def test_pad_fold_and_pool_float4_forms(mode, C):
+    """tf.pad adjoint (float4 form for channel counts that are multiples of 4, scalar otherwise; plain and accumulate mode) and the
+    float4 pooling forward, against numpy.pad's index map / the numpy oracle."""
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(C)
+    N, H, W, pt, pb, pl, pr = 2, 11, 9, 3, 2, 4, 1
+    gp = f32(rng.standard_normal((N, C, H + pt + pb, W + pl + pr)))
+    tmode = {'SYMMETRIC': 'symmetric', 'REFLECT': 'reflect', 'CONSTANT': 'constant'}[mode]
+    # the adjoint through an index map: padded[i, j] = x[iy[i], ix[j]] (or the constant)
+    iy = np.pad(np.arange(H), (pt, pb), mode=tmode, **({'constant_values': -1} if mode == 'CONSTANT' else {}))
+    ix = np.pad(np.arange(W), (pl, pr), mode=tmode, **({'constant_values': -1} if mode == 'CONSTANT' else {}))
+    ref = np.zeros((N, C, H, W))
+    for i, sy in enumerate(iy):
+        for j, sx in enumerate(ix):
+            if sy >= 0 and sx >= 0:
+                ref[:, :, sy, sx] += gp[:, :, i, j]
+    dx = ops.pad_fold_bwd(nhwc(gp), (H, W), ((pt, pb), (pl, pr)), mode)
+    assert rel(nchw(dx), ref) < TOL
+    base = f32(rng.standard_normal(ref.shape))
+    acc = nhwc(base)
+    ops.pad_fold_bwd(nhwc(gp), (H, W), ((pt, pb), (pl, pr)), mode, out=acc, accumulate=True)
+    assert rel(nchw(acc), base + ref) < TOL
+    x = f32(rng.standard_normal((N, C, 14, 10)))
+    for f in (2, 3):
+        for kind in ('average', 'max'):
+            assert rel(nchw(ops.pool2d_fwd(nhwc(x), f, kind)), np_ops.pool2d_same(x, f, kind)) < TOL
+
+
 def test_epilogue_bwd_and_bn_fold():
     from poisson_cnn_amd import ops
     rng = np.random.default_rng(0)
@@ -189,6 +219,28 @@ def test_resize_fwd_bwd(method, hc, wc, Ho, Wo):
     ref = np_ops.resize2d(x, (Ho, Wo), method)
     y = ops.resize_fwd(nhwc(x), (Ho, Wo), method)
     assert rel(nchw(y), ref) < TOL
+    dy = f32(rng.standard_normal(ref.shape))
+    xt = torch.tensor(x, requires_grad=True)
+    (torch_twin.resize2d(xt, (Ho, Wo), method) * torch.tensor(dy)).sum().backward()
+    dx = ops.resize_bwd(nhwc(dy), (hc, wc), method, alpha=0.5)
+    assert rel(nchw(dx), 0.5 * xt.grad.numpy()) < TOL_RED
+
+
+@pytest.mark.parametrize('method', ['nearest', 'bilinear', 'bicubic'])
+@pytest.mark.parametrize('hc,wc,Ho,Wo', [(5, 7, 33, 41), (37, 9, 150, 40), (8, 8, 128, 96)])
+def test_resize_float4_forms(method, hc, wc, Ho, Wo):
+    """Channel counts that are multiples of 4 take the two-pass forward (x pass + row-uniform y pass, two rows per pass: odd Ho) and the
+    streaming backward (8 / 4 coarse rows per workgroup: hc not a multiple of either); accumulate mode y = beta*y + alpha*resize(x)."""
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(hc + Wo)
+    x = f32(rng.standard_normal((2, 8, hc, wc)))
+    ref = np_ops.resize2d(x, (Ho, Wo), method)
+    y = ops.resize_fwd(nhwc(x), (Ho, Wo), method)
+    assert rel(nchw(y), ref) < TOL
+    y0 = f32(rng.standard_normal(ref.shape))
+    out = nhwc(y0)
+    ops.resize_fwd(nhwc(x), (Ho, Wo), method, alpha=0.25, beta=1.0, out=out)
+    assert rel(nchw(out), y0 + 0.25 * ref) < TOL
     dy = f32(rng.standard_normal(ref.shape))
     xt = torch.tensor(x, requires_grad=True)
     (torch_twin.resize2d(xt, (Ho, Wo), method) * torch.tensor(dy)).sum().backward()
