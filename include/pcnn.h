@@ -47,6 +47,9 @@ uint32_t pcnn_crc32c(const void* data, size_t n, uint32_t crc);
  * other ranks over whatever channel the host program has, then every rank (one process per GPU, one handle) calls pcnn_comm_init.
  * pcnn_allreduce / pcnn_broadcast are in place, asynchronous, fp32. */
 #define PCNN_UNIQUE_ID_BYTES 128
+/* host-only probe (no handle, no GPU): 0 when RCCL can be bound, else 1 with the loader's message in `why`.  The environment variable
+ * PCNN_RCCL_LIBRARY names the one library file to try instead of the default search (librccl.so.1, librccl.so, /opt/rocm/lib). */
+int pcnn_collective_available(char* why, size_t why_bytes);
 int pcnn_comm_unique_id(pcnn_handle h, void* id_out);
 int pcnn_comm_init(pcnn_handle h, const void* id, int rank, int world_size);
 int pcnn_comm_destroy(pcnn_handle h);
@@ -203,7 +206,8 @@ int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo,
                     float alpha, float* tmp, float* dx, int lddx);
 
 /* ---- small dense layers (tf.keras.layers.Dense: models/Homogeneous_Poisson_NN_Legacy.py:99-102, layers/Scaling.py:31-33)
- * y[n,o] = act(b[o] + sum_i x[n,i] w[i,o]);  bwd: given dy and y, dx, dw (+=), db (+=) */
+ * y[n,o] = act(b[o] + sum_i x[n,i] w[i,o]);  bwd: given dy and y, dx, dw (+=), db (+=).  b / db may be NULL: a Dense layer without bias
+ * (use_bias=False reaches every Dense layer of the metalearning hyper-networks, layers/metalearning_conv.py:113,128) */
 int pcnn_dense_fwd(pcnn_handle h, int N, int In, int Out, const float* x, const float* w, const float* b, int act, float alpha, float* y);
 int pcnn_dense_bwd(pcnn_handle h, int N, int In, int Out, const float* x, const float* w, const float* y, const float* dy,
                    int act, float alpha, float* dx, float* dw, float* db);

@@ -16,9 +16,11 @@ from . import np_ops, torch_twin as T
 
 
 def hyper(p, name, dense_input, acts, use_layernorm=False):
+    """The Dense layers carry a bias only when the layer's `use_bias` is set (it is forwarded into every Dense layer through
+    `_other_dense_layer_args`, layers/metalearning_conv.py:113,128): a missing '<name>/dense<i>/bias' entry means no bias."""
     kb = dense_input
     for i, a in enumerate(acts):
-        kb = T.dense(kb, p['%s/dense%d/kernel' % (name, i)], p['%s/dense%d/bias' % (name, i)], a)
+        kb = T.dense(kb, p['%s/dense%d/kernel' % (name, i)], p.get('%s/dense%d/bias' % (name, i)), a)
     if use_layernorm:
         mu = kb.mean(dim=-1, keepdim=True)
         var = ((kb - mu) ** 2).mean(dim=-1, keepdim=True)

@@ -132,7 +132,8 @@ def batchnorm_training(x, gamma, beta, eps=np_ops.BN_EPS):
 
 
 def dense(x, w, b, act='linear'):
-    return activation(x @ asarray(w) + asarray(b), act)
+    y = x @ asarray(w)
+    return activation(y if b is None else y + asarray(b), act)
 
 
 def spatial_pyramid_pool(x, levels, kind='max'):

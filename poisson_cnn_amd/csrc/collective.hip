@@ -6,6 +6,7 @@
 // Rendezvous is the caller's business, as in NCCL: rank 0 calls pcnn_comm_unique_id and ships the 128 bytes to the other ranks over any
 // channel it has (a file, MPI, torch.distributed's store ...); every rank then calls pcnn_comm_init with its rank.
 #include "pcnn_internal.h"
+#include <stdlib.h>
 #include <dlfcn.h>
 #include <string.h>
 
@@ -34,11 +35,17 @@ struct Rccl {
 Rccl& rccl() {
   static Rccl r;
   if (r.lib || !r.why.empty()) return r;
-  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+  // PCNN_RCCL_LIBRARY names the one library to try (deployments with RCCL outside the loader path; tests force a failure with it)
+  const char* forced = getenv("PCNN_RCCL_LIBRARY");
+  std::string first_error;
+  for (const char* name : {forced ? forced : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (r.lib) break;
+    const char* e = dlerror();               // ONE call per failure: dlerror() returns the message once and clears it
+    if (first_error.empty()) first_error = e ? e : "unknown dlopen error";
+    if (forced) break;
   }
-  if (!r.lib) { r.why = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"); return r; }
+  if (!r.lib) { r.why = std::string("cannot load ") + (forced ? forced : "librccl.so.1") + ": " + first_error; return r; }
   r.get_unique_id = reinterpret_cast<GetUniqueIdFn>(dlsym(r.lib, "ncclGetUniqueId"));
   r.comm_init_rank = reinterpret_cast<CommInitRankFn>(dlsym(r.lib, "ncclCommInitRank"));
   r.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(r.lib, "ncclAllReduce"));
@@ -55,6 +62,13 @@ Rccl& rccl() {
 const char* estr(Rccl& r, int rc) { return r.error_string ? r.error_string(rc) : "rccl error"; }
 
 }  // namespace
+
+// Host-only: 0 when RCCL can be bound, otherwise 1 with the loader's reason in `why` (always NUL-terminated).  Needs no handle and no GPU.
+extern "C" int pcnn_collective_available(char* why, size_t why_bytes) {
+  Rccl& r = rccl();
+  if (why && why_bytes) snprintf(why, why_bytes, "%s", r.lib ? "" : r.why.c_str());
+  return r.lib ? 0 : 1;
+}
 
 void pcnn_comm_release(pcnn_handle_s* h) {
   if (h->comm) { Rccl& r = rccl(); if (r.lib) (void)r.comm_destroy(h->comm); h->comm = nullptr; h->comm_size = 0; }

@@ -124,11 +124,12 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(int N, int In, int Out, 
     for (int n = 0; n < N; ++n) acc = fmaf(x[n * In + k], dz(n, o), acc);
     dw[i] += acc;
   }
-  for (int o = t0; o < Out; o += ts) {
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc += dz(n, o);
-    db[o] += acc;
-  }
+  if (db)                                                 // a Dense layer built with use_bias=False has no bias gradient
+    for (int o = t0; o < Out; o += ts) {
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc += dz(n, o);
+      db[o] += acc;
+    }
 }
 
 // ---------------------------------------------------------------- SPP max over (bin, channels)
@@ -364,7 +365,7 @@ extern "C" int pcnn_dense_fwd(pcnn_handle h, int N, int In, int Out, const float
 
 extern "C" int pcnn_dense_bwd(pcnn_handle h, int N, int In, int Out, const float* x, const float* w, const float* y, const float* dy, int act,
                               float alpha, float* dx, float* dw, float* db) {
-  PCNN_REQUIRE(h, h && x && w && y && dy && dw && db, "pcnn_dense_bwd: null argument");
+  PCNN_REQUIRE(h, h && x && w && y && dy && dw, "pcnn_dense_bwd: null argument");   // db may be null (no bias)
   const int work = std::max(N * In, In * Out);
   hipLaunchKernelGGL(dense_bwd_kernel, dim3(std::min(pcnn_cdiv(work, 256), 1024)), dim3(256), 0, h->stream, N, In, Out, x, w, y, dy, act, alpha, dx, dw, db);
   PCNN_CHECK_LAUNCH(h, "pcnn_dense_bwd");

@@ -108,11 +108,25 @@ def _poly_and_second_derivative(roots, x):
     return npoly.polyval(x, c), (npoly.polyval(x, npoly.polyder(c, 2)) if c.shape[0] > 2 else np.zeros_like(x))
 
 
+def _streams(seed, shard):
+    """The generators' two host-side random streams.  `shard` = (rank, world_size) of a data-parallel run: the SHAPE stream - everything
+    that decides the grid size (H, W) of a step, drawn for the global batch as the reference's single generator does
+    (dataset/generators/reverse.py:192-193: one shape per batch, which MirroredStrategy then splits) - is seeded identically on every rank;
+    the DATA stream (coefficients, control points, magnitudes) is seeded `seed + rank`.  Without a shard both are ONE stream (single process)."""
+    if shard is None:
+        rng = np.random.default_rng(seed)
+        return rng, rng, (0, 1)
+    rank, world = int(shard[0]), int(shard[1])
+    if not 0 <= rank < world:
+        raise ValueError('shard = (rank, world_size) with 0 <= rank < world_size, got %r' % (shard,))
+    return np.random.default_rng(seed + rank), np.random.default_rng([int(seed), 0x5AFE]), (rank, world)
+
+
 # ----------------------------------------------------------------------------- analytic ("reverse") generators
 class reverse_poisson_dataset_generator:
     def __init__(self, batch_size, batches_per_epoch, random_output_shape_range, fourier_coeff_grid_size_range, taylor_degree_range=None,
                  grid_spacings_range=None, ndims=None, homogeneous_bc=False, return_rhses=True, return_boundaries=True, return_dx=True,
-                 normalizations=None, uniform_grid_spacing=False, seed=0, device=None):
+                 normalizations=None, uniform_grid_spacing=False, seed=0, device=None, shard=None):
         self.batch_size, self.batches_per_epoch = int(batch_size), int(batches_per_epoch)
         self.ndims = 2 if ndims is None else ndims
         if self.ndims != 2:
@@ -125,7 +139,7 @@ class reverse_poisson_dataset_generator:
         self.return_rhses, self.return_boundaries, self.return_dx = return_rhses, return_boundaries, return_dx
         self.normalizations = _process_normalizations(normalizations)
         self.uniform_grid_spacing = uniform_grid_spacing
-        self.rng = np.random.default_rng(seed)
+        self.rng, self.shape_rng, self.shard = _streams(seed, shard)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.neumann = False
         self.fixed_output_shape = None     # set to (H, W) to pin the grid (benchmarks / data-parallel ranks sharing one shape)
@@ -140,10 +154,15 @@ class reverse_poisson_dataset_generator:
 
     def _shape_and_spacings(self):
         """generate_grid_sizes_and_spacings_with_uniform_AR (reverse.py:173-177)."""
+        # one draw for the GLOBAL batch from the stream every rank shares (one grid shape per step on all replicas, reverse.py:192-193);
+        # a rank keeps its own rows of the per-sample spacings
+        rank, world = self.shard
+        gb = self.batch_size * world
         ar = generate_uniformly_distributed_aspect_ratios(self.random_output_shape_range, None if self.uniform_grid_spacing else self.grid_spacings_range,
-                                                          self.batch_size, self.rng)
+                                                          gb, self.shape_rng)
         shape, dx = generate_output_shapes_and_grid_spacings_from_aspect_ratios(ar, self.random_output_shape_range, self.grid_spacings_range,
-                                                                                constant_dx=self.uniform_grid_spacing, samples=self.batch_size, rng=self.rng)
+                                                                                constant_dx=self.uniform_grid_spacing, samples=gb, rng=self.shape_rng)
+        dx = dx[rank * self.batch_size:(rank + 1) * self.batch_size]
         if self.fixed_output_shape is not None:
             shape = np.asarray(self.fixed_output_shape, dtype=np.int64)
         return shape, dx
@@ -228,10 +247,10 @@ class reverse_poisson_dataset_generator_homogeneous_neumann(reverse_poisson_data
     """Cosine-only series: zero normal derivative on every edge, zero-mean RHS (dataset/generators/reverse_neumann.py:9-66)."""
 
     def __init__(self, batch_size, batches_per_epoch, random_output_shape_range, fourier_coeff_grid_size_range, grid_spacings_range=None, ndims=None,
-                 return_rhses=True, return_dx=True, normalizations=None, uniform_grid_spacing=False, seed=0, device=None):
+                 return_rhses=True, return_dx=True, normalizations=None, uniform_grid_spacing=False, seed=0, device=None, shard=None):
         super().__init__(batch_size, batches_per_epoch, random_output_shape_range, fourier_coeff_grid_size_range, None, grid_spacings_range, ndims,
                          homogeneous_bc=False, return_rhses=return_rhses, return_boundaries=False, return_dx=return_dx, normalizations=normalizations,
-                         uniform_grid_spacing=uniform_grid_spacing, seed=seed, device=device)
+                         uniform_grid_spacing=uniform_grid_spacing, seed=seed, device=device, shard=shard)
         self.neumann = True
 
 
@@ -246,7 +265,7 @@ class numerical_dataset_generator:
     def __init__(self, batch_size=1, batches_per_epoch=1, randomize_rhs_smoothness=False, rhs_random_smoothness_range=(5, 20),
                  randomize_boundary_smoothness=False, boundary_random_smoothness_range=None, randomize_rhs_max_magnitude=False,
                  rhs_random_max_magnitude=1.0, randomize_boundary_max_magnitudes=False, boundary_random_max_magnitudes=None,
-                 return_keras_style=True, exclude_zero_boundaries=False, seed=0, device=None, **numerical_dataset_arguments):
+                 return_keras_style=True, exclude_zero_boundaries=False, seed=0, device=None, shard=None, **numerical_dataset_arguments):
         self.batch_size, self.batches_per_epoch = int(batch_size), int(batches_per_epoch)
         self.randomize_rhs_smoothness, self.rhs_random_smoothness_range = randomize_rhs_smoothness, rhs_random_smoothness_range
         self.randomize_boundary_smoothness = randomize_boundary_smoothness
@@ -257,7 +276,7 @@ class numerical_dataset_generator:
         self.return_keras_style, self.exclude_zero_boundaries = return_keras_style, exclude_zero_boundaries
         self.nda = dict(numerical_dataset_arguments)
         self.nda.pop('normalizations', None)
-        self.rng = np.random.default_rng(seed)
+        self.rng, self.shape_rng, self.shard = _streams(seed, shard)
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
 
     def __len__(self):
@@ -286,18 +305,19 @@ class numerical_dataset_generator:
         boundary_types (extension): dict edge -> 'dirichlet' | 'neumann' (default all Dirichlet).  A Neumann
         edge's random smooth boundary function is its normal derivative du/dn; the discrete mixed-BC system is solved directly
         (mixed_bc_poisson_solve) - a true mixed Dirichlet/Neumann ground truth for BASELINE configs[2]."""
-        N, rng = self.batch_size, self.rng
+        N, rng, srng = self.batch_size, self.rng, self.shape_rng
+        rank, world = self.shard
         boundary_max_magnitude = boundary_max_magnitude or {k: 1.0 for k in _BOUNDARY_KEYS}
-        if isinstance(output_shape, str) and output_shape == 'random':
+        if isinstance(output_shape, str) and output_shape == 'random':       # the grid shape comes from the stream all ranks share (see _streams)
             if uniformly_distributed_aspect_ratios:
-                ar = generate_uniformly_distributed_aspect_ratios(random_output_shape_range, None, 1, rng)
+                ar = generate_uniformly_distributed_aspect_ratios(random_output_shape_range, None, 1, srng)
                 shape, dxg = generate_output_shapes_and_grid_spacings_from_aspect_ratios(ar, random_output_shape_range, [list(random_dx_range)], constant_dx=True,
-                                                                                         samples=N, rng=rng)
+                                                                                         samples=N * world, rng=srng)
                 output_shape = [int(s) for s in shape]
                 if isinstance(dx, str) and dx == 'random':
-                    dx = dxg[:, :1]
+                    dx = dxg[rank * N:(rank + 1) * N, :1]
             else:
-                output_shape = [int(rng.integers(r[0], r[1])) for r in random_output_shape_range]
+                output_shape = [int(srng.integers(r[0], r[1])) for r in random_output_shape_range]
         if isinstance(dx, str) and dx == 'random':
             dx = rng.uniform(size=(N, 1)) * (random_dx_range[1] - random_dx_range[0]) + random_dx_range[0]
         elif isinstance(dx, float):

@@ -266,6 +266,7 @@ class ConvUnit:
                 dz = dy
         w = s.w[self.name + '/kernel']
         kh, kw = self.kh, self.kw
+        wf = None
         if need_dx:
             # wide filters: both gradients in one call on the spectral route (the spectrum of dz is shared); None = not eligible
             wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
@@ -299,7 +300,7 @@ class ConvUnit:
             self.ctx.side_reads[dz.data_ptr()] = done          # see Context.before_inplace_write
         if not need_dx:
             return None
-        wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
+        # wf: the flipped filter formed above is still in the context's scratch (nothing in between writes it) - no second launch
         if self.mode == 'CONSTANT':
             return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to)
         gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1))
@@ -476,13 +477,18 @@ class bottleneck_block_multilinearupsample(_bottleneck_base):
 
 # ----------------------------------------------------------------------------- dense / scaling / jacobi
 class Dense:
-    def __init__(self, store, name, din, units, activation='linear'):
+    """tf.keras.layers.Dense.  use_bias=False allocates no bias (the metalearning hyper-networks pass their `use_bias` into every Dense layer,
+    layers/metalearning_conv.py:113,128)."""
+
+    def __init__(self, store, name, din, units, activation='linear', use_bias=True):
         self.store, self.name, self.act = store, name, canonical_activation(activation)
+        self.use_bias = bool(use_bias)
         store.add(name + '/kernel', (din, units), 'glorot')
-        store.add(name + '/bias', (units,), 'zeros')
+        if self.use_bias:
+            store.add(name + '/bias', (units,), 'zeros')
 
     def forward(self, x, training=True):
-        y = ops.dense_fwd(x, self.store.w[self.name + '/kernel'], self.store.w[self.name + '/bias'], self.act)
+        y = ops.dense_fwd(x, self.store.w[self.name + '/kernel'], self.store.w[self.name + '/bias'] if self.use_bias else None, self.act)
         self.saved = (x, y) if training else None
         return y
 
@@ -491,8 +497,11 @@ class Dense:
         self.saved = None
         g = self.store.g
         g[self.name + '/kernel'].zero_()
-        g[self.name + '/bias'].zero_()
-        return ops.dense_bwd(x, self.store.w[self.name + '/kernel'], y, dy, self.act, g[self.name + '/kernel'], g[self.name + '/bias'], need_dx)
+        db = None
+        if self.use_bias:
+            db = g[self.name + '/bias']
+            db.zero_()
+        return ops.dense_bwd(x, self.store.w[self.name + '/kernel'], y, dy, self.act, g[self.name + '/kernel'], db, need_dx)
 
 
 class Scaling:

@@ -61,7 +61,7 @@ class _Hyper:
         acts = _acts(dense_activations, len(units))
         self.dense = []
         for i, (u, a) in enumerate(zip(units, acts)):
-            self.dense.append(L.Dense(self.store, '%s/dense%d' % (self.name, i), int(din), int(u), a))
+            self.dense.append(L.Dense(self.store, '%s/dense%d' % (self.name, i), int(din), int(u), a, use_bias=self.use_bias))
             din = u
         self.use_layernorm = bool(use_layernorm)
         if self.use_layernorm:

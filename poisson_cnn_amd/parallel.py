@@ -28,6 +28,8 @@ class DataParallel:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        if backend is None and dist.is_initialized():          # the caller's own process group: report and rendezvous over ITS backend
+            backend = dist.get_backend()
         self = cls(rank, ws, lr, backend)
         if os.environ.get('PCNN_COLLECTIVE') == 'c_abi' and torch.cuda.is_available():
             self.enable_c_abi_collective()

@@ -202,7 +202,8 @@ def main(argv=None):
     gbs = config['dataset']['batch_size']
     dcfg = dict(config['dataset'])
     dcfg['batch_size'] = dp.local_batch(gbs)
-    dcfg['seed'] = dcfg.get('seed', 0) + dp.rank
+    if dp.world_size > 1:       # every rank draws the step's grid shape from one shared stream and its samples from its own (dataset._streams)
+        dcfg['shard'] = (dp.rank, dp.world_size)
     if args.model == 'dbcnn':      # train/dbcnn_legacy_train.py:26-31: one non-zero edge, zero right-hand side
         dataset = numerical_dataset_generator(randomize_boundary_smoothness=True, exclude_zero_boundaries=True, nonzero_boundaries=['left'], rhses='zero',
                                               return_boundaries=True, return_dx=True, return_rhs=False, **dcfg)

@@ -6,11 +6,13 @@
       loss (global_batch_size = 32, so it is this sample's share of the 32 x 512^2 batch loss), prediction, the gradient of the
       first and of the last two convolution layers, and the L2 norm of every parameter's gradient.
 
+  C4: hpnn.json model, forward of ONE sample (index 3) of the 8 x 1024^2 Dirichlet batch (seed 4) - the bench workload's size.
+
 The oracle is oracle/hpnn.py on oracle/torch_twin.py (fp64 torch-CPU; its forward is pinned to the numpy oracle oracle/np_ops.py
 in tests/test_oracle_ops.py - at these sizes the pure-numpy convolution would take hours).  The TensorFlow reference cannot run
 in the build container.  Run time on 8 cores: about 15 minutes, ~30 GB of memory.
 
-    python tests/golden/make_atsize_golden.py [c2] [c3]
+    python tests/golden/make_atsize_golden.py [c2] [c3] [c4]        (c4 alone: about 10 minutes)
 """
 import os
 import sys
@@ -38,6 +40,15 @@ def c2_inputs():
     return rhs.astype(np.float32), dx.astype(np.float32)
 
 
+def c4_inputs():
+    """SURVEY 8d C4 (per-GPU batch): rhs = 2U-1 of shape [8,1,1024,1024] (seed 4) scaled to max-abs 1 per sample, dx ~ U(5e-3, 5e-2)."""
+    rng = np.random.default_rng(4)
+    rhs = rng.uniform(-1, 1, (8, 1, 1024, 1024))
+    rhs /= np.abs(rhs).max(axis=(1, 2, 3), keepdims=True)
+    dx = rng.uniform(5e-3, 5e-2, (8, 1))
+    return rhs.astype(np.float32), dx.astype(np.float32)
+
+
 def c3_inputs(n=32):
     """[32,1,512,512] seed 3; the target is a smooth analytic-looking field (low-order sine series) so that the loss
     terms have the magnitudes they have in training."""
@@ -53,7 +64,7 @@ def c3_inputs(n=32):
 
 
 def main():
-    which = set(sys.argv[1:]) or {'c2', 'c3'}
+    which = set(sys.argv[1:]) or {'c2', 'c3', 'c4'}
     out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     full = configs.hpnn()
@@ -69,6 +80,19 @@ def main():
         out['c2_sample'] = np.int64(k)
         out['c2_out'] = y.numpy().astype(np.float32)
         print('c2: %.1f s, max|y| %.4g' % (time.time() - t0, np.abs(out['c2_out']).max()), flush=True)
+        np.savez_compressed(PATH, **out)
+    if 'c4' in which:
+        cfg = full['model']
+        p = ohpnn.init_params(cfg, seed=WEIGHT_SEED, gain=WEIGHT_GAIN, randomize_all=True)
+        rhs, dx = c4_inputs()
+        k = 3
+        t0 = time.time()
+        with torch.no_grad():
+            y = ohpnn.forward(torch_twin, cfg, {n: torch.tensor(v) for n, v in p.items()}, torch.tensor(rhs[k:k + 1].astype(np.float64)),
+                              torch.tensor(dx[k:k + 1].astype(np.float64)))
+        out['c4_sample'] = np.int64(k)
+        out['c4_out'] = y.numpy().astype(np.float32)
+        print('c4: %.1f s, max|y| %.4g' % (time.time() - t0, np.abs(out['c4_out']).max()), flush=True)
         np.savez_compressed(PATH, **out)
     if 'c3' in which:
         rhs, dx, tgt = c3_inputs()

@@ -49,8 +49,9 @@ def test_conv_adjoint_identities_at_full_size(mode, pad_mode):
         ops.set_math_mode(prev)
 
 
-def test_model_at_c4_size_sample_independence_and_train_step():
-    """hpnn.json at 8 x 1024^2 (bench workload c4, split mode as benchmarked): every sample's solution is independent of its batch
+@pytest.mark.parametrize('mode', ['fp32', 'split_f16'])
+def test_model_at_c4_size_sample_independence_and_train_step(mode):
+    """hpnn.json at 8 x 1024^2 (bench workload c4; fp32 is the benchmarked library default, split_f16 the opt-in mode): every sample's solution is independent of its batch
     neighbours (bit-exact: inference-mode BN, per-tile arithmetic), the boundary ring is zero (Dirichlet), and one full training step
     leaves finite loss, gradients and weights."""
     from poisson_cnn_amd import configs, ops
@@ -58,7 +59,7 @@ def test_model_at_c4_size_sample_independence_and_train_step():
     from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
     from poisson_cnn_amd.train import Adam
     prev = ops.get_math_mode()
-    ops.set_math_mode('split_f16')
+    ops.set_math_mode(mode)
     try:
         full = configs.hpnn()
         model = Homogeneous_Poisson_NN_Legacy(**full['model'])

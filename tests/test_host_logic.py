@@ -168,4 +168,37 @@ def test_chain_models_structure_and_oracle_names():
             cls(**{**copy.deepcopy(kw), 'bottleneck_config': None}, device='cpu')
         with pytest.raises(ValueError):
             cls(**{**copy.deepcopy(kw), 'bottleneck_upsampling': 'bicubic'}, device='cpu')
-    assert Homogeneous_Poisson_NN_Metalearning(**{k: v for k, v in configs.hpnn_metalearning()['model'].items() if k != 'model_type'}, device='cpu').count_params() == 5650048
+    # use_bias reaches every Dense layer of the hyper-networks (layers/metalearning_conv.py:113,128): the example configuration sets it False
+    # everywhere, so no Dense bias exists and the first layer emits exactly the 19 x 19 x 3 x 4 kernel (hand count: 4*8 + 8*16 + 16*4332 weights)
+    big = {k: v for k, v in configs.hpnn_metalearning()['model'].items() if k != 'model_type'}
+    m0 = Homogeneous_Poisson_NN_Metalearning(**copy.deepcopy(big), device='cpu')
+    assert [n for n in m0.store.names if n.endswith('/bias')] == []
+    assert tuple(m0.store.w['pre/conv0/dense2/kernel'].shape) == (16, 19 * 19 * 3 * 4)
+    assert m0.count_params() == 5317256
+    big['pre_bottleneck_convolutions_config']['use_bias'] = True
+    m1 = Homogeneous_Poisson_NN_Metalearning(**copy.deepcopy(big), device='cpu')
+    assert tuple(m1.store.w['pre/conv0/dense2/kernel'].shape) == (16, 19 * 19 * 3 * 4 + 4)
+    assert [tuple(m1.store.w['pre/conv0/dense%d/bias' % i].shape) for i in range(3)] == [(8,), (16,), (19 * 19 * 3 * 4 + 4,)]
+    # three layers gain (8 + 16 + n_out) biases and 16 more kernel columns per output channel
+    extra = sum(8 + 16 + (k * k * ci * co + co) + 16 * co for k, ci, co in ((19, 3, 4), (17, 4, 6), (15, 6, 8)))
+    assert m1.count_params() == 5317256 + extra
+
+
+def test_rccl_load_failure_is_an_error_return_not_a_crash():
+    """a missing librccl must come back as a non-zero return code with a message (csrc/collective.hip), never as a crash -
+    run in a child process so that a segfault would be seen as a failed return code, with the library name forced to a missing file."""
+    import subprocess
+    import sys
+    code = ('import ctypes, os\n'
+            'from poisson_cnn_amd import _lib\n'
+            'lib = _lib.load()\n'
+            'buf = ctypes.create_string_buffer(512)\n'
+            'rc = lib.pcnn_collective_available(buf, ctypes.c_size_t(512))\n'
+            'rc2 = lib.pcnn_collective_available(buf, ctypes.c_size_t(512))\n'
+            'print(rc, rc2, buf.value.decode())\n')
+    env = dict(os.environ, PCNN_RCCL_LIBRARY='/nonexistent/librccl_missing.so')
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rc, rc2, msg = r.stdout.strip().split(' ', 2)
+    assert rc == '1' and rc2 == '1'
+    assert 'librccl_missing.so' in msg and len(msg) > 30

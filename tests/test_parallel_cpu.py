@@ -138,3 +138,34 @@ def _metric_worker(rank, world, port, q):
         cb.on_epoch_end(e, {'loss': float(gl)})
     q.put((rank, float(loss), float(mse), _M.optimizer.learning_rate))
     torch.distributed.destroy_process_group()
+
+
+def test_all_ranks_draw_one_grid_shape_per_step():
+    """SURVEY section 8(e) / VERDICT r2 #13: every rank must train on the same (H, W) in a step, as the reference's single generator draws one
+    shape per global batch (dataset/generators/reverse.py:192-193).  The shape stream is shared, the data stream is per rank, and a rank's
+    per-sample grid spacings are its rows of the global batch's draw."""
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.dataset import reverse_poisson_dataset_generator, numerical_dataset_generator, _streams
+    d = dict(configs.hpnn()['dataset'])
+    d['batch_size'] = 4
+    whole = reverse_poisson_dataset_generator(**{**d, 'batch_size': 8}, seed=7, device='cpu', shard=(0, 1))
+    ranks = [reverse_poisson_dataset_generator(**d, seed=7, device='cpu', shard=(r, 2)) for r in range(2)]
+    shapes = set()
+    for step in range(6):
+        sw, dxw = whole._shape_and_spacings()
+        got = [g._shape_and_spacings() for g in ranks]
+        assert tuple(got[0][0]) == tuple(got[1][0]) == tuple(sw)
+        assert np.array_equal(np.concatenate([got[0][1], got[1][1]]), dxw)          # the global batch's spacings, split by rank
+        shapes.add(tuple(int(v) for v in sw))
+    assert len(shapes) > 1 and all(192 <= h <= 384 and 192 <= w <= 384 for h, w in shapes)
+    # the data streams differ between ranks, the shape streams do not
+    a, b = ranks
+    assert a.rng.uniform() != b.rng.uniform() and a.shape_rng.uniform() == b.shape_rng.uniform()
+    # no shard: one stream for both (a single process draws exactly as before)
+    rng, srng, sh = _streams(3, None)
+    assert rng is srng and sh == (0, 1)
+    with pytest.raises(ValueError):
+        _streams(0, (2, 2))
+    # numerical generator: constructor plumbing (its draws need the GPU kernels; covered by tests/test_gpu_dp.py)
+    n0 = numerical_dataset_generator(batch_size=2, seed=5, device='cpu', shard=(1, 2), output_shape='random')
+    assert n0.shard == (1, 2) and n0.rng is not n0.shape_rng
