@@ -67,7 +67,7 @@ int pcnn_set_math_mode(pcnn_handle h, int mode);
 int pcnn_get_math_mode(pcnn_handle h);
 
 /* Algorithm of pcnn_conv2d_fwd / pcnn_conv2d_wgrad for wide filters (replaces the same tf.nn.conv2d / backprop-filter calls):
- *   tiled spectral convolution - overlap-save on 32 x 32 tiles, the DFT applied as fp32 MFMA matrix products, per-frequency channel
+ *   tiled spectral convolution - overlap-save on 32 x 32 tiles (64 x 64 for 11..15 taps: csrc/spectral64.hip), the DFT applied as fp32 MFMA matrix products, per-frequency channel
  *   mixing, inverse transform fused with the conv epilogue (csrc/spectral_conv.hip).  Exact fp32 products and accumulation like the
  *   direct kernel, ~k*k/25 times fewer of them.  PCNN_SPECTRAL_AUTO (default; environment PCNN_SPECTRAL=-1|0|1): a cost model picks the
  *   route per layer and math mode; _OFF: always the direct implicit GEMM; _FORCE: spectral whenever the shape allows
@@ -75,6 +75,17 @@ int pcnn_get_math_mode(pcnn_handle h);
 enum { PCNN_SPECTRAL_AUTO = -1, PCNN_SPECTRAL_OFF = 0, PCNN_SPECTRAL_FORCE = 1 };
 int pcnn_set_spectral_mode(pcnn_handle h, int mode);
 int pcnn_get_spectral_mode(pcnn_handle h);
+/* Tile size of the spectral route: 0 (default; environment PCNN_SPEC_T) = per layer - 64 x 64 tiles for 11..15 taps on images of >= 36 such
+ * tiles, 32 x 32 otherwise; 32 / 64 = that size wherever the layer allows it (64: 9..15 taps, more than 16 channels on one side). */
+int pcnn_set_spectral_tile(pcnn_handle h, int tile);
+int pcnn_get_spectral_tile(pcnn_handle h);
+/* The ONE buffer a handle owns besides small scratch: the spectral workspace (tile spectra of the layer in flight, mixing matrices,
+ * constant tables).  By default it grows to a whole layer per launch - 8 x 1024^2 x 32 channels at 15 taps: ~11 GB, sized for 288 GB of
+ * HBM.  pcnn_set_workspace_limit caps it (bytes; 0 = no cap): the launches then cover fewer tiles each (never fewer than 32; a layer that
+ * cannot run inside the cap fails with an ordinary error), so a host program that budgets device memory itself decides what the
+ * library may take.  Growth happens inside a convolution call (stream synchronise + free + allocate) until the largest layer shape has
+ * been seen: call the largest shape once up front, or set the cap, to keep allocation out of the steady state. */
+int pcnn_set_workspace_limit(pcnn_handle h, size_t bytes);
 
 /* ---- 2-D convolution: tf.pad + tf.nn.conv2d(VALID) + bias + activation (+ BN affine) (+ residual) ----------
  * Replaces pad_and_apply_convolution (utils/apply_advanced_padding_and_call_conv_layer.py:16-20), Keras

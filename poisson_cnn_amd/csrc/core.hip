@@ -13,6 +13,7 @@ extern "C" int pcnn_create(int device, void* hip_stream, pcnn_handle* out) {
   h->device = device;
   h->stream = static_cast<hipStream_t>(hip_stream);
   if (const char* e = getenv("PCNN_SPECTRAL")) h->spectral_mode = atoi(e);
+  if (const char* e = getenv("PCNN_SPEC_T")) h->spectral_tile = atoi(e);
   *out = h;
   return 0;
 }
@@ -58,6 +59,15 @@ extern "C" int pcnn_set_spectral_mode(pcnn_handle h, int mode) {
 }
 
 extern "C" int pcnn_get_spectral_mode(pcnn_handle h) { return h ? h->spectral_mode : -2; }
+
+extern "C" int pcnn_set_spectral_tile(pcnn_handle h, int tile) {
+  if (!h) return 1;
+  PCNN_REQUIRE(h, tile == 0 || tile == 32 || tile == 64, "pcnn_set_spectral_tile: tile size %d (0 = per layer, 32, 64)", tile);
+  h->spectral_tile = tile;
+  return 0;
+}
+
+extern "C" int pcnn_get_spectral_tile(pcnn_handle h) { return h ? h->spectral_tile : -1; }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a HOST buffer: the checksum of TensorFlow's TensorBundle checkpoint files
 // (tensorflow/core/lib/hash/crc32c.h) that poisson_cnn_amd/tf_checkpoint.py reads and writes.  Host-only helper, no device work.

@@ -16,9 +16,11 @@ struct pcnn_handle_s {
   float* y_absmax = nullptr;      // set by pcnn_conv2d_fwd_absmax for the duration of one forward launch: receives max|y|
   void* spec_ws = nullptr;        // spectral-convolution workspace (tables, filter spectrum, tile spectra; grown on demand, owned by the handle)
   size_t spec_ws_bytes = 0;
+  size_t spec_ws_limit = 0;       // caller's cap on the spectral workspace in bytes (0: none), pcnn_set_workspace_limit
   void* aux_ws = nullptr;         // scratch of the two-pass resize (x-interpolated coarse rows; grown on demand, owned by the handle)
   size_t aux_ws_bytes = 0;
   int spectral_mode = -1;         // PCNN_SPECTRAL_AUTO (cost model) / _OFF / _FORCE, see pcnn_set_spectral_mode
+  int spectral_tile = 0;          // 0: per layer (pick_tile), 32 / 64: that tile size wherever the layer allows it, see pcnn_set_spectral_tile
   void* comm = nullptr;           // RCCL communicator (ncclComm_t) of pcnn_comm_init, see collective.hip
   int comm_rank = 0, comm_size = 0;
 };

@@ -1,0 +1,58 @@
+// Shared declarations of the tiled spectral convolution: spectral_conv.hip (32-point tiles, mixing kernels, host side) and spectral64.hip
+// (64-point tiles).  Spectrum layout for a tile size T (T = 32 or 64): items (tile x channel group of 32) are T*T rows of 32 floats
+// (128-byte channel vectors); rows [0,T): column fx = 0 (real in x, half-complex in y: Re fy = 0..T/2, then Im fy = 1..T/2-1),
+// [T,2T): fx = T/2, then for fx = 1..T/2-1: 2T + 2T (fx-1) + {fy | T + fy} = Re | Im of the complex column (tools/spectral_model.py,
+// tools/spectral_model64.py).  T*T/2 mixing slots.
+#pragma once
+#include "pcnn_internal.h"
+
+namespace pcnn_spec {
+
+constexpr int RS = 32;                       // floats between consecutive spectrum rows of an item
+__host__ __device__ __forceinline__ int64_t sp_item(int64_t item, int rows) { return item * ((int64_t)rows * RS); }
+__host__ __device__ __forceinline__ size_t sp_bytes(size_t items, int rows) { return items * (size_t)rows * RS * sizeof(float); }
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+// All LDS reads issued so far have landed; nothing moves across.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also drains vmcnt, i.e. waits for the next item's prefetch loads and the
+// spectrum stores in flight; the prefetched registers are waited for where they are consumed, global stores need no ordering here).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// accumulator register r of lane (half) <-> row of the 32x32 tile
+__device__ __forceinline__ int acc_row(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
+
+struct FwdParams {
+  const float* x; float* sp; const float* tab;
+  int H, W, C, ld, groups, cstride, cvalid;
+  int tiles_x, tiles_y, tile0, ntile;
+  int Vy, Vx, oy, ox, pad_mode; float pad_value;
+  int ylim, xlim;        // the window holds values only in its first ylim x xlim entries (gradient / input tiles of the backward pass)
+  int ext_y, ext_x;      // ... and only where the tile grid coordinate (ty Vy + r, tx Vx + c) lies inside ext_y x ext_x
+  int pack, cpt, tgx;    // layers of <= 16 channels: `pack` x-adjacent tiles share the 32 lanes (lane = cpt * tile + channel, cpt = 32 / pack);
+                         // tgx = tile groups per tile row; an "item" is then a tile GROUP and tile0 / ntile count groups
+};
+
+struct InvParams {
+  const float* sp; const float* tab;
+  float* y; const float* bias; const float* bn_scale; const float* bn_shift; const float* res; float* act_out; unsigned* absmax;
+  int Ho, Wo, C, ldy, ld_res, ld_act, groups, cstride, cvalid, act; float alpha;
+  int tiles_x, tiles_y, tile0, ntile, Vy, Vx;
+  int flip;              // store output pixel (y, x) at (Ho-1-y, Wo-1-x): the input-partitioned weight gradient comes out tap-reversed
+  int pack, cpt, tgx;    // tile packing, as in FwdParams (flip requires pack == 1)
+};
+
+// 64-point tiles (spectral64.hip): table block, slots are built by build_tables64; the launchers take the same parameter blocks (pack = 1)
+constexpr int TAB64_FLOATS = 20480;
+void build_tables64(float* tab, int* slots);                 // TAB64_FLOATS floats, 2048 x int4 slots
+void launch_fwd64(pcnn_handle h, FwdParams p, int ntile);     // p.tab: the 64-point table block
+void launch_inv64(pcnn_handle h, InvParams p, int ntile);
+
+}  // namespace pcnn_spec

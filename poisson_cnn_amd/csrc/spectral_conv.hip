@@ -18,7 +18,7 @@
 //                     by spec_inv_kernel as a one-tile "image" with Cin*Cout channels; the first k x k taps are dw.
 // The filter spectrum is produced by spec_fwd_kernel too (the filter is a kh x kw image with Cin*Cout channels).
 // Index conventions: tools/spectral_model.py (numpy model, checked against direct correlation).
-#include "pcnn_internal.h"
+#include "spectral_common.h"
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
@@ -30,6 +30,8 @@ bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad);
 bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d);   // conv_small.hip
 bool pcnn_conv_fwd_takes_narrow_route(pcnn_handle h, const pcnn_conv_desc* d);
 
+using namespace pcnn_spec;
+
 namespace {
 
 constexpr int T = 32, ROWS = 1024, NSLOT = 512;
@@ -37,44 +39,10 @@ constexpr int T = 32, ROWS = 1024, NSLOT = 512;
 // transforms of one radix-2 step of the 32-point complex DFT (see build_tables); GI2 the real-column inverse split into its two parities
 constexpr int TAB_G = 0, TAB_GI = 1024, TAB_F2 = 2048, TAB_FI2 = 4096, TAB_GI2 = 6144, TAB_FLOATS = 7168;
 constexpr size_t LDS_U = (size_t)T * T * 32 * sizeof(float);   // 128 KB
-// Spectrum storage: items (tile x channel group) in blocks of SPB, rows outermost inside a block (row r of the block's SPB items is one
-// contiguous SPB x 128 B run).  SPB = 1 is the plain item-major layout.  Measured at 8 x 1024^2, 15x15, 32 -> 32 (8192-tile launches):
-// SPB = 32 makes the per-frequency kernels stream whole DRAM pages but gains them nothing (mix 0.59 -> 0.61 ms, wmix 0.56 -> 0.58 ms)
-// and costs the inverse transform its sequential rows (0.45 -> 0.52 ms) - the page pattern is not what bounds them.
-constexpr int SPB = 1, RS = SPB * 32;
-                          // items per block, floats between consecutive rows of an item
-__host__ __device__ __forceinline__ int64_t sp_item(int64_t item) { return (item / SPB) * ((int64_t)ROWS * RS) + (item % SPB) * 32; }
-__host__ __device__ __forceinline__ size_t sp_bytes(size_t items) { return ((items + SPB - 1) / SPB) * SPB * (size_t)ROWS * 32 * sizeof(float); }
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x16 zero16() {
-  f32x16 z;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.f;
-  return z;
-}
-// All LDS reads issued so far have landed; nothing moves across.  Without it the compiler sinks every ds_read next to the MFMA that
-// consumes it (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, one LDS round trip exposed per MFMA); with it a unit's operands are
-// fetched as one burst and the MFMA chain then issues back to back.
-__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// Workgroup barrier that orders LDS traffic only (__syncthreads() also drains vmcnt, i.e. waits for the next item's prefetch loads and the
-// spectrum stores in flight; the prefetched registers are waited for where they are consumed, global stores need no ordering here).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// accumulator register r of lane (half) <-> row of the 32x32 tile
-__device__ __forceinline__ int acc_row(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
+// (a storage order with rows blocked 32 tiles wide - whole DRAM pages for the per-frequency kernels - was measured in round 2: no gain)
+__host__ __device__ __forceinline__ int64_t sp_item(int64_t item) { return pcnn_spec::sp_item(item, ROWS); }
 
 // ------------------------------------------------------------------------------------------------------------------ forward transform
-struct FwdParams {
-  const float* x; float* sp; const float* tab;
-  int H, W, C, ld, groups, cstride, cvalid;
-  int tiles_x, tiles_y, tile0, ntile;
-  int Vy, Vx, oy, ox, pad_mode; float pad_value;
-  int ylim, xlim;        // the window holds values only in its first ylim x xlim entries (gradient / input tiles of the backward pass)
-  int ext_y, ext_x;      // ... and only where the tile grid coordinate (ty Vy + r, tx Vx + c) lies inside ext_y x ext_x
-  int pack, cpt, tgx;    // layers of <= 16 channels: `pack` x-adjacent tiles share the 32 lanes (lane = cpt * tile + channel, cpt = 32 / pack);
-                         // tgx = tile groups per tile row; an "item" is then a tile GROUP and tile0 / ntile count groups
-};
-
 // one (tile, channel group) work item as the loader sees it: a wave-uniform image base plus 32-bit per-lane offsets (so the loads take
 // the scalar-base + vector-offset form and no 64-bit address lives in vector registers)
 struct FwdItem {
@@ -244,14 +212,6 @@ __global__ __launch_bounds__(512, 1) void spec_fwd_kernel(FwdParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ inverse transform + epilogue
-struct InvParams {
-  const float* sp; const float* tab;
-  float* y; const float* bias; const float* bn_scale; const float* bn_shift; const float* res; float* act_out; unsigned* absmax;
-  int Ho, Wo, C, ldy, ld_res, ld_act, groups, cstride, cvalid, act; float alpha;
-  int tiles_x, tiles_y, tile0, ntile, Vy, Vx;
-  int flip;              // store output pixel (y, x) at (Ho-1-y, Wo-1-x): the input-partitioned weight gradient comes out tap-reversed
-  int pack, cpt, tgx;    // tile packing, as in FwdParams (flip requires pack == 1)
-};
 
 // unit u of wave (q, h): complex column fx = 1 + q + 4u, input frequencies fy of parity h (K = (part, m), fy = 2 m + h), or - q == 3, u == 3 -
 // the real column 0 / 16 (all 32 half-complex entries).  `in` is the item's uniform base, `loff` = RS half + c the lane's offset.
@@ -411,7 +371,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ per-frequency channel mixing
-struct MixParams { const float* xs; float* ys; const float* M; const int4* slots; int ntile, gin, gout; };
+struct MixParams { const float* xs; float* ys; const float* M; const int4* slots; int ntile, gin, gout, rows; };      // rows: spectrum rows per item (T*T)
 
 // K order inside one 64-row block of M_f (one input channel group): step ks = 16 p + j pairs channel j (lanes 0-31) with channel 16 + j
 // (lanes 32-63) of part p (0: real row, 1: imaginary row) - so a lane's A operands are 16 CONSECUTIVE channels of its tile's row.
@@ -435,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   const int mstride = gridDim.y * 4;
   auto load_a = [&](int mt, int gi, f32x4 (&a)[2][4]) {
     const int tile = min(mt * 32 + c, p.ntile - 1);
-    const float* base = p.xs + sp_item((int64_t)tile * GIN + gi) + 16 * half;
+    const float* base = p.xs + pcnn_spec::sp_item((int64_t)tile * GIN + gi, p.rows) + 16 * half;
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
       a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * RS + 4 * j4);
@@ -471,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int trow = mt * 32 + acc_row(r, half);
-        p.ys[sp_item((int64_t)trow * p.gout + go) + row * RS + c] = acc[nt][r];            // rows >= ntile: padding of the buffer (pad32)
+        p.ys[pcnn_spec::sp_item((int64_t)trow * p.gout + go, p.rows) + row * RS + c] = acc[nt][r];            // rows >= ntile: padding of the buffer (pad32)
       }
     }
   };
@@ -481,11 +441,74 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   for (mt += mstride; mt < nMt; mt += mstride) m_tile(mt);
 }
 
+// The same product with M_f held in LDS (16 KB per input channel group, shared by the workgroup's four waves) instead of 64 registers per
+// lane: under 128 registers a CU holds 16 waves instead of 8, i.e. twice the operand loads in flight - the kernel is bound by the latency of
+// its 128-byte row gathers (64 KB in flight per CU cover ~4 TB/s), not by the matrix pipes (one ds_read_b32 per MFMA is far below the LDS rate).
+template <int GIN>
+__global__ __launch_bounds__(256, 4) void spec_mix_lds_kernel(MixParams p) {
+  __shared__ float Bl[GIN * 32 * 2 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int slot = blockIdx.x, go = blockIdx.z;
+  const int4 sl = p.slots[slot];
+  const int rr = sl.x, ri = sl.y;
+  for (int i = tid; i < GIN * 32 * 2 * 64; i += 256) {
+    const int l = i & 63, nt = (i >> 6) & 1, ks = (i >> 7) & 31, gi = i >> 12;
+    const int k = (ks >> 4) * 32 + (ks & 15) + 16 * (l >> 5);
+    Bl[i] = p.M[((((int64_t)slot * p.gout + go) * GIN + gi) * 64 + k) * 64 + nt * 32 + (l & 31)];
+  }
+  __syncthreads();
+  const int nMt = (p.ntile + 31) >> 5;
+  const int mstride = gridDim.y * 4;
+  auto load_a = [&](int mt, int gi, f32x4 (&a)[2][4]) {
+    const int tile = min(mt * 32 + c, p.ntile - 1);
+    const float* base = p.xs + pcnn_spec::sp_item((int64_t)tile * GIN + gi, p.rows) + 16 * half;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * RS + 4 * j4);
+      a[1][j4] = *reinterpret_cast<const f32x4*>(base + ri * RS + 4 * j4);
+    }
+  };
+  f32x4 a[2][4], an[2][4];
+  int mt = blockIdx.y * 4 + wave;
+  if (mt >= nMt) return;
+  load_a(mt, 0, a);
+  auto m_tile = [&](int mt) {
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int gi = 0; gi < GIN; ++gi) {
+      if (gi + 1 < GIN) load_a(mt, gi + 1, an);
+      else if (mt + mstride < nMt) load_a(mt + mstride, 0, an);
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        const float av = a[ks >> 4][(ks & 15) >> 2][ks & 3];
+        acc[0] = mfma(av, Bl[((gi * 32 + ks) * 2 + 0) * 64 + lane], acc[0]);
+        acc[1] = mfma(av, Bl[((gi * 32 + ks) * 2 + 1) * 64 + lane], acc[1]);
+        if ((ks & 3) == 3) asm volatile("" ::: "memory");           // keeps the LDS reads in groups of eight: unfenced, all 64 are hoisted (spills)
+      }
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) a[pp][j4] = an[pp][j4];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = nt ? ri : rr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = mt * 32 + acc_row(r, half);
+        p.ys[pcnn_spec::sp_item((int64_t)trow * p.gout + go, p.rows) + row * RS + c] = acc[nt][r];
+      }
+    }
+  };
+  m_tile(mt);
+  for (mt += mstride; mt < nMt; mt += mstride) m_tile(mt);
+}
+
 // M_f from the filter spectrum Wsp[ci * gout + go][row][co % 32] (conj: correlation).
 // M[slot][go][gi][k = 32 part_in + ci % 32][n = 32 part_out + co % 32]
 // cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and M_f is block diagonal - a tile's channels mix only among themselves.
-__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout, int cpt) {
-  const int64_t total = (int64_t)NSLOT * gout * gin * 64 * 64;
+__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout, int cpt, int rows) {
+  const int64_t total = (int64_t)(rows / 2) * gout * gin * 64 * 64;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int nn = i & 63; int64_t r = i >> 6; const int k = r & 63; r >>= 6; const int gi = r % gin; r /= gin; const int go = r % gout; const int slot = r / gout;
     const int pin = k >> 5, pout = nn >> 5;
@@ -495,7 +518,7 @@ __global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4*
     const int4 sl = slots[slot];
     float v = 0.f;
     if (ci < Cin && same_tile) {
-      const float* wg = wsp + sp_item(ci * gout + go) + co;
+      const float* wg = wsp + pcnn_spec::sp_item(ci * gout + go, rows) + co;
       const float wr = wg[sl.x * RS], wi = wg[sl.y * RS];
       if (sl.z == 1) v = (pin == 0 && pout == 0) ? wr : ((pin == 1 && pout == 1) ? wi : 0.f);     // two real frequencies packed in one slot
       else v = pin == pout ? wr : (pin == 0 ? -wi : wi);                                          // [[Hr, Hi], [-Hi, Hr]], H = conj(W)
@@ -505,7 +528,7 @@ __global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4*
 }
 
 // ------------------------------------------------------------------------------------------------------------------ weight gradient
-struct WMixParams { const float* xs; const float* ds; float* part; const int4* slots; int ntile, gin, S, accumulate; };
+struct WMixParams { const float* xs; const float* ds; float* part; const int4* slots; int ntile, gin, S, accumulate, rows, nslot; };
 
 // P[slot][gi][quadrant][ci][co] = sum over tiles of [Xr | Xi]^T [Dr | Di]: quadrant 0 = Xr^T Dr, 1 = Xi^T Dr, 2 = Xr^T Di, 3 = Xi^T Di.
 // One wave owns all four quadrants (each operand row is loaded once per tile pair: 4 loads feed 4 MFMAs) for its share of the tiles:
@@ -529,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
     for (int u = 0; u < WU; ++u) {
       const int tt = tb + 2 * u + half;
       const unsigned tc = (unsigned)(tt < t1 ? tt : t0);
-      const unsigned ix = (unsigned)sp_item((int64_t)tc * p.gin + gi) + c, id = (unsigned)sp_item(tc) + c;
+      const unsigned ix = (unsigned)pcnn_spec::sp_item((int64_t)tc * p.gin + gi, p.rows) + c, id = (unsigned)pcnn_spec::sp_item(tc, p.rows) + c;
       a0[u] = xr[ix]; a1[u] = xi[ix]; b0[u] = dr[id]; b1[u] = di[id];
     }
   };
@@ -548,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
 #pragma unroll
     for (int u = 0; u < WU; ++u) { ar[u] = nar[u]; ai[u] = nai[u]; br[u] = nbr[u]; bi[u] = nbi[u]; }
   }
-  float* o = p.part + (((int64_t)part * NSLOT + slot) * p.gin + gi) * 4 * 1024 + c;
+  float* o = p.part + (((int64_t)part * p.nslot + slot) * p.gin + gi) * 4 * 1024 + c;
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     float old[16];                                                   // accumulate: the quadrant's old values as one burst (a load between two
@@ -564,8 +587,9 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
 // C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
 // Output: spectrum of a one-tile image with Cin*Cout channels, group = ci, lane = co.
 // cpt < 32 (tile packing): the wanted products are the 32 / cpt diagonal blocks (tile with itself); they are summed here.
-__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin, float isign, int cpt) {
-  const int64_t total = (int64_t)NSLOT * gin * 1024;
+__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin, float isign, int cpt, int rows) {
+  const int nslot = rows / 2;
+  const int64_t total = (int64_t)nslot * gin * 1024;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = i & 1023; int64_t r = i >> 10; const int gi = r % gin; const int slot = r / gin;
     const int cil = e >> 5, co = e & 31, ci = gi * 32 + cil;
@@ -573,15 +597,15 @@ __global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4*
     float P[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s)
       for (int sub = 0; sub < 32 / cpt; ++sub) {
-        const float* b = part + (((int64_t)s * NSLOT + slot) * gin + gi) * 4 * 1024 + (sub * cpt + cil) * 32 + sub * cpt + co;
+        const float* b = part + (((int64_t)s * nslot + slot) * gin + gi) * 4 * 1024 + (sub * cpt + cil) * 32 + sub * cpt + co;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) P[qd] += b[qd * 1024];
       }
     const int4 sl = slots[slot];
     // P[0] = Xr^T Dr, P[1] = Xi^T Dr, P[2] = Xr^T Di, P[3] = Xi^T Di
     const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : isign * (P[1] - P[2]);     // isign = -1: conj(X^) D^ instead of X^ conj(D^)
-    csp[sp_item(ci) + sl.x * RS + co] = cr;
-    csp[sp_item(ci) + sl.y * RS + co] = cim;
+    csp[pcnn_spec::sp_item(ci, rows) + sl.x * RS + co] = cr;
+    csp[pcnn_spec::sp_item(ci, rows) + sl.y * RS + co] = cim;
   }
 }
 
@@ -629,58 +653,68 @@ void build_tables(std::vector<float>& tab, std::vector<int>& slots) {
     for (int fy = 0; fy < 32; ++fy) slots.insert(slots.end(), {64 + 64 * (fx - 1) + fy, 64 + 64 * (fx - 1) + 32 + fy, 0, 0});
 }
 
-struct Workspace {           // carved out of the handle's spectral workspace
-  float* tab; int4* slots; float* wsp; float* M; float* xs; float* ys; float* part; float* csp;
-};
+// The transform geometry of one call: tile size, spectrum rows per item, mixing slots, and the device tables of that size.
+struct Geom { int T, rows, nslot; const float* tab; const int4* slots; };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // the channel-mixing kernel writes whole 32-tile M-tiles (unconditional stores: their number per pass is then static): its output spectra are
 // allocated for a multiple of 32 tiles; the rows of tiles that do not exist are never read
 int pad32(int tiles) { return (tiles + 31) & ~31; }
 
-int chunk_tiles() {
+int chunk_tiles(int Tg) {
   // tiles per launch of the transform / mixing kernels: 32 768 covers a whole 8 x 1024^2 layer (26 k tiles at 15 taps) - 4 GB of spectrum per
-  // buffer, which 288 GB of HBM can afford; fewer, longer launches = fewer tails (8 192: + 1.8 % on the train step, 4 096: + 5.8 %)
+  // buffer, which 288 GB of HBM can afford; fewer, longer launches = fewer tails (8 192: + 1.8 % on the train step, 4 096: + 5.8 %).
+  // A 64-point tile holds four times the rows: a quarter of the tiles is the same number of bytes.
   static const int v = getenv("PCNN_SPEC_CHUNK") ? atoi(getenv("PCNN_SPEC_CHUNK")) : 32768;
-  return v < 32 ? 32 : v;
+  const int t = Tg == 64 ? v / 4 : v;
+  return t < 32 ? 32 : t;
 }
 int wgrad_splits() { return 8; }   // partial sums of the weight-gradient GEMM: 2 workgroups x 4 waves per (slot, channel group)
 
-// grows the handle's workspace; the constant tables live at its start and are (re)uploaded after every growth
-int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, Workspace& ws, int gin, int gout, int cin, int chunk) {
-  const size_t o_tab = 0, o_slots = align256(TAB_FLOATS * 4), o_rest = o_slots + align256(NSLOT * 16);
-  const size_t need = o_rest + bytes_after_tables;
+// workspace header: the constant tables of both tile sizes; the per-call regions follow
+constexpr size_t O_TAB32 = 0, O_SLOTS32 = O_TAB32 + ((TAB_FLOATS * 4 + 255) & ~255), O_TAB64 = O_SLOTS32 + NSLOT * 16,
+                 O_SLOTS64 = O_TAB64 + TAB64_FLOATS * 4, O_REST = O_SLOTS64 + 2048 * 16;
+static_assert(O_REST % 256 == 0, "workspace header alignment");
+
+// grows the handle's workspace (never beyond the caller's limit, pcnn_set_workspace_limit); the tables are (re)uploaded after every growth
+int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, char** rest) {
+  const size_t need = O_REST + bytes_after_tables;
   if (h->spec_ws_bytes < need) {
+    if (h->spec_ws_limit && need > h->spec_ws_limit)
+      PCNN_FAIL(h, "spectral convolution: %zu B of workspace needed, the caller allows %zu B (pcnn_set_workspace_limit)", need, h->spec_ws_limit);
     if (h->spec_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->spec_ws); h->spec_ws = nullptr; h->spec_ws_bytes = 0; }
-    const size_t cap = need + need / 8;
+    size_t cap = need + need / 8;
+    if (h->spec_ws_limit && cap > h->spec_ws_limit) cap = h->spec_ws_limit;
     if (hipMalloc(&h->spec_ws, cap) != hipSuccess) PCNN_FAIL(h, "spectral convolution: cannot allocate %zu B of workspace", cap);
     h->spec_ws_bytes = cap;
-    static std::vector<float> tab; static std::vector<int> slots;          // static: the async copies below read them after this call returns
-    if (tab.empty()) build_tables(tab, slots);
-    if (hipMemcpyAsync(static_cast<char*>(h->spec_ws) + o_tab, tab.data(), TAB_FLOATS * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipMemcpyAsync(static_cast<char*>(h->spec_ws) + o_slots, slots.data(), NSLOT * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+    static std::vector<float> tab, tab64; static std::vector<int> slots, slots64;   // static: the async copies below read them after this call returns
+    if (tab.empty()) {
+      build_tables(tab, slots);
+      tab64.resize(TAB64_FLOATS); slots64.resize(2048 * 4);
+      build_tables64(tab64.data(), slots64.data());
+    }
+    char* b = static_cast<char*>(h->spec_ws);
+    if (hipMemcpyAsync(b + O_TAB32, tab.data(), TAB_FLOATS * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(b + O_SLOTS32, slots.data(), NSLOT * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(b + O_TAB64, tab64.data(), TAB64_FLOATS * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(b + O_SLOTS64, slots64.data(), 2048 * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess)
       PCNN_FAIL(h, "spectral convolution: table upload failed");
   }
-  char* b = static_cast<char*>(h->spec_ws);
-  ws.tab = reinterpret_cast<float*>(b + o_tab);
-  ws.slots = reinterpret_cast<int4*>(b + o_slots);
-  char* r = b + o_rest;
-  const size_t wsp_b = align256(sp_bytes((size_t)cin * gout)), M_b = align256((size_t)NSLOT * gin * gout * 64 * 64 * 4);
-  const size_t xs_b = align256(sp_bytes((size_t)chunk * gin)), ys_b = align256(sp_bytes((size_t)pad32(chunk) * gout));
-  ws.wsp = reinterpret_cast<float*>(r); r += wsp_b;                        // filter spectrum (forward) / C^ (weight gradient)
-  ws.M = reinterpret_cast<float*>(r); r += M_b;
-  ws.xs = reinterpret_cast<float*>(r); r += xs_b;
-  ws.ys = reinterpret_cast<float*>(r); r += ys_b;
-  ws.part = reinterpret_cast<float*>(r);
-  ws.csp = ws.wsp;
+  *rest = static_cast<char*>(h->spec_ws) + O_REST;
   return 0;
 }
 
-size_t workspace_bytes(int gin, int gout, int cin, int chunk, bool wgrad) {
-  size_t b = align256(sp_bytes((size_t)cin * gout)) + align256((size_t)NSLOT * gin * gout * 64 * 64 * 4) +
-             align256(sp_bytes((size_t)chunk * gin)) + align256(sp_bytes((size_t)pad32(chunk) * gout));
-  if (wgrad) b += align256((size_t)wgrad_splits() * NSLOT * gin * 4 * 1024 * 4);
-  return b;
+// under a caller's workspace limit the launches cover fewer tiles each (never fewer than 32): halve until the call's regions fit
+template <typename F>
+int fit_chunk(pcnn_handle h, int chunk, F bytes_for) {
+  while (h->spec_ws_limit && chunk > 32 && O_REST + bytes_for(chunk) > h->spec_ws_limit) chunk = std::max(32, chunk / 2);
+  return chunk;
+}
+
+Geom geom_of(pcnn_handle h, int Tg) {
+  char* b = static_cast<char*>(h->spec_ws);
+  if (Tg == 64) return Geom{64, 4096, 2048, reinterpret_cast<const float*>(b + O_TAB64), reinterpret_cast<const int4*>(b + O_SLOTS64)};
+  return Geom{32, ROWS, NSLOT, reinterpret_cast<const float*>(b + O_TAB32), reinterpret_cast<const int4*>(b + O_SLOTS32)};
 }
 
 template <typename K>
@@ -692,9 +726,10 @@ void launch_fwd_t(pcnn_handle h, const FwdParams& p, int ntile) {
   set_lds(spec_fwd_kernel<MASKED, FENCE>);
   hipLaunchKernelGGL((spec_fwd_kernel<MASKED, FENCE>), dim3((unsigned)std::min(ntile * p.groups, 256)), dim3(512), LDS_U, h->stream, p);
 }
-void launch_fwd(pcnn_handle h, FwdParams p, int ntile) {
+void launch_fwd(pcnn_handle h, const Geom& gm, FwdParams p, int ntile) {
   static const int fence = getenv("PCNN_SPEC_FENCE") ? atoi(getenv("PCNN_SPEC_FENCE")) : 0;
-  p.ntile = ntile;
+  p.ntile = ntile; p.tab = gm.tab;
+  if (gm.T == 64) { launch_fwd64(h, p, ntile); return; }
   const bool masked = p.ylim < T || p.xlim < T;
   if (masked) { if (fence) launch_fwd_t<true, true>(h, p, ntile); else launch_fwd_t<true, false>(h, p, ntile); }
   else { if (fence) launch_fwd_t<false, true>(h, p, ntile); else launch_fwd_t<false, false>(h, p, ntile); }
@@ -704,8 +739,9 @@ void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
   set_lds(spec_inv_kernel<TANH, RES>);
   hipLaunchKernelGGL((spec_inv_kernel<TANH, RES>), grid, dim3(512), LDS_U, h->stream, p);
 }
-void launch_inv(pcnn_handle h, InvParams p, int ntile) {
-  p.ntile = ntile;
+void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
+  p.ntile = ntile; p.tab = gm.tab;
+  if (gm.T == 64) { launch_inv64(h, p, ntile); return; }
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.act == PCNN_ACT_TANH) {
     if (p.res) launch_inv_t<true, true>(h, p, grid); else launch_inv_t<true, false>(h, p, grid);
@@ -713,6 +749,21 @@ void launch_inv(pcnn_handle h, InvParams p, int ntile) {
     p.alpha = p.act == PCNN_ACT_LINEAR ? 1.f : (p.act == PCNN_ACT_RELU ? 0.f : p.alpha);     // slope of the negative side
     if (p.res) launch_inv_t<false, true>(h, p, grid); else launch_inv_t<false, false>(h, p, grid);
   }
+}
+
+void launch_mix(pcnn_handle h, const Geom& gm, MixParams mx, int gin, int gout, int nt) {
+  static const int variant = getenv("PCNN_SPEC_MIX") ? atoi(getenv("PCNN_SPEC_MIX")) : 0;        // 0: M_f in registers, 1: M_f in LDS (16 waves per CU)
+  mx.slots = gm.slots; mx.rows = gm.rows; mx.ntile = nt;
+  const int nMt = pcnn_cdiv(nt, 32);
+  if (variant == 1) {
+    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 6));
+    if (gin == 1) hipLaunchKernelGGL(spec_mix_lds_kernel<1>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
+    else hipLaunchKernelGGL(spec_mix_lds_kernel<2>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
+    return;
+  }
+  const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
+  if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
+  else hipLaunchKernelGGL(spec_mix_kernel<2>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
 }
 
 // tiles per lane group for a layer of Cin -> Cout channels: both sides must fit `cpt` lanes (a power of two >= 4)
@@ -723,7 +774,26 @@ int pack_for(int Cin, int Cout) {
   return c <= 4 ? 8 : (c <= 8 ? 4 : 2);
 }
 
+// Tile size of a layer's spectral route.  64-point tiles halve the spectrum volume of the 11..15-tap layers ((64/50)^2 = 1.6 values per output
+// pixel at 15 taps against (32/18)^2 = 3.2) at about the matrix-core work per pixel of the 32-point tiles; below 11 taps their transforms cost
+// more than the mixing pass saves, layers of <= 16 channels keep the tile-packed 32-point form, and the inverse kernel holds the rows of a
+// tile's valid region in 7 accumulator sets per wave (56 rows: >= 9 taps).  Decided on ONE image (>= 36 tiles of 64 points), like the route.
+int pick_tile(pcnn_handle h, const pcnn_conv_desc* d) {
+  const int forced = h->spectral_tile;                     // pcnn_set_spectral_tile / environment PCNN_SPEC_T
+  const bool can64 = d->kh >= 9 && d->kw >= 9 && d->kh <= 15 && d->kw <= 15 && pack_for(d->Cin, d->Cout) == 1;
+  if (forced == 32 || !can64) return 32;
+  if (forced == 64) return 64;
+  const int Vy = 65 - d->kh, Vx = 65 - d->kw;
+  return (d->kh >= 11 && d->kw >= 11 && pcnn_cdiv(d->Ho, Vy) * pcnn_cdiv(d->Wo, Vx) >= 36) ? 64 : 32;
+}
+
 }  // namespace
+
+extern "C" int pcnn_set_workspace_limit(pcnn_handle h, size_t bytes) {
+  if (!h) return 1;
+  h->spec_ws_limit = bytes;
+  return 0;
+}
 
 // Route choice.  Both estimates are calibrated on MI355X measurements at 8 x 1024^2 (tools/probe_spectral.py, profiles/r02_probe_spectral.txt):
 // the spectral route costs a fixed time per 32 x 32 tile whatever the filter size (0.21 us per tile with <= 32 channels, 0.33 us with
@@ -758,91 +828,122 @@ bool pcnn_conv_fwd_takes_narrow_route(pcnn_handle h, const pcnn_conv_desc* d) {
   return pcnn_conv_small_fwd_eligible(d) && !(d->kh == 5 && pcnn_spectral_eligible(h, d, false));
 }
 
+namespace {
+// the filter as a kh x kw one-tile "image" with Cin*Cout channels (group = ci [x output group], lane = co): its spectrum feeds the mixing matrices
+FwdParams filter_params(const Geom& gm, const float* w, float* wsp, int kh, int kw, int Cin, int Cout, int gout) {
+  FwdParams fw;
+  fw.x = w; fw.sp = wsp; fw.tab = gm.tab; fw.H = kh; fw.W = kw; fw.C = Cin * Cout; fw.ld = Cin * Cout; fw.groups = Cin * gout;
+  fw.cstride = gout > 1 ? 32 : Cout; fw.cvalid = gout > 1 ? 32 : Cout;     // group ci * gout + go holds output channels 32 go .. 32 go + 31
+  fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.ntile = 1; fw.Vy = gm.T; fw.Vx = gm.T; fw.oy = 0; fw.ox = 0;
+  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = gm.T; fw.xlim = gm.T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
+  fw.pack = 1; fw.cpt = 32; fw.tgx = 1;
+  return fw;
+}
+// the weight gradient's spectrum C^ (one tile, Cin*Cout channels) back to its kh x kw taps
+InvParams taps_params(const Geom& gm, const float* csp, float* dw, int kh, int kw, int Cin, int Cout, int flip) {
+  InvParams iv;
+  iv.sp = csp; iv.tab = gm.tab; iv.y = dw; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = nullptr; iv.act_out = nullptr;
+  iv.absmax = nullptr; iv.Ho = kh; iv.Wo = kw; iv.C = Cin * Cout; iv.ldy = Cin * Cout; iv.ld_res = 0; iv.ld_act = 0;
+  iv.groups = Cin; iv.cstride = Cout; iv.cvalid = Cout; iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f;
+  iv.tiles_x = 1; iv.tiles_y = 1; iv.tile0 = 0; iv.ntile = 1; iv.Vy = gm.T; iv.Vx = gm.T; iv.flip = flip; iv.pack = 1; iv.cpt = 32; iv.tgx = 1;
+  return iv;
+}
+}  // namespace
+
 int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                            const float* bn_shift, const float* residual, float* y, float* act_out) {
-  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const int Tg = pick_tile(h, d);
+  const int Vy = Tg - d->kh + 1, Vx = Tg - d->kw + 1;
   const int tiles_y = pcnn_cdiv(d->Ho, Vy), tiles_x = pcnn_cdiv(d->Wo, Vx);
-  const int pack = pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
+  const int pack = Tg == 64 ? 1 : pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
   const int64_t ntile = (int64_t)d->N * tiles_y * tgx;                       // tile groups (= tiles when pack == 1)
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gin = pcnn_cdiv(d->Cin, 32), gout = pcnn_cdiv(d->Cout, 32);
-  const int chunk = (int)std::min<int64_t>(chunk_tiles() / (gin > gout ? gin : gout), ntile);
-  Workspace ws;
-  if (int rc = ensure_workspace(h, workspace_bytes(gin, gout, d->Cin, chunk, false), ws, gin, gout, d->Cin, chunk)) return rc;
-  // filter spectrum: the filter as a kh x kw image with Cin*Cout channels, group = ci, lane = co
-  FwdParams fw;
-  fw.x = w; fw.sp = ws.wsp; fw.tab = ws.tab; fw.H = d->kh; fw.W = d->kw; fw.C = d->Cin * d->Cout; fw.ld = d->Cin * d->Cout; fw.groups = d->Cin * gout;
-  fw.cstride = gout > 1 ? 32 : d->Cout; fw.cvalid = gout > 1 ? 32 : d->Cout;     // group ci * gout + go holds output channels 32 go .. 32 go + 31
-  fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
-  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
-  fw.pack = 1; fw.cpt = 32; fw.tgx = 1;
-  launch_fwd(h, fw, 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, ws.wsp, ws.slots, ws.M, d->Cin, gin, gout, cpt);
+  const int rows = Tg * Tg, nslot = rows / 2;
+  // workspace: [filter spectrum | M | input spectra | output spectra]
+  const size_t wsp_b = align256(sp_bytes((size_t)d->Cin * gout, rows)), M_b = align256((size_t)nslot * gin * gout * 64 * 64 * 4);
+  auto xs_bytes = [&](int ch) { return align256(sp_bytes((size_t)ch * gin, rows)); };
+  auto ys_bytes = [&](int ch) { return align256(sp_bytes((size_t)pad32(ch) * gout, rows)); };
+  const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / (gin > gout ? gin : gout), ntile), [&](int ch) { return wsp_b + M_b + xs_bytes(ch) + ys_bytes(ch); });
+  const size_t xs_b = xs_bytes(chunk), ys_b = ys_bytes(chunk);
+  char* r;
+  if (int rc = ensure_workspace(h, wsp_b + M_b + xs_b + ys_b, &r)) return rc;
+  const Geom gm = geom_of(h, Tg);
+  float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
+  float* Mm = reinterpret_cast<float*>(r); r += M_b;
+  float* xs = reinterpret_cast<float*>(r); r += xs_b;
+  float* ys = reinterpret_cast<float*>(r);
+  launch_fwd(h, gm, filter_params(gm, w, wsp, d->kh, d->kw, d->Cin, d->Cout, gout), 1);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, gm.slots, Mm, d->Cin, gin, gout, cpt, rows);
   PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
   FwdParams fx;
-  fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
+  fx.x = x; fx.sp = xs; fx.tab = gm.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
   fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
-  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
+  fx.pad_value = d->pad_value; fx.ylim = Tg; fx.xlim = Tg; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
   fx.pack = pack; fx.cpt = cpt; fx.tgx = tgx;
   if (pack > 1) { fx.cstride = cpt; fx.cvalid = cpt; }
   InvParams iv;
-  iv.sp = ws.ys; iv.tab = ws.tab; iv.y = y; iv.bias = bias; iv.bn_scale = bn_scale; iv.bn_shift = bn_shift; iv.res = residual; iv.act_out = act_out;
+  iv.sp = ys; iv.tab = gm.tab; iv.y = y; iv.bias = bias; iv.bn_scale = bn_scale; iv.bn_shift = bn_shift; iv.res = residual; iv.act_out = act_out;
   iv.absmax = reinterpret_cast<unsigned*>(h->y_absmax);
   iv.Ho = d->Ho; iv.Wo = d->Wo; iv.C = d->Cout; iv.ldy = d->ldy; iv.ld_res = d->ld_res; iv.ld_act = d->ld_act_out; iv.groups = gout; iv.cstride = 32; iv.cvalid = 32;
   iv.act = d->act; iv.alpha = d->act_alpha; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx; iv.flip = 0;
   iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
   if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
   MixParams mx;
-  mx.xs = ws.xs; mx.ys = ws.ys; mx.M = ws.M; mx.slots = ws.slots; mx.gin = gin; mx.gout = gout;
+  mx.xs = xs; mx.ys = ys; mx.M = Mm; mx.gin = gin; mx.gout = gout;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
-    fx.tile0 = (int)t0; iv.tile0 = (int)t0; mx.ntile = nt;
-    launch_fwd(h, fx, nt);
-    const int nMt = pcnn_cdiv(nt, 32);
-    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
-    if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy, gout), dim3(256), 0, h->stream, mx);
-    else hipLaunchKernelGGL(spec_mix_kernel<2>, dim3(NSLOT, gy, gout), dim3(256), 0, h->stream, mx);
-    launch_inv(h, iv, nt);
+    fx.tile0 = (int)t0; iv.tile0 = (int)t0;
+    launch_fwd(h, gm, fx, nt);
+    launch_mix(h, gm, mx, gin, gout, nt);
+    launch_inv(h, gm, iv, nt);
   }
   PCNN_CHECK_LAUNCH(h, "spectral convolution");
   return 0;
 }
 
 int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw) {
-  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const int Tg = pick_tile(h, d);
+  const int Vy = Tg - d->kh + 1, Vx = Tg - d->kw + 1;
   const int tiles_y = pcnn_cdiv(d->Ho, Vy), tiles_x = pcnn_cdiv(d->Wo, Vx);
-  const int pack = pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
+  const int pack = Tg == 64 ? 1 : pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
   const int64_t ntile = (int64_t)d->N * tiles_y * tgx;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gin = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();
-  const int chunk = (int)std::min<int64_t>(chunk_tiles() / gin, ntile);
-  Workspace ws;
-  if (int rc = ensure_workspace(h, workspace_bytes(gin, 1, d->Cin, chunk, true), ws, gin, 1, d->Cin, chunk)) return rc;
+  const int rows = Tg * Tg, nslot = rows / 2;
+  // workspace: [C^ | x window spectra | dz tile spectra | partial sums]
+  const size_t csp_b = align256(sp_bytes((size_t)d->Cin, rows)), part_b = align256((size_t)S * nslot * gin * 4 * 1024 * 4);
+  auto xs_bytes = [&](int ch) { return align256(sp_bytes((size_t)ch * gin, rows)); };
+  auto zs_bytes = [&](int ch) { return align256(sp_bytes((size_t)ch, rows)); };
+  const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / gin, ntile), [&](int ch) { return csp_b + part_b + xs_bytes(ch) + zs_bytes(ch); });
+  const size_t xs_b = xs_bytes(chunk), zs_b = zs_bytes(chunk);
+  char* r;
+  if (int rc = ensure_workspace(h, csp_b + xs_b + zs_b + part_b, &r)) return rc;
+  const Geom gm = geom_of(h, Tg);
+  float* csp = reinterpret_cast<float*>(r); r += csp_b;
+  float* xs = reinterpret_cast<float*>(r); r += xs_b;
+  float* zs = reinterpret_cast<float*>(r); r += zs_b;
+  float* part = reinterpret_cast<float*>(r);
   FwdParams fx;
-  fx.x = x; fx.sp = ws.xs; fx.tab = ws.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
+  fx.x = x; fx.sp = xs; fx.tab = gm.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
   fx.tiles_x = tiles_x; fx.tiles_y = tiles_y; fx.Vy = Vy; fx.Vx = Vx; fx.oy = d->pad_top; fx.ox = d->pad_left; fx.pad_mode = d->pad_mode;
-  fx.pad_value = d->pad_value; fx.ylim = T; fx.xlim = T; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
+  fx.pad_value = d->pad_value; fx.ylim = Tg; fx.xlim = Tg; fx.ext_y = 1 << 30; fx.ext_x = 1 << 30;
   fx.pack = pack; fx.cpt = cpt; fx.tgx = tgx;
   if (pack > 1) { fx.cstride = cpt; fx.cvalid = cpt; }
   FwdParams fz = fx;                                    // dz: the tile's own Vy x Vx outputs, zero elsewhere in the window
-  fz.x = dz; fz.sp = ws.ys; fz.H = d->Ho; fz.W = d->Wo; fz.C = d->Cout; fz.ld = d->ldy; fz.groups = 1; fz.oy = 0; fz.ox = 0;
+  fz.x = dz; fz.sp = zs; fz.H = d->Ho; fz.W = d->Wo; fz.C = d->Cout; fz.ld = d->ldy; fz.groups = 1; fz.oy = 0; fz.ox = 0;
   fz.pad_mode = PCNN_PAD_CONSTANT; fz.pad_value = 0.f; fz.ylim = Vy; fz.xlim = Vx;
   WMixParams wm;
-  wm.xs = ws.xs; wm.ds = ws.ys; wm.part = ws.part; wm.slots = ws.slots; wm.gin = gin; wm.S = S / 4;
+  wm.xs = xs; wm.ds = zs; wm.part = part; wm.slots = gm.slots; wm.gin = gin; wm.S = S / 4; wm.rows = rows; wm.nslot = nslot;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
     fx.tile0 = (int)t0; fz.tile0 = (int)t0; wm.ntile = nt; wm.accumulate = t0 > 0;
-    launch_fwd(h, fx, nt);
-    launch_fwd(h, fz, nt);
-    hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S / 4, gin), dim3(256), 0, h->stream, wm);
+    launch_fwd(h, gm, fx, nt);
+    launch_fwd(h, gm, fz, nt);
+    hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gin), dim3(256), 0, h->stream, wm);
   }
-  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, ws.part, ws.slots, ws.csp, S, gin, d->Cin, 1.0f, cpt);
-  InvParams iv;
-  iv.sp = ws.csp; iv.tab = ws.tab; iv.y = dw; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = nullptr; iv.act_out = nullptr;
-  iv.absmax = nullptr; iv.Ho = d->kh; iv.Wo = d->kw; iv.C = d->Cin * d->Cout; iv.ldy = d->Cin * d->Cout; iv.ld_res = 0; iv.ld_act = 0;
-  iv.groups = d->Cin; iv.cstride = d->Cout; iv.cvalid = d->Cout; iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f;
-  iv.tiles_x = 1; iv.tiles_y = 1; iv.tile0 = 0; iv.Vy = T; iv.Vx = T; iv.flip = 0; iv.pack = 1; iv.cpt = 32; iv.tgx = 1;
-  launch_inv(h, iv, 1);
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, gm.slots, csp, S, gin, d->Cin, 1.0f, cpt, rows);
+  launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 0), 1);
   PCNN_CHECK_LAUNCH(h, "spectral weight gradient");
   return 0;
 }
@@ -866,20 +967,24 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   PCNN_REQUIRE(h, h && d && dg && x && dz && w_flipped && dx && dw, "pcnn_conv2d_bwd_spectral: null argument");
   PCNN_REQUIRE(h, pcnn_conv2d_bwd_spectral_eligible(h, d, dg), "pcnn_conv2d_bwd_spectral: layer is not eligible (ask pcnn_conv2d_bwd_spectral_eligible first)");
   PCNN_REQUIRE(h, dg->Cin == d->Cout && dg->Cout == d->Cin && dg->kh == d->kh && dg->kw == d->kw && dg->N == d->N, "pcnn_conv2d_bwd_spectral: descriptors do not match");
-  const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
+  const int Tg = pick_tile(h, dg);
+  const int Vy = Tg - d->kh + 1, Vx = Tg - d->kw + 1;
   const int tiles_y = pcnn_cdiv(dg->Ho, Vy), tiles_x = pcnn_cdiv(dg->Wo, Vx);
-  const int pack = pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
+  const int pack = Tg == 64 ? 1 : pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
   const int64_t ntile = (int64_t)d->N * tiles_y * tgx;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gz = 1, gx = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();       // channel groups of dz (<= 32 channels) and of x / dx
-  const int chunk = (int)std::min<int64_t>(chunk_tiles() / gx, ntile);
+  const int rows = Tg * Tg, nslot = rows / 2;
   // workspace: [filter spectrum | M | dz spectra (gz) | dx spectra (gx) | x-tile spectra (gx) | partial sums]; C^ reuses the filter-spectrum slot
-  const size_t wsp_b = align256(sp_bytes((size_t)std::max(dg->Cin * gx, d->Cin))), M_b = align256((size_t)NSLOT * gz * gx * 64 * 64 * 4);
-  const size_t zs_b = align256(sp_bytes((size_t)chunk * gz)), ys_b = align256(sp_bytes((size_t)pad32(chunk) * gx));
-  const size_t part_b = align256((size_t)S * NSLOT * gx * 4 * 1024 * 4);
-  Workspace ws;
-  if (int rc = ensure_workspace(h, wsp_b + M_b + zs_b + 2 * ys_b + part_b + 4096, ws, 1, 1, 1, 1)) return rc;
-  char* r = reinterpret_cast<char*>(ws.wsp);
+  const size_t wsp_b = align256(sp_bytes((size_t)std::max(dg->Cin * gx, d->Cin), rows)), M_b = align256((size_t)nslot * gz * gx * 64 * 64 * 4);
+  const size_t part_b = align256((size_t)S * nslot * gx * 4 * 1024 * 4);
+  auto zs_bytes = [&](int ch) { return align256(sp_bytes((size_t)ch * gz, rows)); };
+  auto ys_bytes = [&](int ch) { return align256(sp_bytes((size_t)pad32(ch) * gx, rows)); };
+  const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / gx, ntile), [&](int ch) { return wsp_b + M_b + part_b + 4096 + zs_bytes(ch) + 2 * ys_bytes(ch); });
+  const size_t zs_b = zs_bytes(chunk), ys_b = ys_bytes(chunk);
+  char* r;
+  if (int rc = ensure_workspace(h, wsp_b + M_b + zs_b + 2 * ys_b + part_b + 4096, &r)) return rc;
+  const Geom gm = geom_of(h, Tg);
   float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
   float* Mm = reinterpret_cast<float*>(r); r += M_b;
   float* zs = reinterpret_cast<float*>(r); r += zs_b;
@@ -887,20 +992,14 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   float* xs = reinterpret_cast<float*>(r); r += ys_b;
   float* part = reinterpret_cast<float*>(r);
   // flipped filter spectrum -> mixing matrices of the data gradient (input groups: dz's, output groups: dx's)
-  FwdParams fw;
-  fw.x = w_flipped; fw.sp = wsp; fw.tab = ws.tab; fw.H = d->kh; fw.W = d->kw; fw.C = dg->Cin * dg->Cout; fw.ld = dg->Cin * dg->Cout; fw.groups = dg->Cin * gx;
-  fw.cstride = gx > 1 ? 32 : dg->Cout; fw.cvalid = gx > 1 ? 32 : dg->Cout;
-  fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.Vy = T; fw.Vx = T; fw.oy = 0; fw.ox = 0;
-  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = T; fw.xlim = T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
-  fw.pack = 1; fw.cpt = 32; fw.tgx = 1;
   PCNN_REQUIRE(h, gx == 1 || dg->Cout == 64, "pcnn_conv2d_bwd_spectral: %d input channels unsupported (<= 32 or 64)", d->Cin);
-  launch_fwd(h, fw, 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, ws.slots, Mm, dg->Cin, gz, gx, cpt);
+  launch_fwd(h, gm, filter_params(gm, w_flipped, wsp, d->kh, d->kw, dg->Cin, dg->Cout, gx), 1);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, gm.slots, Mm, dg->Cin, gz, gx, cpt, rows);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral (filter spectrum)");
   FwdParams fz;                                          // dz windows with halo: the data gradient's input transform
-  fz.x = dz; fz.sp = zs; fz.tab = ws.tab; fz.H = dg->H; fz.W = dg->W; fz.C = dg->Cin; fz.ld = dg->ldx; fz.groups = gz; fz.cstride = 32; fz.cvalid = 32;
+  fz.x = dz; fz.sp = zs; fz.tab = gm.tab; fz.H = dg->H; fz.W = dg->W; fz.C = dg->Cin; fz.ld = dg->ldx; fz.groups = gz; fz.cstride = 32; fz.cvalid = 32;
   fz.tiles_x = tiles_x; fz.tiles_y = tiles_y; fz.Vy = Vy; fz.Vx = Vx; fz.oy = dg->pad_top; fz.ox = dg->pad_left; fz.pad_mode = dg->pad_mode;
-  fz.pad_value = dg->pad_value; fz.ylim = T; fz.xlim = T; fz.ext_y = 1 << 30; fz.ext_x = 1 << 30;
+  fz.pad_value = dg->pad_value; fz.ylim = Tg; fz.xlim = Tg; fz.ext_y = 1 << 30; fz.ext_x = 1 << 30;
   fz.pack = pack; fz.cpt = cpt; fz.tgx = tgx;
   if (pack > 1) { fz.cstride = cpt; fz.cvalid = cpt; }
   FwdParams fxm = fz;                                    // x tiles: own Vy x Vx values (boundary-condition padded where the grid is the padded domain)
@@ -909,34 +1008,27 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   fxm.oy = padded_domain ? d->pad_top : 0; fxm.ox = padded_domain ? d->pad_left : 0; fxm.pad_mode = d->pad_mode; fxm.pad_value = 0.f;
   fxm.ylim = Vy; fxm.xlim = Vx; fxm.ext_y = dg->Ho; fxm.ext_x = dg->Wo;
   InvParams iv;
-  iv.sp = ys; iv.tab = ws.tab; iv.y = dx; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = residual; iv.act_out = nullptr; iv.absmax = nullptr;
+  iv.sp = ys; iv.tab = gm.tab; iv.y = dx; iv.bias = nullptr; iv.bn_scale = nullptr; iv.bn_shift = nullptr; iv.res = residual; iv.act_out = nullptr; iv.absmax = nullptr;
   iv.Ho = dg->Ho; iv.Wo = dg->Wo; iv.C = dg->Cout; iv.ldy = dg->ldy; iv.ld_res = dg->ld_res; iv.ld_act = 0; iv.groups = gx; iv.cstride = 32; iv.cvalid = 32;
   iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx; iv.flip = 0;
   iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
   if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
   MixParams mx;
-  mx.xs = zs; mx.ys = ys; mx.M = Mm; mx.slots = ws.slots; mx.gin = gz; mx.gout = gx;
+  mx.xs = zs; mx.ys = ys; mx.M = Mm; mx.gin = gz; mx.gout = gx;
   WMixParams wm;
-  wm.xs = xs; wm.ds = zs; wm.part = part; wm.slots = ws.slots; wm.gin = gx; wm.S = S / 4;
+  wm.xs = xs; wm.ds = zs; wm.part = part; wm.slots = gm.slots; wm.gin = gx; wm.S = S / 4; wm.rows = rows; wm.nslot = nslot;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
-    fz.tile0 = (int)t0; fxm.tile0 = (int)t0; iv.tile0 = (int)t0; mx.ntile = nt; wm.ntile = nt; wm.accumulate = t0 > 0;
-    launch_fwd(h, fz, nt);
-    const int nMt = pcnn_cdiv(nt, 32);
-    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
-    hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(NSLOT, gy, gx), dim3(256), 0, h->stream, mx);
-    launch_inv(h, iv, nt);
-    launch_fwd(h, fxm, nt);
-    hipLaunchKernelGGL(spec_wmix_kernel, dim3(NSLOT, S / 4, gx), dim3(256), 0, h->stream, wm);
+    fz.tile0 = (int)t0; fxm.tile0 = (int)t0; iv.tile0 = (int)t0; wm.ntile = nt; wm.accumulate = t0 > 0;
+    launch_fwd(h, gm, fz, nt);
+    launch_mix(h, gm, mx, gz, gx, nt);
+    launch_inv(h, gm, iv, nt);
+    launch_fwd(h, gm, fxm, nt);
+    hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gx), dim3(256), 0, h->stream, wm);
   }
   float* csp = wsp;                                      // the filter spectrum is no longer needed
-  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, ws.slots, csp, S, gx, d->Cin, -1.0f, cpt);
-  InvParams iw;
-  iw.sp = csp; iw.tab = ws.tab; iw.y = dw; iw.bias = nullptr; iw.bn_scale = nullptr; iw.bn_shift = nullptr; iw.res = nullptr; iw.act_out = nullptr;
-  iw.absmax = nullptr; iw.Ho = d->kh; iw.Wo = d->kw; iw.C = d->Cin * d->Cout; iw.ldy = d->Cin * d->Cout; iw.ld_res = 0; iw.ld_act = 0;
-  iw.groups = d->Cin; iw.cstride = d->Cout; iw.cvalid = d->Cout; iw.act = PCNN_ACT_LINEAR; iw.alpha = 0.f;
-  iw.tiles_x = 1; iw.tiles_y = 1; iw.tile0 = 0; iw.Vy = T; iw.Vx = T; iw.flip = 1; iw.pack = 1; iw.cpt = 32; iw.tgx = 1;
-  launch_inv(h, iw, 1);
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);
+  launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 1), 1);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral");
   return 0;
 }

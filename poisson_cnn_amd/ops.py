@@ -47,6 +47,22 @@ def get_spectral_mode():
     return _spectral_mode
 
 
+_spectral_tile = int(__import__('os').environ.get('PCNN_SPEC_T', '0'))
+
+
+def set_spectral_tile(tile):
+    """0 (default: per layer - 64 x 64 tiles for 11..15 taps on large images), 32 or 64: include/pcnn.h pcnn_set_spectral_tile.
+    Environment: PCNN_SPEC_T."""
+    global _spectral_tile
+    _spectral_tile = int(tile)
+    for h in _handles.values():
+        h.call('pcnn_set_spectral_tile', c_int(_spectral_tile))
+
+
+def get_spectral_tile():
+    return _spectral_tile
+
+
 def get_math_mode():
     return [k for k, v in MATH_MODES.items() if v == _math_mode][0]
 
@@ -61,6 +77,7 @@ def handle():
         h = _lib.Handle(dev, st)
         h.call('pcnn_set_math_mode', c_int(_math_mode))
         h.call('pcnn_set_spectral_mode', c_int(_spectral_mode))
+        h.call('pcnn_set_spectral_tile', c_int(_spectral_tile))
         _handles[(dev, st)] = h
     return h
 

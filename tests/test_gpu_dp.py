@@ -171,27 +171,32 @@ def test_c_abi_collective_single_rank():
 
 def _train_main_worker(rank, world, port, cfg_path, ckpt_dir, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', PCNN_DIST_BACKEND='gloo')
-    from poisson_cnn_amd import train as T
-    shapes, captured = [], {}
+    try:
+        from poisson_cnn_amd import dataset as D, models as M, train as T
+        shapes, captured = [], {}
+        orig_get = D.reverse_poisson_dataset_generator.__getitem__     # train.main imports the class from the package at call time
 
-    class Recording(T.reverse_poisson_dataset_generator):
-        def __getitem__(self, idx=0):
-            inp, soln = super().__getitem__(idx)
+        def getitem(self, idx=0):
+            inp, soln = orig_get(self, idx)
             shapes.append((tuple(soln.shape), float(inp[0].double().abs().sum())))
             return inp, soln
-    T.reverse_poisson_dataset_generator = Recording
-    orig_fit = T.Homogeneous_Poisson_NN_Legacy.fit
+        D.reverse_poisson_dataset_generator.__getitem__ = getitem
+        orig_fit = M.Homogeneous_Poisson_NN_Legacy.fit
 
-    def fit(self, *a, **kw):
-        captured['model'] = self
-        return orig_fit(self, *a, **kw)
-    T.Homogeneous_Poisson_NN_Legacy.fit = fit
-    T.main([cfg_path, '--epochs', '1', '--checkpoint_dir', os.path.join(ckpt_dir, 'r%d' % rank)])
-    torch.cuda.synchronize()
-    m = captured['model']
-    q.put((rank, shapes, m.store.flat_w.cpu().numpy().copy()))
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+        def fit(self, *a, **kw):
+            captured['model'] = self
+            return orig_fit(self, *a, **kw)
+        M.Homogeneous_Poisson_NN_Legacy.fit = fit
+        os.makedirs(os.path.join(ckpt_dir, 'r%d' % rank), exist_ok=True)
+        T.main([cfg_path, '--epochs', '1', '--checkpoint_dir', os.path.join(ckpt_dir, 'r%d' % rank)])
+        torch.cuda.synchronize()
+        m = captured['model']
+        q.put((rank, shapes, m.store.flat_w.cpu().numpy().copy()))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    except BaseException as e:       # a crashed rank must fail the test at once, not leave the parent waiting on the queue
+        q.put((rank, 'error: %r' % (e,), None))
+        raise
 
 
 def test_train_main_two_ranks_share_the_grid_shape_and_the_weights(tmp_path):
@@ -212,7 +217,8 @@ def test_train_main_two_ranks_share_the_grid_shape_and_the_weights(tmp_path):
     procs = [ctx.Process(target=_train_main_worker, args=(r, 2, port, path, str(tmp_path), q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    assert not any(isinstance(r[1], str) for r in res), res
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
