@@ -54,6 +54,7 @@ def parse_args(argv=None):
                          "(runs on CPU/gloo; exercises the N > 1 launch path without a GPU)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dataset', action='store_true')
+    ap.add_argument('--no-c3', action='store_true', help='skip the 32 x 512^2 block that the default c4 run appends')
     ap.add_argument('--modes', default='split_f16,fp32', help='math modes to time, in order; the LAST one is the headline (default: split_f16,fp32)')
     ap.add_argument('--math', default=None, choices=['split_f16', 'fp32'], help='time only this mode (profiling runs)')
     ap.add_argument('--cpu-baseline-hw', type=int, default=512)
@@ -141,13 +142,13 @@ def dataset_block():
         gen[0]
     torch.cuda.synchronize()
     rounds = []
-    for _ in range(3):           # three rounds of ten batches, the fastest round counts: the generator's host side (numpy control points, launch
-        t0 = time.perf_counter()  # glue) shares the box's cores with whatever else runs there, and single rounds were seen 4x apart between boxes
+    for _ in range(4):           # four rounds of ten batches: the first is a warm-up (allocator, table uploads), the MEDIAN of the other three counts -
+        t0 = time.perf_counter()  # the generator's host side (numpy control points, launch glue) shares the box's cores with whatever else runs there
         for _ in range(10):
             inp, soln = gen[0]
         torch.cuda.synchronize()
         rounds.append((time.perf_counter() - t0) / 10)
-    t = min(rounds)
+    t = sorted(rounds[1:])[1]
     rhs, left, top, right, bottom, dx = [x.cpu().numpy().astype(np.float64) for x in inp]
     t0 = time.perf_counter()
     ref = ods.multigrid_poisson_solve(rhs[:2, 0], {'left': left[:2, 0], 'right': right[:2, 0], 'top': top[:2, 0], 'bottom': bottom[:2, 0]}, dx[:2, 0])
@@ -155,7 +156,7 @@ def dataset_block():
     err = float(np.linalg.norm(soln[:2, 0].cpu().numpy() - ref) / np.linalg.norm(ref))
     n = H - 2
     return {'metric': 'reference-solution samples/s at 512^2 (control points -> legacy bicubic -> fp64 DST-I solve, on device)', 'value': N / t,
-            'seconds_per_batch_rounds': rounds, 'fp64_mfma_tflops': 8.0 * n ** 3 * N / t / 1e12, 'fp64_mfma_peak_tflops': PEAK_FP64_MFMA_TFLOPS,
+            'seconds_per_batch_rounds': rounds, 'value_is': 'median of rounds 2-4 (round 1 is a warm-up)', 'fp64_mfma_tflops': 8.0 * n ** 3 * N / t / 1e12, 'fp64_mfma_peak_tflops': PEAK_FP64_MFMA_TFLOPS,
             'fp64_mfma_frac': 8.0 * n ** 3 * N / t / 1e12 / PEAK_FP64_MFMA_TFLOPS, 'algorithm': 'GEMM DST-I on v_mfma_f64_16x16x4_f64, 8 n^3 FLOP per sample',
             'cpu_baseline': {'value': 1.0 / tc, 'unit': 'samples/s', 'kind': 'port',
                              'sample': '2 samples, scipy.sparse.linalg.splu of the same 5-point system (stand-in for pyamg), 1 thread'},
@@ -186,40 +187,22 @@ def launch_check(args, dp):
                           'config': {'workload': 'launch-check', 'collective': dp.collective_name(), 'parallelism': 'dp%d' % dp.world_size}}), flush=True)
 
 
-def traffic_from_profiles(math, workload, kernel_prefix):
-    """(bytes per launch, provenance) from the committed PMC summary of this mode - only if it was measured on these kernel sources."""
+PROFILE_ROUND = 'r03'
+
+
+def pmc_summary(math, workload):
+    """(summary dict, provenance string) of the committed PMC summary of this (workload, mode) - only if it was measured on these kernel sources."""
     from poisson_cnn_amd import _lib
-    name = 'r02_c4_pmc_summary_%s.json' % math
+    name = '%s_%s_pmc_summary_%s.json' % (PROFILE_ROUND, workload, math)
     path = os.path.join(ROOT, 'profiles', name)
-    if workload != 'c4':
-        return None, 'PMC passes are collected for workload c4 only'
     if not os.path.exists(path):
-        return None, 'profiles/%s not found' % name
+        return None, 'profiles/%s not found (tools/collect_pmc.sh writes it)' % name
     with open(path) as f:
         summ = json.load(f)
     if summ.get('source_hash') != _lib.source_hash():
         return None, 'profiles/%s was measured on other kernel sources (stamp %s, this tree %s): re-run tools/collect_pmc.sh' % (name, summ.get('source_hash'), _lib.source_hash())
-    ks = [v for k, v in summ['kernels'].items() if k.startswith(kernel_prefix + ' (')] or [v for k, v in summ['kernels'].items() if k.startswith(kernel_prefix)]
-    if not ks:
-        return None, 'no %s* rows in profiles/%s' % (kernel_prefix, name)
-    return (sum(v['traffic_bytes_per_launch'] * v['launches'] for v in ks) / max(sum(v['launches'] for v in ks), 1),
-            'profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes; source stamp %s matches)' % (name, summ['source_hash']))
-
-
-def mfma_busy_from_profiles(math, workload):
-    """Matrix-pipe busy fraction over all convolution kernels of a step (third PMC pass of tools/collect_pmc.sh), same provenance rule."""
-    from poisson_cnn_amd import _lib
-    path = os.path.join(ROOT, 'profiles', 'r02_c4_pmc_summary_%s.json' % math)
-    if workload != 'c4' or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        summ = json.load(f)
-    if summ.get('source_hash') != _lib.source_hash():
-        return None
-    for k, v in summ['kernels'].items():
-        if k.startswith('conv ('):
-            return v.get('mfma_busy_frac')
-    return None
+    return summ, ('profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes; SQ_VALU_MFMA_BUSY_CYCLES / (128 GRBM_GUI_ACTIVE); '
+                  'source stamp %s matches this tree)' % (name, summ['source_hash']))
 
 
 def run(args):
@@ -236,20 +219,9 @@ def run(args):
     from poisson_cnn_amd.losses import loss_wrapper
     from poisson_cnn_amd.train import Adam
 
-    per_gpu, H = WORKLOADS[args.workload]
-    W = H
     full = configs.hpnn()
     model = Homogeneous_Poisson_NN_Legacy(**full['model'])
-    gbs = per_gpu * dp.world_size
-    model.compile(loss=loss_wrapper(global_batch_size=gbs, **full['training']['loss_parameters']),
-                  optimizer=Adam(**full['training']['optimizer_parameters']))
     dp.attach(model)
-    g = torch.Generator(device='cpu').manual_seed(4 + dp.rank)
-    rhs = (torch.rand((per_gpu, 1, H, W), generator=g) * 2 - 1).cuda()
-    rhs = rhs / rhs.abs().amax(dim=(1, 2, 3), keepdim=True)
-    dx = (torch.rand((per_gpu, 1), generator=g) * 4.5e-2 + 5e-3).cuda()
-    target = (torch.randn((per_gpu, 1, H, W), generator=g) * 0.1).cuda()
-    batch = ((rhs, dx), target)
 
     def note(msg):
         if dp.rank == 0:
@@ -257,10 +229,20 @@ def run(args):
 
     modes = [args.math] if args.math else [m for m in args.modes.split(',') if m]
     note('model built, %d params; modes %s' % (model.count_params(), modes))
+    DTYPE = {'fp32': 'f32', 'split_f16': 'f32 tensors and accumulate; products as 3 x fp16 MFMA on 2 x fp16 splits of the fp32 operands (opt-in mode)'}
 
-    # ---- accuracy gate on the benchmark batch itself: same weights, same inputs, the two math modes side by side (no optimizer step)
-    accuracy = None
-    if 'split_f16' in modes and 'fp32' in modes:
+    def make_batch(workload):
+        per_gpu, H = WORKLOADS[workload]
+        g = torch.Generator(device='cpu').manual_seed(4 + dp.rank)
+        rhs = (torch.rand((per_gpu, 1, H, H), generator=g) * 2 - 1).cuda()
+        rhs = rhs / rhs.abs().amax(dim=(1, 2, 3), keepdim=True)
+        dx = (torch.rand((per_gpu, 1), generator=g) * 4.5e-2 + 5e-3).cuda()
+        target = (torch.randn((per_gpu, 1, H, H), generator=g) * 0.1).cuda()
+        return per_gpu, H, ((rhs, dx), target)
+
+    def accuracy_gate(per_gpu, batch):
+        """same weights, same inputs, the two math modes side by side (no optimizer step)"""
+        (rhs, dx), target = batch
         res = {}
         for mode in ('fp32', 'split_f16'):
             ops.set_math_mode(mode)
@@ -273,81 +255,122 @@ def run(args):
             sig = b.abs() >= 1e-3 * b.abs().max()
             return {'rel_l2': float((a - b).norm() / b.norm()), 'max_abs_err_over_max_abs': float(d.max() / b.abs().max()),
                     'max_rel_err_where_ref_above_1e-3_of_max': float((d[sig] / b.abs()[sig]).max())}
-        accuracy = {'what': 'split_f16 mode vs fp32 mode on this benchmark batch (rank 0 shard), identical weights and inputs',
-                    'forward_output': cmp(res['split_f16'][0], res['fp32'][0]), 'flat_gradient': cmp(res['split_f16'][1], res['fp32'][1])}
-        note('accuracy gate: forward rel-L2 %.3g, gradient rel-L2 %.3g' % (accuracy['forward_output']['rel_l2'], accuracy['flat_gradient']['rel_l2']))
-        del res
+        acc = {'what': 'split_f16 mode vs fp32 mode on this benchmark batch (rank 0 shard), identical weights and inputs',
+               'forward_output': cmp(res['split_f16'][0], res['fp32'][0]), 'flat_gradient': cmp(res['split_f16'][1], res['fp32'][1])}
+        note('accuracy gate: forward rel-L2 %.3g, gradient rel-L2 %.3g' % (acc['forward_output']['rel_l2'], acc['flat_gradient']['rel_l2']))
+        return acc
 
-    def timed(mode):
+    def timed(mode, batch, steps, warmup):
         ops.set_math_mode(mode)
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             model.train_step(batch)
         torch.cuda.synchronize()
-        note('%s: warm-up done; timing %d steps' % (mode, args.steps))
+        note('%s: warm-up done; timing %d steps' % (mode, steps))
         prof = ops.KernelTimer()
         dp.barrier()
         torch.cuda.synchronize()
         ops.set_kernel_timer(prof)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             logs = model.train_step(batch)
         torch.cuda.synchronize()
+        local = time.perf_counter() - t0
         dp.barrier()
         elapsed = time.perf_counter() - t0
         ops.set_kernel_timer(None)
         elapsed = dp.max_over_ranks(elapsed)
+        # per-rank view of the same region (before the closing barrier): load imbalance between ranks shows as max > min
+        rank_ms = {'max': 1e3 * dp.max_over_ranks(local) / steps, 'min': -1e3 * dp.max_over_ranks(-local) / steps}
         note('%s: timed region %.3f s' % (mode, elapsed))
-        return elapsed, prof, float(logs['loss'])
+        return elapsed, prof, float(logs['loss']), rank_ms
 
-    def roofline(mode, prof):
-        peak = PEAK_FP32_MFMA_TFLOPS if mode == 'fp32' else PEAK_SPLIT_TFLOPS
+    def collective_ms(reps=10):
+        """the gradient exchange alone: `reps` all-reduces of the flat gradient bucket, HIP-event time on this stream"""
+        if dp.world_size == 1:
+            return None
+        flat = model.store.flat_g
+        dp.all_reduce_sum(flat); torch.cuda.synchronize(); dp.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dp.all_reduce_sum(flat)
+        torch.cuda.synchronize()
+        return 1e3 * dp.max_over_ranks(time.perf_counter() - t0) / reps
+
+    def roofline(mode, prof, workload, steps):
+        """The convolution kernels of one train step against the HBM roofline (they are bound by the tile spectra they stream, not by the
+        matrix pipes): counter traffic over their HIP-event time, per kernel where the committed rocprofv3 summary carries the table."""
         flops, secs, calls = prof.totals('conv_fwd')
         wf, ws_, wc = prof.totals('conv_wgrad')
         bf, bs, bc = prof.totals('conv_bwd_fused')
         af, as_, ac = flops + wf + bf, secs + ws_ + bs, calls + wc + bc
-        traffic, tsrc = traffic_from_profiles(mode, args.workload, 'conv')
-        busy = mfma_busy_from_profiles(mode, args.workload)
-        conv_s_per_step = as_ / max(args.steps, 1)
-        executed = {'what': 'the work the convolution kernels actually execute (the spectral route does not execute the direct-convolution FLOP of '
-                            '`achieved`): their HBM traffic from the PMC passes over their summed HIP-event time of this run, and the fraction of '
-                            'cycles their matrix pipes are busy (SQ_VALU_MFMA_BUSY_CYCLES / (128 GRBM_GUI_ACTIVE), PMC)',
-                    'hbm_achieved': traffic / conv_s_per_step / 1e9 if (traffic and conv_s_per_step) else None, 'hbm_peak': PEAK_HBM_GBS, 'hbm_unit': 'GB/s',
-                    'hbm_frac': traffic / conv_s_per_step / 1e9 / PEAK_HBM_GBS if (traffic and conv_s_per_step) else None, 'mfma_busy_frac': busy}
+        conv_s = as_ / max(steps, 1)
+        alg_bytes = (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad')) / max(steps, 1)
+        summ, src = pmc_summary(mode, workload)
+        traffic = busy = table = None
+        if summ is not None:
+            for k, v in summ['kernels'].items():
+                if k.startswith('conv ('):
+                    traffic, busy = v['traffic_bytes_per_launch'], v.get('mfma_busy_frac')
+            table = [{'kernel': k, 'launches_per_step': v.get('launches_per_step', v['launches']), 'ms_per_step': v.get('ms_per_step'),
+                      'avg_launch_ms': v.get('avg_launch_ms'), 'traffic_MB_per_launch': v['traffic_bytes_per_launch'] / 1e6, 'hbm_TBs': v.get('hbm_tbs'),
+                      'hbm_frac': v.get('hbm_frac'), 'mfma_busy_frac': v.get('mfma_busy_frac')}
+                     for k, v in sorted(summ['kernels'].items(), key=lambda kv: -(kv[1].get('ms_per_step') or 0.0)) if not k.startswith('conv (')]
+        achieved = (traffic if traffic else alg_bytes) / conv_s / 1e9 if conv_s else None
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
         hf, hb, hs, hc = prof.select(lambda k, f, b: k == 'conv_fwd' and b > 0 and f / b < ridge)
         df, db, ds, dc = prof.select(lambda k, f, b: k == 'deconv_fwd')
         rf, rb, rs, rc = prof.select(lambda k, f, b: k == 'resize_fwd')
-
-        def blk(f, s_, c):
-            return {'achieved': f / s_ / 1e12 if s_ else None, 'frac': f / s_ / 1e12 / peak if s_ else None, 'launches': c, 'avg_launch_ms': 1e3 * s_ / c if c else None}
-        return {'bound': 'mfma',
-                'kernel': 'all convolution launches of the timed steps (forward, data gradient, weight gradient): fp32-MFMA implicit GEMM (%s), tiled spectral '
-                          'route (spec_fwd / spec_mix / spec_inv / spec_wmix: DFT as fp32 MFMA GEMM) for the wide filters (tile-packed below 17 channels), vector-ALU forward and 16x16x4-MFMA weight-gradient kernels for the 3x3 layers of <= 16 channels'
-                          % ('conv_fwd_kernel / wgrad_kernel' if mode == 'fp32' else 'conv_fwd_split_kernel / wgrad_split_kernel'),
-                'achieved': af / as_ / 1e12 if as_ else None, 'peak': peak, 'unit': 'TFLOP/s (ALGORITHMIC direct-convolution fp32 FLOP, 2 N Ho Wo kh kw Cin Cout per launch)',
-                'frac': af / as_ / 1e12 / peak if as_ else None,
-                'note': 'frac > 1 is possible: the spectral route needs ~k^2/25 times fewer multiply-adds than the direct convolution the numerator counts',
-                'executed': executed,
-                'traffic': traffic, 'traffic_unit': 'bytes per training step over all convolution kernels (2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': tsrc, 'launches': ac, 'avg_launch_ms': 1e3 * as_ / ac if ac else None,
-                'algorithmic_bytes_per_step': (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad')) / max(args.steps, 1),
-                'forward_and_data_gradient': blk(flops, secs, calls), 'wgrad_kernel': blk(wf, ws_, wc), 'backward_fused': blk(bf, bs, bc),
+        direct_tflops = af / as_ / 1e12 if as_ else None
+        return {'bound': 'hbm',
+                'kernel': 'all convolution launches of the timed steps (forward, data gradient, weight gradient): tiled spectral route (spec_fwd / spec64_fwd, '
+                          'spec_mix, spec_inv / spec64_inv, spec_wmix: the DFT as fp32 MFMA GEMM, 64-point tiles for 11..15 taps) for the wide filters, '
+                          'fp32-MFMA implicit GEMM, vector-ALU forward and 16x16x4-MFMA weight-gradient kernels for the 3x3 layers of <= 16 channels',
+                'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS if achieved else None,
+                'achieved_source': ('EXECUTED traffic (PMC bytes of all convolution kernels of a step) / their summed HIP-event time in this run' if traffic
+                                    else 'ALGORITHMIC bytes (layer inputs + outputs + filters) / their summed HIP-event time: no stamped PMC summary for this tree'),
+                'traffic': traffic, 'traffic_unit': 'bytes per training step over all convolution kernels (2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': src,
+                'mfma_busy': busy, 'conv_kernel_ms_per_step': 1e3 * conv_s, 'launches': ac, 'avg_launch_ms': 1e3 * as_ / ac if ac else None,
+                'algorithmic_bytes_per_step': alg_bytes, 'algorithmic_GBs': alg_bytes / conv_s / 1e9 if conv_s else None,
+                'traffic_over_algorithmic': traffic / alg_bytes if (traffic and alg_bytes) else None,
+                'direct_conv_equivalent': {'what': 'the direct convolution\'s 2 N Ho Wo kh kw Cin Cout FLOP over the same time - a speed-up measure, NOT a roofline '
+                                                   'fraction: the spectral route does not execute these FLOP',
+                                           'tflops': direct_tflops, 'speedup_vs_direct_fp32_peak': direct_tflops / PEAK_FP32_MFMA_TFLOPS if direct_tflops else None},
+                'kernels': table,
                 'hbm_bound': {'what': 'conv forward / data-gradient launches below the fp32 ridge (%.1f FLOP/B: the 3x3 tail with <= 8 channels and the Scaling convs)' % ridge,
                               'bound': 'hbm', 'achieved': hb / hs / 1e9 if hs else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s (algorithmic bytes)',
                               'frac': hb / hs / 1e9 / PEAK_HBM_GBS if hs else None, 'launches': hc, 'avg_launch_ms': 1e3 * hs / hc if hc else None,
                               'deconv_fwd': {'achieved': db / ds / 1e9 if ds else None, 'frac': db / ds / 1e9 / PEAK_HBM_GBS if ds else None, 'launches': dc},
                               'resize_fwd': {'achieved': rb / rs / 1e9 if rs else None, 'frac': rb / rs / 1e9 / PEAK_HBM_GBS if rs else None, 'launches': rc}}}
 
-    DTYPE = {'fp32': 'f32', 'split_f16': 'f32 tensors and accumulate; products as 3 x fp16 MFMA on 2 x fp16 splits of the fp32 operands (opt-in mode)'}
-    blocks = {}
-    for mode in modes:
-        elapsed, prof, loss = timed(mode)
-        blocks[mode] = {'value': gbs * args.steps / elapsed, 'unit': 'grids/s', 'ms_per_step': 1e3 * elapsed / args.steps, 'dtype': DTYPE[mode],
-                        'final_loss': loss, 'roofline': roofline(mode, prof) if dp.rank == 0 else None}
-        del prof
+    def bench_workload(workload, wl_modes, steps, warmup, gate):
+        per_gpu, H, batch = make_batch(workload)
+        gbs = per_gpu * dp.world_size
+        model.compile(loss=loss_wrapper(global_batch_size=gbs, **full['training']['loss_parameters']), optimizer=Adam(**full['training']['optimizer_parameters']))
+        accuracy = accuracy_gate(per_gpu, batch) if (gate and 'split_f16' in wl_modes and 'fp32' in wl_modes) else None
+        blocks = {}
+        for mode in wl_modes:
+            elapsed, prof, loss, rank_ms = timed(mode, batch, steps, warmup)
+            blocks[mode] = {'value': gbs * steps / elapsed, 'unit': 'grids/s', 'ms_per_step': 1e3 * elapsed / steps, 'dtype': DTYPE[mode], 'final_loss': loss,
+                            'rank_ms_per_step': rank_ms, 'roofline': roofline(mode, prof, workload, steps) if dp.rank == 0 else None}
+            del prof
+        if accuracy is not None:
+            blocks['split_f16']['accuracy_vs_fp32'] = accuracy
+        return per_gpu, H, gbs, blocks
+
+    per_gpu, H, gbs, blocks = bench_workload(args.workload, modes, args.steps, args.warmup, True)
+    coll_ms = collective_ms()
+    # the other half of BASELINE.json's metric ("at 512^2 & 1024^2"): the default c4 run appends the 32 x 512^2 workload, fp32 mode, same timing rules
+    c3 = None
+    if args.workload == 'c4' and not args.no_c3 and modes[-1] == 'fp32':
+        note('c3 block (32 x 512^2, fp32) ...')
+        p3, H3, g3, b3 = bench_workload('c3', ['fp32'], args.steps, args.warmup, False)
+        c3 = dict(b3['fp32'], metric='grids/sec (fwd+bwd) at %d^2' % H3, steps=args.steps, warmup=args.warmup,
+                  config={'workload': 'c3: the same full train step on %d x %dx%d grids per GPU (BASELINE.json configs[2] size)' % (p3, H3, H3), 'global_batch': g3})
     if dp.rank != 0:
         return
     head = modes[-1]
     hb = blocks[head]
+    W = H
     out = {
         'metric': 'grids/sec (fwd+bwd) at %d^2' % H, 'value': hb['value'], 'unit': 'grids/s',
         'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': hb['ms_per_step'],
@@ -356,12 +379,13 @@ def run(args):
                                % (args.workload, ('+' + dp.collective_name()) if dp.world_size > 1 else '', per_gpu, H, W),
                    'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': head, 'library_default_math': 'fp32',
                    'overlap_wgrad': bool(args.overlap_wgrad), 'final_loss': hb['final_loss'], 'collective': dp.collective_name() if dp.world_size > 1 else None},
+        'rank_ms_per_step': hb['rank_ms_per_step'], 'collective_ms': coll_ms,
         'roofline': hb['roofline'],
     }
     for mode in modes[:-1]:
         out[mode] = blocks[mode]
-        if mode == 'split_f16' and accuracy is not None:
-            out[mode]['accuracy_vs_fp32'] = accuracy
+    if c3 is not None:
+        out['c3'] = c3
     if dp.world_size == 1 and not args.no_cpu_baseline:
         note('cpu baseline (bounded sample: one %d^2 grid) ...' % args.cpu_baseline_hw)
         out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_hw)

@@ -19,6 +19,7 @@
 #include "spectral_common.h"
 #include <math.h>
 #include <algorithm>
+#include <stdlib.h>
 
 namespace pcnn_spec {
 
@@ -65,13 +66,21 @@ __device__ __forceinline__ void make_ctx(const FwdParams& p, int tg, int half, i
   cx.off0 = (unsigned)((cx.fast ? (cx.wx0 + half) * p.ld : 0) + (cx.cok ? chan : 0));
 }
 
+// tf.pad index map without control flow (selects only): the 32 loads of a boundary row are issued back to back
+__device__ __forceinline__ int pad_sel(int i, int n, int mode) {
+  const int refl = mode == PCNN_PAD_SYMMETRIC ? (i < 0 ? -i - 1 : 2 * n - 1 - i) : (i < 0 ? -i : 2 * n - 2 - i);
+  const int rc = min(max(refl, 0), n - 1);
+  return (unsigned)i < (unsigned)n ? i : (mode == PCNN_PAD_CONSTANT ? 0 : rc);       // constant padding: any valid pixel (replaced when consumed)
+}
+
 // issues the 32 loads of window row y: lo[ks] = column 2 ks + half, hi[ks] = column 32 + 2 ks + half (always-valid addresses; padding and
 // masks are applied when the values are consumed).  y is wave-uniform.
 template <bool MASKED>
 __device__ __forceinline__ void load_row64(const FwdParams& p, const Ctx64& cx, int y, int half, float (&lo)[16], float (&hi)[16]) {
   if (MASKED && y >= cx.ylim) return;
-  const int sy = pcnn_pad_index(cx.wy0 + y, p.H, p.pad_mode);
-  const float* row = cx.img + (int64_t)(sy < 0 ? 0 : sy) * p.W * p.ld;
+  if (p.cpt & 2) return;                                    // removal study (PCNN_DBG64): no window loads
+  const int sy = pad_sel(cx.wy0 + y, p.H, p.pad_mode);
+  const float* row = cx.img + (int64_t)sy * p.W * p.ld;
   if (cx.fast) {
     const float* rl = row, *rh = row + 32 * p.ld;                   // uniform pointers step by two pixels; ONE lane offset for all 32 loads
 #pragma unroll
@@ -81,13 +90,38 @@ __device__ __forceinline__ void load_row64(const FwdParams& p, const Ctx64& cx, 
       rl += 2 * p.ld; rh += 2 * p.ld;
     }
   } else {
+    const int xa = cx.wx0 + half;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const int sa = pcnn_pad_index(cx.wx0 + 2 * ks + half, p.W, p.pad_mode), sb = pcnn_pad_index(cx.wx0 + 32 + 2 * ks + half, p.W, p.pad_mode);
-      lo[ks] = row[cx.off0 + (unsigned)((sa < 0 ? 0 : sa) * p.ld)];
-      hi[ks] = row[cx.off0 + (unsigned)((sb < 0 ? 0 : sb) * p.ld)];
+      lo[ks] = row[cx.off0 + (unsigned)(pad_sel(xa + 2 * ks, p.W, p.pad_mode) * p.ld)];
+      hi[ks] = row[cx.off0 + (unsigned)(pad_sel(xa + 32 + 2 * ks, p.W, p.pad_mode) * p.ld)];
     }
   }
+}
+
+// x axis of one window row: D[rho][c] = sum_x GX[rho][x] (w[x] +- w[x + 32]); A = GX (lane = rho), B = the pixel's channel row
+template <bool MASKED>
+__device__ __forceinline__ f32x16 x_row64(const FwdParams& p, const Ctx64& cx, int y, int half, float sgx, const float (&gx)[16], const float (&lo)[16],
+                                          const float (&hi)[16]) {
+  f32x16 acc = zero16();
+  if (MASKED && y >= cx.ylim) return acc;
+  const int gy = cx.wy0 + y;
+  const bool rowpad = p.pad_mode == PCNN_PAD_CONSTANT && (unsigned)gy >= (unsigned)p.H;      // uniform: the whole row is constant padding
+  const bool edge = rowpad || (!cx.fast && p.pad_mode == PCNN_PAD_CONSTANT);                   // uniform: some pixels of this row are
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    float a = lo[ks], b = hi[ks];
+    const int xa = 2 * ks + half, xb = xa + 32;
+    if (edge) {
+      if (rowpad || (unsigned)(cx.wx0 + xa) >= (unsigned)p.W) a = p.pad_value;
+      if (rowpad || (unsigned)(cx.wx0 + xb) >= (unsigned)p.W) b = p.pad_value;
+    }
+    if (MASKED) { if (xa >= cx.xlim) a = 0.f; if (xb >= cx.xlim) b = 0.f; }
+    float u = a + sgx * b;
+    if (!cx.cok) u = 0.f;
+    acc = mfma(gx[ks], u, acc);
+  }
+  return acc;
 }
 
 template <bool MASKED>
@@ -104,8 +138,9 @@ __global__ __launch_bounds__(512, 2) void spec64_fwd_kernel(FwdParams p) {
                                                            // with a grid that is a multiple of 16 a workgroup keeps ONE parity (its table stays in
                                                            // registers) and the two parities of a tile run on workgroups b and b + 8 (one XCD's L2)
   auto group_of = [&](int it) { return ((it >> 4) << 3) | (it & 7); };
+  auto next_item = [&](int it) { it += gridDim.x; while (it < nitem && group_of(it) >= ntg) it += gridDim.x; return it; };
   int item = blockIdx.x;
-  while (item < nitem && group_of(item) >= ntg) item += gridDim.x;
+  if (group_of(item) >= ntg) item = next_item(item);
   if (item >= nitem) return;
   const int px = (item >> 3) & 1;
   const bool special = px == 0 && pg == 0;                 // this wave's first pair is the two real columns (fx = 0 | 32)
@@ -118,75 +153,77 @@ __global__ __launch_bounds__(512, 2) void spec64_fwd_kernel(FwdParams p) {
   // LDS addresses of this lane: its x-axis results (row = wave) and the columns of its four pairs in stage rows `half` (+ 2 kap, + 4 for the partner)
   const int wr_off = (wave * 32 + 4 * half) * 32 + c;
   const int rd_off = (half * 32 + 4 * pg) * 32 + c;
-  Ctx64 cur;
-  make_ctx(p, group_of(item), half, c, cur);
+  // Software pipeline over the stages q = 0, 1, ... of this workgroup's items (8 per item): while the y axis consumes stage q from one LDS
+  // buffer, the x axis of stage q + 1 runs on the matrix pipe from registers and lands in the other buffer, and the window row of stage q + 2
+  // is in flight from global.  cy / cx / cl: the items those three stages belong to.  One LDS barrier per stage.
+  Ctx64 cy, cx, cl;
+  make_ctx(p, group_of(item), half, c, cy);
+  cx = cy; cl = cy;
   float lo[16], hi[16];
-  load_row64<MASKED>(p, cur, srow, half, lo, hi);
   f32x16 Z[4][2];
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) { Z[jj][0] = zero16(); Z[jj][1] = zero16(); }
-  int st = 0;
-  int next = item + gridDim.x;
-  while (next < nitem && group_of(next) >= ntg) next += gridDim.x;
-  // ONE loop over (item, stage): stage 7 of an item prefetches the first row of the next one and is followed by the item's stores
+  int item_l = item;                                        // item of the load stage
+  load_row64<MASKED>(p, cl, srow, half, lo, hi);
+  {
+    const f32x16 acc = x_row64<MASKED>(p, cx, srow, half, sgx, gx, lo, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) SB[wr_off + (8 * (r >> 2) + (r & 3)) * 32] = acc[r];
+  }
+  load_row64<MASKED>(p, cl, srow + 4, half, lo, hi);      // stage 1
+  lds_barrier();
+  int st = 0;                                               // stage of the y axis
+  bool more_x = true;                                       // a stage q + 1 exists
 #pragma unroll 1
   for (;;) {
-    float* const sb = SB + (st & 1) * SB_FLOATS;
-    // ---- x axis of this wave's row: D[rho][c] = sum_x GX[rho][x] (w[x] +- w[x + 32]); A = GX (lane = rho), B = the pixel's channel row
+    const float* const sb = SB + (st & 1) * SB_FLOATS;
+    float* const sbn = SB + ((st + 1) & 1) * SB_FLOATS;
+    const int stx = (st + 1) & 7;                           // stage of the x axis (stage q + 1), of item cx
+    // ---- x axis of stage q + 1: its sixteen MFMAs run while the LDS reads of the y axis below are in flight
+    f32x16 accx = zero16();
+    if (more_x) accx = x_row64<MASKED>(p, cx, srow + 4 * stx, half, sgx, gx, lo, hi);
+    // ---- the window row of stage q + 2 (item cl): its latency sits under this stage's y axis and the next stage's
     {
-      const int y = srow + 4 * st;
-      f32x16 acc = zero16();
-      if (!(MASKED && y >= cur.ylim)) {
-        const int sy = pcnn_pad_index(cur.wy0 + y, p.H, p.pad_mode);
-        const bool edge = sy < 0 || (!cur.fast && p.pad_mode == PCNN_PAD_CONSTANT);       // uniform: some pixels of this row are constant padding
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          float a = lo[ks], b = hi[ks];
-          const int xa = 2 * ks + half, xb = xa + 32;
-          if (edge) {
-            if (sy < 0 || (unsigned)(cur.wx0 + xa) >= (unsigned)p.W) a = p.pad_value;
-            if (sy < 0 || (unsigned)(cur.wx0 + xb) >= (unsigned)p.W) b = p.pad_value;
-          }
-          if (MASKED) { if (xa >= cur.xlim) a = 0.f; if (xb >= cur.xlim) b = 0.f; }
-          float u = a + sgx * b;
-          if (!cur.cok) u = 0.f;
-          acc = mfma(gx[ks], u, acc);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sb[wr_off + (8 * (r >> 2) + (r & 3)) * 32] = acc[r];
+      const int stl = (st + 2) & 7;
+      if (stl == 0 && more_x) { item_l = next_item(item_l); if (item_l < nitem) make_ctx(p, group_of(item_l), half, c, cl); }
+      if (item_l < nitem) load_row64<MASKED>(p, cl, srow + 4 * stl, half, lo, hi);
     }
-    lds_barrier();
-    // ---- the row of the next stage (or of the next item's first stage): its latency sits under this stage's y phase
-    if (st < 7) load_row64<MASKED>(p, cur, srow + 4 * (st + 1), half, lo, hi);
-    else if (next < nitem) {
-      Ctx64 nx;
-      make_ctx(p, group_of(next), half, c, nx);
-      load_row64<MASKED>(p, nx, srow, half, lo, hi);
-    }
-    // ---- y axis, rows 4 st .. 4 st + 3 and + 32: v = D[y] +- D[y + 32]; K step = two consecutive y (lane half).  The real pair of the
-    // special wave takes the same four MFMAs with (R, 0) in place of (C, S)
+    // ---- y axis of stage q, rows 4 st .. 4 st + 3 and + 32: v = D[y] +- D[y + 32]; K step = two consecutive y (lane half).  The real pair
+    // of the special wave takes the same four MFMAs with (R, 0) in place of (C, S)
 #pragma unroll
     for (int kap = 0; kap < 2; ++kap) {
       const float* t = ty + (2 * st + kap) * (3 * 64);
-      const float cy = t[0], sny = t[64], ry = t[128];
-      const float c0 = special ? ry : cy, s0 = special ? 0.f : sny;
+      const float cyv = t[0], sny = t[64], ry = t[128];
+      const float c0 = special ? ry : cyv, s0 = special ? 0.f : sny;
       const float* slo = sb + rd_off + (2 * kap) * 1024;
       const float* shi = slo + 4 * 1024;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const float vr = slo[jj * 32] + sgy * shi[jj * 32];
         const float vi = slo[(16 + jj) * 32] + sgy * shi[(16 + jj) * 32];
-        const float ac = jj == 0 ? c0 : cy, as = jj == 0 ? s0 : sny;
+        const float ac = jj == 0 ? c0 : cyv, as = jj == 0 ? s0 : sny;
         Z[jj][0] = mfma(ac, vr, Z[jj][0]);
         Z[jj][1] = mfma(ac, vi, Z[jj][1]);
         Z[jj][0] = mfma(as, vi, Z[jj][0]);
         Z[jj][1] = mfma(as, -vr, Z[jj][1]);
       }
     }
-    if (++st < 8) continue;
-    // ---- the item's spectrum rows, straight from the accumulators (accumulator row m <-> fy = 2 m + h)
-    float* const out = p.sp + sp_item(cur.tg, ROWS);
+    if (more_x) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sbn[wr_off + (8 * (r >> 2) + (r & 3)) * 32] = accx[r];
+    }
+    lds_barrier();
+    if (++st < 8) {
+      if (st == 7) {                                        // the x stage moves on to the next item (its first row is what lo / hi receive now)
+        cx = cl;
+        more_x = item_l < nitem && (item_l != item);
+      }
+      continue;
+    }
+    // ---- the item's spectrum rows, straight from the accumulators (accumulator row m <-> fy = 2 m + h).  (Measured and rejected: the
+    // transposed product - data as the A operand - whose accumulators hold four consecutive channels per lane: 32 16-byte stores instead of
+    // 128 dword stores, but each store instruction then writes 32-byte pieces of 32 different rows: 1.24 -> 1.39 ms per 8 x 1024^2 layer.)
+    float* const out = p.sp + sp_item(cy.tg, ROWS);
     // the 128 store offsets are invariant across items: left alone, the compiler hoists all of them out of the persistent loop (256 registers
     // of 64-bit offsets, spilled); opaque lane coordinates make it form them here, one v_add each
     int hv = half, cv = c;
@@ -197,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void spec64_fwd_kernel(FwdParams p) {
       const int base = 128 + 128 * (fx - 1) + h;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if ((p.cpt & 1) && r > 0) continue;                      // removal study (PCNN_DBG64 bit 0): one store instead of sixteen
         const int m = 8 * (r >> 2) + 4 * hv + (r & 3);
         int r0 = base + 2 * m, r1 = r0 + 64;
         if (jj == 0 && special) { r0 = ry_row(h, m); r1 = 64 + r0; }      // the two real columns: half-complex rows of fx = 0 and fx = 32
@@ -205,11 +243,9 @@ __global__ __launch_bounds__(512, 2) void spec64_fwd_kernel(FwdParams p) {
       }
       Z[jj][0] = zero16(); Z[jj][1] = zero16();
     }
-    if (next >= nitem) break;
-    item = next;
-    make_ctx(p, group_of(item), half, c, cur);
-    next = item + gridDim.x;
-    while (next < nitem && group_of(next) >= ntg) next += gridDim.x;
+    if (!more_x) break;
+    item = item_l;                                          // == the item of cx
+    cy = cx;
     st = 0;
   }
 }
@@ -231,40 +267,50 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
   const int ex = wave >> 2, s = wave & 3;
   for (int i = tid; i < 8192; i += 512) lds[i] = p.tab[TB_IY + i];
   const int ntg = p.ntile * p.groups;
-  const int nitem = 2 * ((ntg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);     // this workgroup's items: (tile group, channel half)
+  // items (tile group, channel half q): global item i -> q = (i >> 3) & 1, group = ((i >> 4) << 3) | (i & 7); with a grid that is a multiple of 16
+  // a workgroup keeps one q and the two halves of a tile's 128-byte spectrum rows are read at the same time by workgroups b and b + 8 - one
+  // XCD, one L2: each line comes from HBM once (the same workgroup taking both halves in turn fetched every line twice: 3.7 GB for 1.85 GB)
+  const int nall = 2 * ((ntg + 7) & ~7);
+  auto group_of = [&](int i) { return ((i >> 4) << 3) | (i & 7); };
+  int nitem = 0;
+  for (int i = blockIdx.x; i < nall; i += gridDim.x) nitem += group_of(i) < ntg ? 1 : 0;
   if (nitem <= 0) return;
   auto item_of = [&](int n, InvItem& it) {
-    it.tg = blockIdx.x + (n >> 1) * gridDim.x; it.q = n & 1;
+    int i = blockIdx.x, seen = -1;                            // the n-th valid item of this workgroup (items are few: a short scalar walk)
+    for (;; i += gridDim.x) { if (group_of(i) < ntg && ++seen == n) break; }
+    it.tg = group_of(i); it.q = (i >> 3) & 1;
     int t = p.tile0 + it.tg / p.groups;
     t /= p.tiles_x;
     it.vy = min(p.Vy, p.Ho - (t % p.tiles_y) * p.Vy);
   };
-  // spectrum rows of pair j = 4 tau + s of this wave's x parity, 16 channels: z[16 hh + 8 part + ks] = row (fy = 2 (4 ks + g4) + hh)
+  // spectrum rows of pair j = 4 tau + s of this wave's x parity, 16 channels: z[16 hh + 8 part + ks] = row (fy = 2 (4 ks + g4) + hh) of this
+  // lane's channel.  Loaded 16 bytes per lane - lane (g4, quad q, i) fetches channels 4 q .. 4 q + 3 of the rows of K steps 4 b + i - and brought
+  // into the per-channel operand layout by quad transposes when consumed (fix_pair): 8 loads instead of 32 (1.26 -> 1.14 ms per 8 x 1024^2 layer)
   auto load_pair = [&](const InvItem& it, int tau, float (&z)[32]) {
-    const float* in = p.sp + sp_item(it.tg, ROWS) + 16 * it.q + c;
+    int g4v = lane >> 4, cv = c;
+    asm volatile("" : "+v"(g4v), "+v"(cv));                   // opaque: the row offsets are formed per call, not hoisted out of the item loop
+    if (p.cpt & 2) return;                                     // removal study (PCNN_DBG64): no spectrum loads
+    const int iq = cv & 3;
+    const float* in = p.sp + sp_item(it.tg, ROWS) + 16 * it.q + (cv & ~3);
     const int j = 4 * tau + s;
-    int g4 = lane >> 4;
-    asm volatile("" : "+v"(g4));                               // opaque: the 32 row offsets are formed per call, not hoisted out of the item loop
-    if (ex == 0 && j == 0) {
+    const bool real = ex == 0 && j == 0;
+    const float* src = real ? in : in + (128 + 128 * (2 * j + ex - 1)) * RS;
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+    for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const int row = ry_row(hh, 4 * ks + g4);
-          z[16 * hh + ks] = in[(unsigned)(row * RS)];
-          z[16 * hh + 8 + ks] = in[(unsigned)((64 + row) * RS)];
-        }
-    } else {
-      const float* src = in + (128 + 128 * (2 * j + ex - 1)) * RS;
+      for (int b = 0; b < 2; ++b) {
+        const int kidx = 4 * (4 * b + iq) + g4v;              // K index of this lane's load: K step 4 b + iq, row g4 of the step
+        const int row = real ? ry_row(hh, kidx) : 2 * kidx + hh;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (unsigned)(row * RS));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (unsigned)((64 + row) * RS));
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+        for (int jj = 0; jj < 4; ++jj) { z[16 * hh + 4 * b + jj] = v0[jj]; z[16 * hh + 8 + 4 * b + jj] = v1[jj]; }
+      }
+  };
+  auto fix_pair = [&](float (&z)[32]) {
+    const bool odd = c & 1, upper = c & 2;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const int row = 2 * (4 * ks + g4) + hh;
-          z[16 * hh + ks] = src[(unsigned)(row * RS)];
-          z[16 * hh + 8 + ks] = src[(unsigned)((64 + row) * RS)];
-        }
-    }
+    for (int b = 0; b < 8; ++b) quad_transpose(z[4 * b], z[4 * b + 1], z[4 * b + 2], z[4 * b + 3], odd, upper);
   };
   f32x4 XE[NR][2], XO[NR][2];
 #pragma unroll
@@ -284,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
       const int tau = k & 3;
       const bool special = ex == 0 && tau == 0 && s == 0;
       f32x4 Er[2] = {zero4(), zero4()}, Ei[2] = {zero4(), zero4()}, Or[2] = {zero4(), zero4()}, Oi[2] = {zero4(), zero4()};
+      fix_pair(z);
       if (special) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -335,7 +382,10 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
         }
     }
     if (k > 0) {
-      // ---- B(k - 1): this wave's output rows y = wave + 8 i; columns 0..7 feed the even-frequency half E_x, 8..15 the odd half O_x
+      // ---- B(k - 1): this wave's output rows y = wave + 8 i; columns 0..7 feed the even-frequency half E_x, 8..15 the odd half O_x.
+      // The product is taken TRANSPOSED - the data is the A operand (rows = channels), the table the B operand (columns = pixels) - so that an
+      // accumulator's four registers are four consecutive CHANNELS of one pixel: the epilogue stores 16 bytes per lane (a quarter of the store
+      // instructions of the channel-per-lane form, which bounded this kernel: 112 dword stores per wave and item)
       const int tau = (k - 1) & 3;
       const float* db = DB + ((k - 1) & 1) * (vycap * 256) + g4 * 16 + c;
       float ax[2][2][2];
@@ -352,15 +402,15 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const float be = db[y * 256 + (4 * kk) * 16], bo = db[y * 256 + (8 + 4 * kk) * 16];
-            XE[i][0] = mfma16(ax[0][kk][0], be, XE[i][0]);
-            XE[i][1] = mfma16(ax[0][kk][1], be, XE[i][1]);
-            XO[i][0] = mfma16(ax[1][kk][0], bo, XO[i][0]);
-            XO[i][1] = mfma16(ax[1][kk][1], bo, XO[i][1]);
+            XE[i][0] = mfma16(be, ax[0][kk][0], XE[i][0]);
+            XE[i][1] = mfma16(be, ax[0][kk][1], XE[i][1]);
+            XO[i][0] = mfma16(bo, ax[1][kk][0], XO[i][0]);
+            XO[i][1] = mfma16(bo, ax[1][kk][1], XO[i][1]);
           }
         }
       }
       if (tau == 3) {
-        // ---- epilogue of item ib from the accumulators: out[x] = E + O (x < 32), E - O (x >= 32); lane = (pixel group g4, channel)
+        // ---- epilogue of item ib from the accumulators: out[x] = E + O (x < 32), E - O (x >= 32); lane = (channel quad g4, pixel lane & 15)
         const int g = ib.tg % p.groups;
         int t = p.tile0 + ib.tg / p.groups;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -368,46 +418,68 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
         const int n = t / p.tiles_y;
         const int y0 = tyy * p.Vy, x0 = tx * p.Vx;
         const int vx = min(p.Vx, p.Wo - x0);
-        const int cc = 16 * ib.q + c, chan = g * p.cstride + cc;
-        const bool cok = cc < p.cvalid && chan < p.C;
-        const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
-        const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
+        const int cc = 16 * ib.q + 4 * g4, chan = g * p.cstride + cc;       // this lane's four channels: chan .. chan + 3
+        const int nv = max(0, min(4, min(p.cvalid - cc, p.C - chan)));       // how many of them exist
+        const bool vec = nv == 4 && (p.cpt & 4) && (chan & 3) == 0;           // 16-byte accesses (host: pointers and strides are multiples of 16 B)
+        float bias[4], sc[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bias[j] = (p.bias && j < nv) ? p.bias[chan + j] : 0.f;
+          sc[j] = (p.bn_scale && j < nv) ? p.bn_scale[chan + j] : 1.f;
+          sh[j] = (p.bn_scale && j < nv) ? p.bn_shift[chan + j] : 0.f;
+        }
         const int xsgn = p.flip ? -1 : 1;
+        const int xl = c;                                        // pixel inside a 16-pixel block
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           const int y = wave + 8 * i;
-          if (y < ib.vy) {
+          if (y < ib.vy && nv > 0 && !(p.cpt & 1)) {             // (p.cpt & 1: removal study, PCNN_DBG64 - no epilogue)
             const int64_t rowpix = p.flip ? ((int64_t)n * p.Ho + (p.Ho - 1 - y0 - y)) * p.Wo + (p.Wo - 1 - x0) : ((int64_t)n * p.Ho + y0 + y) * p.Wo + x0;
             float* yrow = p.y + rowpix * p.ldy;
             float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
             const float* rrow = RES ? p.res + rowpix * p.ld_res : nullptr;
-            unsigned chv = (unsigned)chan;
-            asm volatile("" : "+v"(chv));
-            if (cok) {
+            int chv = chan;
+            asm volatile("" : "+v"(chv));                         // opaque: the pixel offsets below are formed here, not hoisted out of the item loop
+            f32x4 rv[4];
+            if (RES) {                                             // the row's residual values first, as one burst of loads (no load between stores)
 #pragma unroll
-              for (int hx = 0; hx < 2; ++hx) {                       // x < 32 | x >= 32
-                float rv[8];
-                if (RES) {
+              for (int e = 0; e < 4; ++e) {
+                const int xx = 32 * (e >> 1) + 16 * (e & 1) + xl;
+                const float* rp = rrow + (xx < vx ? (int)(xsgn * xx * p.ld_res) : 0) + chv;
+                if (vec) rv[e] = *reinterpret_cast<const f32x4*>(rp);
+                else {
 #pragma unroll
-                  for (int e = 0; e < 8; ++e) {
-                    const int xx = 32 * hx + 16 * (e >> 2) + 4 * g4 + (e & 3);
-                    rv[e] = rrow[xx < vx ? (int)(xsgn * xx * p.ld_res) + (int)chv : (int)chv];
-                  }
+                  for (int j = 0; j < 4; ++j) rv[e][j] = j < nv ? rp[j] : 0.f;
                 }
+              }
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  const int xb = e >> 2, r = e & 3;
-                  const int xx = 32 * hx + 16 * xb + 4 * g4 + r;
-                  if (xx < vx) {
-                    float v = (hx ? XE[i][xb][r] - XO[i][xb][r] : XE[i][xb][r] + XO[i][xb][r]) + bias;
-                    v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
-                    const int xo = xsgn * xx;
-                    if (arow) arow[(int)(xo * p.ld_act) + (int)chv] = v;
-                    v = v * sc + sh;
-                    if (RES) v += rv[e];
-                    yrow[(int)(xo * p.ldy) + (int)chv] = v;
-                    ymax = fmaxf(ymax, fabsf(v));
-                  }
+            for (int e = 0; e < 4; ++e) {
+              const int hx = e >> 1, xb = e & 1;
+              const int xx = 32 * hx + 16 * xb + xl;
+              if (xx < vx) {
+                f32x4 a4, o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  float v = (hx ? XE[i][xb][j] - XO[i][xb][j] : XE[i][xb][j] + XO[i][xb][j]) + bias[j];
+                  v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+                  a4[j] = v;
+                  v = v * sc[j] + sh[j];
+                  if (RES) v += rv[e][j];
+                  o4[j] = v;
+                  if (j < nv) ymax = fmaxf(ymax, fabsf(v));
+                }
+                const int xo = xsgn * xx;
+                if (vec) {
+                  if (arow) *reinterpret_cast<f32x4*>(arow + (int)(xo * p.ld_act) + chv) = a4;
+                  *reinterpret_cast<f32x4*>(yrow + (int)(xo * p.ldy) + chv) = o4;
+                } else {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    if (j < nv) {
+                      if (arow) arow[(int)(xo * p.ld_act) + chv + j] = a4[j];
+                      yrow[(int)(xo * p.ldy) + chv + j] = o4[j];
+                    }
                 }
               }
             }
@@ -494,8 +566,11 @@ void build_tables64(float* tab, int* slots) {
     for (int fy = 0; fy < T; ++fy) put(2 * T + 2 * T * (fx - 1) + fy, 2 * T + 2 * T * (fx - 1) + T + fy, 0);
 }
 
+static int dbg64() { static const int v = getenv("PCNN_DBG64") ? atoi(getenv("PCNN_DBG64")) : 0; return v; }
+
 void launch_fwd64(pcnn_handle h, FwdParams p, int ntile) {
   p.ntile = ntile;
+  p.cpt = dbg64() & 3;
   const int ntg = ntile * p.groups;
   const int nitem = 2 * ((ntg + 7) & ~7);
   const unsigned grid = (unsigned)std::min((nitem + 15) & ~15, 256);
@@ -518,8 +593,13 @@ static void launch_inv64_t(pcnn_handle h, const InvParams& p, unsigned grid, int
 
 void launch_inv64(pcnn_handle h, InvParams p, int ntile) {
   p.ntile = ntile;
+  p.cpt = (dbg64() >> 2) & 3;
+  // bit 2: every tensor the epilogue touches allows 16-byte accesses at channel offsets that are multiples of four
+  auto al = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
+  if (al(p.y, p.ldy) && al(p.act_out, p.ld_act) && al(p.res, p.ld_res) && (p.cstride & 3) == 0) p.cpt |= 4;
   const int vycap = std::min(p.Vy, p.Ho);                        // <= 56: checked by the caller (pick of the tile size)
-  const unsigned grid = (unsigned)std::min(ntile * p.groups, 256);
+  const int ntg = ntile * p.groups;
+  const unsigned grid = (unsigned)std::min((2 * ((ntg + 7) & ~7) + 15) & ~15, 256);
   const size_t lds = (8192 + 2 * (size_t)vycap * 256) * sizeof(float);
   if (p.act == PCNN_ACT_TANH) {
     if (p.res) launch_inv64_t<true, true>(h, p, grid, vycap, lds); else launch_inv64_t<true, false>(h, p, grid, vycap, lds);

@@ -29,6 +29,20 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // accumulator register r of lane (half) <-> row of the 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int half) { return 8 * (r >> 2) + 4 * half + (r & 3); }
 
+// 4 x 4 transpose between the four lanes of a quad and four registers: lane i, register j  <->  lane j, register i.  A 16-byte load gives a
+// lane four consecutive CHANNELS of one pixel (or spectrum row), the MFMA operand layout wants a lane to hold ONE channel of four pixels:
+// two DPP exchange steps (neighbours, then pairs) convert between the two, so that every global access of the transform kernels moves
+// 16 bytes per lane - the texture-address path takes a wave instruction every ~16 cycles whatever its width, and at 4 bytes per lane the
+// transforms' loads and stores occupied it for as long as their MFMAs occupy the matrix pipe (in-kernel stamps).
+__device__ __forceinline__ float dpp_quad_swap1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }   // [1,0,3,2]
+__device__ __forceinline__ float dpp_quad_swap2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); }   // [2,3,0,1]
+__device__ __forceinline__ void quad_transpose(float& r0, float& r1, float& r2, float& r3, bool odd, bool upper) {
+  { const float t = dpp_quad_swap1(odd ? r0 : r1); if (odd) r0 = t; else r1 = t; }
+  { const float t = dpp_quad_swap1(odd ? r2 : r3); if (odd) r2 = t; else r3 = t; }
+  { const float t = dpp_quad_swap2(upper ? r0 : r2); if (upper) r0 = t; else r2 = t; }
+  { const float t = dpp_quad_swap2(upper ? r1 : r3); if (upper) r1 = t; else r3 = t; }
+}
+
 struct FwdParams {
   const float* x; float* sp; const float* tab;
   int H, W, C, ld, groups, cstride, cvalid;

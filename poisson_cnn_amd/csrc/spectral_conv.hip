@@ -679,9 +679,9 @@ static_assert(O_REST % 256 == 0, "workspace header alignment");
 // grows the handle's workspace (never beyond the caller's limit, pcnn_set_workspace_limit); the tables are (re)uploaded after every growth
 int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, char** rest) {
   const size_t need = O_REST + bytes_after_tables;
+  if (h->spec_ws_limit && need > h->spec_ws_limit)
+    PCNN_FAIL(h, "spectral convolution: %zu B of workspace needed, the caller allows %zu B (pcnn_set_workspace_limit)", need, h->spec_ws_limit);
   if (h->spec_ws_bytes < need) {
-    if (h->spec_ws_limit && need > h->spec_ws_limit)
-      PCNN_FAIL(h, "spectral convolution: %zu B of workspace needed, the caller allows %zu B (pcnn_set_workspace_limit)", need, h->spec_ws_limit);
     if (h->spec_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->spec_ws); h->spec_ws = nullptr; h->spec_ws_bytes = 0; }
     size_t cap = need + need / 8;
     if (h->spec_ws_limit && cap > h->spec_ws_limit) cap = h->spec_ws_limit;
@@ -774,17 +774,19 @@ int pack_for(int Cin, int Cout) {
   return c <= 4 ? 8 : (c <= 8 ? 4 : 2);
 }
 
-// Tile size of a layer's spectral route.  64-point tiles halve the spectrum volume of the 11..15-tap layers ((64/50)^2 = 1.6 values per output
-// pixel at 15 taps against (32/18)^2 = 3.2) at about the matrix-core work per pixel of the 32-point tiles; below 11 taps their transforms cost
-// more than the mixing pass saves, layers of <= 16 channels keep the tile-packed 32-point form, and the inverse kernel holds the rows of a
-// tile's valid region in 7 accumulator sets per wave (56 rows: >= 9 taps).  Decided on ONE image (>= 36 tiles of 64 points), like the route.
+// Tile size of a layer's spectral route.  64-point tiles halve the spectrum volume of the 13- and 15-tap layers ((64/50)^2 = 1.6 values per output
+// pixel at 15 taps against (32/18)^2 = 3.2): the two mixing passes take 0.55 of their time, the transforms about the same (measured at
+// 8 x 1024^2, tools/probe_tile64.py: 15 taps 4.4 -> 3.5 ms forward, 6.9 -> 5.6 ms fused backward; 13 taps 3.8 -> 3.6 / 6.0 -> 5.5).  At 11 taps
+// and below their transforms cost more than the mixing saves (11 taps: 2.98 -> 3.25 ms), layers of <= 16 channels keep the tile-packed
+// 32-point form, and the inverse kernel holds the rows of a tile's valid region in 7 accumulator sets per wave (56 rows: >= 9 taps).
+// Decided on ONE image (>= 36 tiles of 64 points), like the route, so that a sample's arithmetic never depends on its batch neighbours.
 int pick_tile(pcnn_handle h, const pcnn_conv_desc* d) {
   const int forced = h->spectral_tile;                     // pcnn_set_spectral_tile / environment PCNN_SPEC_T
   const bool can64 = d->kh >= 9 && d->kw >= 9 && d->kh <= 15 && d->kw <= 15 && pack_for(d->Cin, d->Cout) == 1;
   if (forced == 32 || !can64) return 32;
   if (forced == 64) return 64;
   const int Vy = 65 - d->kh, Vx = 65 - d->kw;
-  return (d->kh >= 11 && d->kw >= 11 && pcnn_cdiv(d->Ho, Vy) * pcnn_cdiv(d->Wo, Vx) >= 36) ? 64 : 32;
+  return (d->kh >= 13 && d->kw >= 13 && pcnn_cdiv(d->Ho, Vy) * pcnn_cdiv(d->Wo, Vx) >= 36) ? 64 : 32;
 }
 
 }  // namespace
@@ -792,6 +794,11 @@ int pick_tile(pcnn_handle h, const pcnn_conv_desc* d) {
 extern "C" int pcnn_set_workspace_limit(pcnn_handle h, size_t bytes) {
   if (!h) return 1;
   h->spec_ws_limit = bytes;
+  if (bytes && h->spec_ws && h->spec_ws_bytes > bytes) {       // what the handle already holds beyond the new cap goes back to the caller's pool
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->spec_ws);
+    h->spec_ws = nullptr; h->spec_ws_bytes = 0;
+  }
   return 0;
 }
 

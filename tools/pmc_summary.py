@@ -6,7 +6,12 @@ the stamp matches the tree it runs from.
 A third pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE, optional) adds the matrix-pipe busy fraction per kernel: BUSY sums the busy cycles
 of the 1024 SIMDs, GUI_ACTIVE the active cycles of the 8 XCDs, so busy fraction = BUSY / (128 * GUI_ACTIVE).
 
-usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <math> [<mfma_counter_collection.csv>]"""
+A kernel-stats CSV of `rocprofv3 --kernel-trace --stats` over the same command with S steps (optional, with S) adds each kernel's time per step,
+so that the summary carries the per-kernel roofline table bench.py prints: launches and ms per step, bytes per launch, achieved TB/s against
+the 8 TB/s HBM peak, matrix-pipe busy fraction.
+
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <math> [<mfma_counter_collection.csv>
+                                   [<kernel_stats.csv> <steps covered by it>]]"""
 import collections
 import csv
 import json
@@ -16,9 +21,10 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KERNELS = (r'(conv_fwd_split_kernel<\d, \d>|conv_fwd_kernel<\d>|wgrad_split_kernel|wgrad_kernel|spec_fwd_kernel<\w+, \w+>|spec_inv_kernel|spec_mix_kernel<\d>|spec_wmix_kernel|'
+KERNELS = (r'(conv_fwd_split_kernel<\d, \d>|conv_fwd_kernel<\d>|wgrad_split_kernel|wgrad_kernel|spec_fwd_kernel<\w+, \w+>|spec_inv_kernel|spec_mix_kernel<\d>|spec_mix_lds_kernel<\d>|spec_wmix_kernel|'
+           r'spec64_fwd_kernel<\w+>|spec64_inv_kernel|'
            r'conv_small_fwd_kernel|conv_small_wgrad_kernel|split_convert_kernel|split_absmax_kernel|epilogue_bwd\w*|deconv_fwd_mfma_kernel|resize_fwd_kernel)')
-CONV = ('conv_fwd', 'wgrad', 'spec_', 'conv_small')      # what bench.py's `roofline` covers: every convolution launch
+CONV = ('conv_fwd', 'wgrad', 'spec', 'conv_small')      # what bench.py's `roofline` covers: every convolution launch
 
 
 def per_kernel(path, counter, scale=1024.0):
@@ -47,6 +53,22 @@ def main():
                       'traffic_bytes_per_launch': 2.0 * fr + wr}
         if k in busy and sum(active.get(k, [])) > 0:
             kernels[k]['mfma_busy_frac'] = sum(busy[k]) / (128.0 * sum(active[k]))
+    if len(sys.argv) > 7:            # per-kernel time from the --stats run: average duration per launch, launches per step
+        steps = float(sys.argv[7])
+        for r in csv.DictReader(open(sys.argv[6])):
+            m = re.search(KERNELS, r['Name'])
+            if m and m.group(1) in kernels:
+                kv = kernels[m.group(1)]
+                kv['stats_calls'] = kv.get('stats_calls', 0) + int(r['Calls'])
+                kv['stats_total_ns'] = kv.get('stats_total_ns', 0.0) + float(r['TotalDurationNs'])
+        for k, kv in kernels.items():
+            if kv.get('stats_calls'):
+                avg_s = kv['stats_total_ns'] / kv['stats_calls'] * 1e-9
+                kv['avg_launch_ms'] = avg_s * 1e3
+                kv['ms_per_step'] = kv['stats_total_ns'] * 1e-6 / steps
+                kv['launches_per_step'] = kv['stats_calls'] / steps
+                kv['hbm_tbs'] = kv['traffic_bytes_per_launch'] / avg_s / 1e12
+                kv['hbm_frac'] = kv['hbm_tbs'] / 8.0
     conv = [v for k, v in kernels.items() if k.startswith(CONV)]
     total = sum(v['traffic_bytes_per_launch'] * v['launches'] for v in conv)
     kernels['conv (all convolution kernels of one training step)'] = {'launches': 1, 'fetch_size_bytes_per_launch_raw': None, 'write_size_bytes_per_launch': None,
