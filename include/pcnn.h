@@ -216,6 +216,26 @@ int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo,
                     const int32_t* idx_y, const float* wt_y, const int32_t* idx_x, const float* wt_x,
                     float alpha, float* tmp, float* dx, int lddx);
 
+/* ---- per-sample-filter ("metalearning") convolutions: ONE launch for the whole batch -------------------------------------------
+ * Replace the tf.map_fn over samples of layers/metalearning_conv.py:148-169 (tf.pad + tf.nn.conv{1,2}d + bias per sample, filter and bias
+ * emitted by the layer's hyper-network) and layers/metalearning_deconvupscale.py:104-137 (conv2d_transpose, kernel = stride).  Sample n
+ * uses the filter at w + n * w_sample_stride (HWIO (kh,kw,Cin,Cout); transposed convolution (f,f,Cout,Cin)) and the bias at
+ * bias + n * bias_sample_stride.  d->N = batch, <= 32 output channels, <= 31 taps; 1-D layers are kh = 1.
+ *   _fwd    flip_transpose = 0: y = act(conv(pad(x), w_n) + b_n).  flip_transpose = 1: the same kernel as the DATA gradient - x is dz, the
+ *           stored filter is the forward filter (kh,kw,Cout_of_this_call,Cin_of_this_call), read flipped and transposed.
+ *   _wgrad  dw_n = filter gradient of sample n (not summed over the batch); workspace: pcnn_grouped_conv2d_wgrad_workspace(d) bytes. */
+size_t pcnn_grouped_conv2d_wgrad_workspace(const pcnn_conv_desc* d);
+int pcnn_grouped_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, long long w_sample_stride, const float* bias,
+                            long long bias_sample_stride, int flip_transpose, float* y);
+int pcnn_grouped_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw, long long dw_sample_stride, void* workspace);
+int pcnn_grouped_bias_grad(pcnn_handle h, int N, long long HW, int C, const float* dz, int lddz, float* dbias, long long bias_sample_stride);
+int pcnn_grouped_deconv_fwd(pcnn_handle h, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int f, const float* x, const float* k,
+                            long long k_sample_stride, const float* bias, long long bias_sample_stride, float* y);
+int pcnn_grouped_deconv_bwd_data(pcnn_handle h, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int f, const float* dy, const float* k,
+                                 long long k_sample_stride, float* dx);
+int pcnn_grouped_deconv_bwd_filter(pcnn_handle h, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int f, const float* x, const float* dy,
+                                   float* dk, long long k_sample_stride, float* dbias, long long bias_sample_stride);
+
 /* ---- small dense layers (tf.keras.layers.Dense: models/Homogeneous_Poisson_NN_Legacy.py:99-102, layers/Scaling.py:31-33)
  * y[n,o] = act(b[o] + sum_i x[n,i] w[i,o]);  bwd: given dy and y, dx, dw (+=), db (+=).  b / db may be NULL: a Dense layer without bias
  * (use_bias=False reaches every Dense layer of the metalearning hyper-networks, layers/metalearning_conv.py:113,128) */

@@ -9,7 +9,7 @@ import torch  # noqa: F401  - MUST be imported before libpcnn.so is dlopen'ed: b
 from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpcnn.so')
+LIB_PATH = os.environ.get('PCNN_LIBRARY') or os.path.join(_HERE, 'libpcnn.so')     # PCNN_LIBRARY: another build of the same library (developer A/B runs)
 
 
 class ConvDesc(Structure):

@@ -9,8 +9,14 @@
 namespace pcnn_spec {
 
 constexpr int RS = 32;                       // floats between consecutive spectrum rows of an item
-__host__ __device__ __forceinline__ int64_t sp_item(int64_t item, int rows) { return item * ((int64_t)rows * RS); }
-__host__ __device__ __forceinline__ size_t sp_bytes(size_t items, int rows) { return items * (size_t)rows * RS * sizeof(float); }
+// floats between consecutive items: rows x RS plus SP_PAD - the per-frequency kernels gather the same row of many items, i.e. they walk
+// memory with the item stride; a power-of-two stride maps those accesses onto few HBM channels
+#ifndef PCNN_SP_PAD
+#define PCNN_SP_PAD 32
+#endif
+constexpr int SP_PAD = PCNN_SP_PAD;
+__host__ __device__ __forceinline__ int64_t sp_item(int64_t item, int rows) { return item * ((int64_t)rows * RS + SP_PAD); }
+__host__ __device__ __forceinline__ size_t sp_bytes(size_t items, int rows) { return items * ((size_t)rows * RS + SP_PAD) * sizeof(float); }
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }

@@ -117,8 +117,11 @@ class metalearning_conv(_Hyper):
         self._init_common(data_format, store, ctx, name, device, seed)
         if dilation_rate not in (None, 1):
             raise NotImplementedError('dilation other than 1 is not used by any reference config')
-        if dimensions not in (None, 2):
-            raise NotImplementedError('dimensions = 2 only (the hot path of BASELINE.json)')
+        if dimensions not in (None, 1, 2):
+            raise NotImplementedError('dimensions = 1 or 2')
+        # dimensions = 1 (tf.nn.conv1d, layers/metalearning_conv.py:115-116; the boundary convolutions of models/Dirichlet_BC_NN_Metalearning.py:43-55):
+        # the same kernels with one filter row - tensors (N, L, C) are handled as (N, 1, L, C)
+        self.ndims = 1 if (dimensions == 1 or (dimensions is None and not isinstance(kernel_size, int) and len(kernel_size) == 1)) else 2
         self.k = _scalar(kernel_size, 'kernel_size')
         self.stride = 1 if strides is None else _scalar(strides, 'strides')
         self.cout = int(filters)
@@ -139,61 +142,75 @@ class metalearning_conv(_Hyper):
     def build(self, cin, dense_features):
         self.cin = int(cin)
         units, acts, ln = self._dense_args
-        self._build_dense(dense_features, self.k * self.k * self.cin * self.cout + (self.cout if self.use_bias else 0), units, acts, ln)
+        self.kh = 1 if self.ndims == 1 else self.k
+        self._build_dense(dense_features, self.kh * self.k * self.cin * self.cout + (self.cout if self.use_bias else 0), units, acts, ln)
 
     def _pads(self):
         # 'same': [ks//2, ks//2 if odd else ks//2-1] (metalearning_conv.py:103-107); 'valid': none
         return (self.k // 2, self.k // 2 - (1 - self.k % 2)) if self.same else (0, 0)
 
     def forward(self, x, dense_input, training=True):
-        """x (N,H,W,Cin) NHWC, dense_input (N,F)."""
+        """x (N,H,W,Cin) NHWC - (N,L,Cin) for a 1-D layer -, dense_input (N,F)."""
+        if self.ndims == 1:
+            x = x.unsqueeze(1)
         if not self.built:
             self.build(x.shape[3], dense_input.shape[1])
         N, H, W, _ = x.shape
         kb = self._emit(dense_input, training)
-        nk = self.k * self.k * self.cin * self.cout
+        kh, kw = self.kh, self.k
+        nk = kh * kw * self.cin * self.cout
         pt, pb = self._pads()
-        Ho, Wo = H + pt + pb - self.k + 1, W + pt + pb - self.k + 1
-        y = ops.empty((N, Ho, Wo, self.cout), x.device)
-        for n in range(N):
-            w = kb[n, :nk].view(self.k, self.k, self.cin, self.cout)
-            b = kb[n, nk:] if self.use_bias else None
-            ops.conv2d_fwd(x[n:n + 1], w, b, pad_top=pt, pad_left=pt, out_hw=(Ho, Wo), pad_mode=self.mode if self.same else 'CONSTANT',
-                           pad_value=self.pad_value, act=self.act, out=y[n:n + 1])
+        pty, pby = (0, 0) if self.ndims == 1 else (pt, pb)
+        Ho, Wo = H + pty + pby - kh + 1, W + pt + pb - kw + 1
+        # ONE launch for the batch: sample n takes its filter and bias from row n of the hyper-network's output (the reference serialises the
+        # samples with tf.map_fn, layers/metalearning_conv.py:18,30)
+        y = ops.grouped_conv2d_fwd(x, kb, (kh, kw, self.cin, self.cout), kb[:, nk:] if self.use_bias else None, pad_top=pty, pad_left=pt, out_hw=(Ho, Wo),
+                                   pad_mode=self.mode if self.same else 'CONSTANT', pad_value=self.pad_value, act=self.act)
         self.saved = (x, kb, y) if training else None
-        return ops.subsample(y, self.stride) if self.stride > 1 else y
+        if self.stride > 1:
+            y = ops.subsample(y, self.stride)
+        return y.squeeze(1) if self.ndims == 1 else y
 
     def backward(self, dy, need_dx=True):
         """Returns (dx, d_dense_input); parameter gradients of the hyper-network go to store.g."""
         x, kb, y = self.saved
         self.saved = None
+        if self.ndims == 1:
+            dy = dy.unsqueeze(1)
         if self.stride > 1:
             dy = ops.subsample_bwd(dy, (y.shape[1], y.shape[2]), self.stride)
         N, H, W, _ = x.shape
-        nk = self.k * self.k * self.cin * self.cout
+        kh, kw = self.kh, self.k
+        nk = kh * kw * self.cin * self.cout
         pt, pb = self._pads()
+        pty, pby = (0, 0) if self.ndims == 1 else (pt, pb)
         dkb = ops.zeros(tuple(kb.shape), x.device)
         dx = ops.empty(tuple(x.shape), x.device) if need_dx else None
         mode = self.mode if self.same else 'CONSTANT'
-        for n in range(N):
-            dyn, yn = dy[n:n + 1], y[n:n + 1]
-            dz = ops.empty(tuple(dyn.shape), x.device)
-            ops.epilogue_bwd(dyn, yn if self.act != 'linear' else None, act=self.act, dz=dz, dbias=dkb[n, nk:] if self.use_bias else None, ws=self.ctx.ws)
-            w = kb[n, :nk].view(self.k, self.k, self.cin, self.cout)
-            ops.conv2d_wgrad(x[n:n + 1], dz, w.shape, pad_top=pt, pad_left=pt, pad_mode=mode, pad_value=self.pad_value,
-                             out=dkb[n, :nk].view(self.k, self.k, self.cin, self.cout), ws=self.ctx.ws)
-            if need_dx:
-                wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((self.k, self.k, self.cout, self.cin), x.device))
-                if mode == 'CONSTANT':
-                    ops.conv2d_fwd(dz, wf, None, pad_top=self.k - 1 - pt, pad_left=self.k - 1 - pt, out_hw=(H, W), out=dx[n:n + 1])
-                else:
-                    gp = ops.conv2d_fwd(dz, wf, None, pad_top=self.k - 1, pad_left=self.k - 1, out_hw=(H + pt + pb, W + pt + pb))
-                    ops.pad_fold_bwd(gp, (H, W), ((pt, pb), (pt, pb)), mode, out=dx[n:n + 1])
+        wshape = (kh, kw, self.cin, self.cout)
+        if self.act == 'linear':
+            dz = dy if dy.is_contiguous() else dy.contiguous()
+        else:
+            dz = ops.empty(tuple(dy.shape), x.device)
+            ops.epilogue_bwd(dy, y, act=self.act, dz=dz, ws=self.ctx.ws)
+        if self.use_bias:
+            ops.grouped_bias_grad(dz, dkb[:, nk:])
+        ops.grouped_conv2d_wgrad(x, dz, wshape, dkb, pad_top=pty, pad_left=pt, pad_mode=mode, pad_value=self.pad_value, ws=self.ctx.ws)
+        if need_dx:          # the forward filters read flipped and transposed inside the kernel: no per-sample flip launches
+            if mode == 'CONSTANT':
+                ops.grouped_conv2d_fwd(dz, kb, wshape, None, pad_top=kh - 1 - pty, pad_left=kw - 1 - pt, out_hw=(H, W), flip_transpose=True, out=dx)
+            else:
+                gp = ops.grouped_conv2d_fwd(dz, kb, wshape, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + pty + pby, W + pt + pb), flip_transpose=True)
+                ops.pad_fold_bwd(gp, (H, W), ((pty, pby), (pt, pb)), mode, out=dx)
+        if need_dx and self.ndims == 1:
+            dx = dx.squeeze(1)
         return dx, self._emit_backward(dkb)
 
     def __call__(self, inputs, training=False):
         """Reference call convention: [conv_input (N,C,H,W), dense_input (N,F)] -> (N,filters,H',W')."""
         x, dense_input = inputs
+        if self.ndims == 1:                     # (N, C, L) -> (N, L, C)
+            return self.forward(x.permute(0, 2, 1).contiguous(), dense_input.contiguous(), training=training).permute(0, 2, 1)
         x = x.permute(0, 2, 3, 1).contiguous()
         return self.forward(x, dense_input.contiguous(), training=training).permute(0, 3, 1, 2)
 
@@ -229,9 +246,7 @@ class metalearning_deconvupscale(_Hyper):
         N = x.shape[0]
         kb = self._emit(dense_input, training)
         nk = self.k * self.k * self.cout * self.cin
-        y = ops.empty((N, out_hw[0], out_hw[1], self.cout), x.device)
-        for n in range(N):
-            ops.deconv_fwd(x[n:n + 1], kb[n, :nk].view(self.k, self.k, self.cout, self.cin), kb[n, nk:] if self.use_bias else None, out_hw, self.up, out=y[n:n + 1])
+        y = ops.grouped_deconv_fwd(x, kb, (self.k, self.k, self.cout, self.cin), kb[:, nk:] if self.use_bias else None, out_hw, self.up)
         self.saved = (x, kb) if training else None
         return y
 
@@ -242,11 +257,10 @@ class metalearning_deconvupscale(_Hyper):
         nk = self.k * self.k * self.cout * self.cin
         dkb = ops.zeros(tuple(kb.shape), x.device)
         dx = ops.empty(tuple(x.shape), x.device) if need_dx else None
-        for n in range(N):
-            ops.deconv_bwd_filter(x[n:n + 1], dy[n:n + 1], self.up, dk=dkb[n, :nk].view(self.k, self.k, self.cout, self.cin),
-                                  dbias=dkb[n, nk:] if self.use_bias else None, ws=self.ctx.ws)
-            if need_dx:
-                ops.deconv_bwd_data(dy[n:n + 1], kb[n, :nk].view(self.k, self.k, self.cout, self.cin), (x.shape[1], x.shape[2]), self.up, out=dx[n:n + 1])
+        dyc = dy if dy.is_contiguous() else dy.contiguous()
+        ops.grouped_deconv_bwd_filter(x, dyc, self.up, dkb, dkb[:, nk:] if self.use_bias else None)
+        if need_dx:
+            ops.grouped_deconv_bwd_data(dyc, kb, (self.k, self.k, self.cout, self.cin), (x.shape[1], x.shape[2]), self.up, out=dx)
         return dx, self._emit_backward(dkb)
 
     def __call__(self, inputs, training=False):

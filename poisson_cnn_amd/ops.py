@@ -740,3 +740,75 @@ def flip_rotate(x_nhw, transpose=False, flip_y=False, flip_x=False, alpha=None, 
     handle().call('pcnn_flip_rotate', c_int(N), c_int(Ho), c_int(Wo), c_int(int(transpose)), c_int(int(flip_y)), c_int(int(flip_x)), _p(x_nhw),
                   _p(alpha), c_int(int(accumulate)), _p(out))
     return out
+
+
+# ----------------------------------------------------------------------------- per-sample-filter ("metalearning") convolutions
+def _row_stride(t):
+    """floats between consecutive samples of a (N, F) parameter matrix emitted by a hyper-network (a view of it may start at a column offset)"""
+    assert t.dim() == 2 and t.stride(1) == 1
+    return int(t.stride(0))
+
+
+def grouped_conv2d_fwd(x, w_all, w_shape, bias_all=None, *, pad_top, pad_left, out_hw, pad_mode='CONSTANT', pad_value=0.0, act='linear', flip_transpose=False,
+                       out=None):
+    """ONE launch for the batch: sample n is convolved with ITS filter w_all[n] (a row of the hyper-network's output matrix, HWIO w_shape) and
+    bias bias_all[n] (layers/metalearning_conv.py:148-169).  flip_transpose: w_shape is then the FORWARD filter's (kh, kw, Cout_here, Cin_here)
+    and the kernel reads it flipped and transposed - the data gradient of the same layer."""
+    N, H, W, Cin = x.shape
+    kh, kw, a, b = w_shape
+    Cout = a if flip_transpose else b
+    assert (b if flip_transpose else a) == Cin, (w_shape, Cin, flip_transpose)
+    Ho, Wo = out_hw
+    y = out if out is not None else empty((N, Ho, Wo, Cout), x.device)
+    d = conv_desc(x.shape, _ld(x), (kh, kw, Cin, Cout), (Ho, Wo), _ld(y), pad_top, pad_left, pad_mode, pad_value, act)
+    handle().call('pcnn_grouped_conv2d_fwd', byref(d), _p(x), _p(w_all), ctypes.c_longlong(_row_stride(w_all)), _p(bias_all),
+                  ctypes.c_longlong(_row_stride(bias_all) if bias_all is not None else 0), c_int(1 if flip_transpose else 0), _p(y))
+    return y
+
+
+def grouped_conv2d_wgrad(x, dz, w_shape, dw_all, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, ws=None):
+    """dw_all[n] (a row of the (N, F) gradient matrix) = filter gradient of sample n, one launch (+ a fixed-order reduction)."""
+    kh, kw, Cin, Cout = w_shape
+    d = conv_desc(x.shape, _ld(x), w_shape, (dz.shape[1], dz.shape[2]), _ld(dz), pad_top, pad_left, pad_mode, pad_value)
+    lib = _lib.load()
+    lib.pcnn_grouped_conv2d_wgrad_workspace.restype = c_size_t
+    wsb = (ws or _default_ws).get(lib.pcnn_grouped_conv2d_wgrad_workspace(byref(d)), x.device)
+    handle().call('pcnn_grouped_conv2d_wgrad', byref(d), _p(x), _p(dz), _p(dw_all), ctypes.c_longlong(_row_stride(dw_all)), _p(wsb))
+    return dw_all
+
+
+def grouped_bias_grad(dz, dbias_all):
+    N, H, W, C = dz.shape
+    handle().call('pcnn_grouped_bias_grad', c_int(N), ctypes.c_longlong(H * W), c_int(C), _p(dz), c_int(_ld(dz)), _p(dbias_all), ctypes.c_longlong(_row_stride(dbias_all)))
+    return dbias_all
+
+
+def grouped_deconv_fwd(x, k_all, k_shape, bias_all, out_hw, f, out=None):
+    """Per-sample conv2d_transpose with kernel = stride = f (layers/metalearning_deconvupscale.py:104-137), k_shape (f, f, Cout, Cin)."""
+    N, hc, wc, Cin = x.shape
+    assert x.is_contiguous() and k_shape[0] == f and k_shape[1] == f and k_shape[3] == Cin
+    Cout = k_shape[2]
+    y = out if out is not None else empty((N, out_hw[0], out_hw[1], Cout), x.device)
+    assert y.is_contiguous()
+    handle().call('pcnn_grouped_deconv_fwd', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(out_hw[0]), c_int(out_hw[1]), c_int(Cout), c_int(f), _p(x), _p(k_all),
+                  ctypes.c_longlong(_row_stride(k_all)), _p(bias_all), ctypes.c_longlong(_row_stride(bias_all) if bias_all is not None else 0), _p(y))
+    return y
+
+
+def grouped_deconv_bwd_data(dy, k_all, k_shape, coarse_hw, f, out=None):
+    N, H, W, Cout = dy.shape
+    Cin = k_shape[3]
+    assert dy.is_contiguous()
+    dx = out if out is not None else empty((N, coarse_hw[0], coarse_hw[1], Cin), dy.device)
+    handle().call('pcnn_grouped_deconv_bwd_data', c_int(N), c_int(coarse_hw[0]), c_int(coarse_hw[1]), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(dy), _p(k_all),
+                  ctypes.c_longlong(_row_stride(k_all)), _p(dx))
+    return dx
+
+
+def grouped_deconv_bwd_filter(x, dy, f, dk_all, dbias_all=None):
+    N, hc, wc, Cin = x.shape
+    _, H, W, Cout = dy.shape
+    assert x.is_contiguous() and dy.is_contiguous()
+    handle().call('pcnn_grouped_deconv_bwd_filter', c_int(N), c_int(hc), c_int(wc), c_int(Cin), c_int(H), c_int(W), c_int(Cout), c_int(f), _p(x), _p(dy), _p(dk_all),
+                  ctypes.c_longlong(_row_stride(dk_all)), _p(dbias_all), ctypes.c_longlong(_row_stride(dbias_all) if dbias_all is not None else 0))
+    return dk_all

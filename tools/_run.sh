@@ -1,4 +1,2 @@
 R=$GRAFT_REPO_ROOT
-python bench.py --math fp32 --no-c3 --no-cpu-baseline --no-dataset --steps 3 --warmup 1 > $R/gpurun_out/r03_bench_q_auto.json 2> $R/gpurun_out/r03_bench_q_auto.err; python -c "import json;d=json.load(open('$R/gpurun_out/r03_bench_q_auto.json'));print('auto ms/step',d['ms_per_step'])"
-PCNN_SPEC_T=32 python bench.py --math fp32 --no-c3 --no-cpu-baseline --no-dataset --steps 3 --warmup 1 > $R/gpurun_out/r03_bench_q_t32.json 2> $R/gpurun_out/r03_bench_q_t32.err; python -c "import json;d=json.load(open('$R/gpurun_out/r03_bench_q_t32.json'));print('T=32 ms/step',d['ms_per_step'])"
-python -m pytest tests -m gpu -x -v > $R/gpurun_out/r03_tests_c.log 2>&1; echo "tests rc=$?"; tail -3 $R/gpurun_out/r03_tests_c.log
+timeout -k 10 800 python -m pytest tests/test_gpu_grouped.py tests/test_gpu_ops.py tests/test_gpu_hpnn_chain.py tests/test_gpu_spectral64.py tests/test_gpu_spectral.py -x -v > $R/gpurun_out/r03_tests_d.log 2>&1; echo "rc=$?"; tail -15 $R/gpurun_out/r03_tests_d.log
