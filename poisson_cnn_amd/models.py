@@ -688,10 +688,16 @@ class Poisson_CNN_Legacy(_ModelBase):
             self.hpnn.set_weights(list(weights[:k]))
             self.dbcnn.set_weights(list(weights[k:]))
 
-    def save_weights(self, path):
+    def save_weights(self, path, save_format=None):
+        if save_format in ('tf', 'tensorflow'):
+            from .tf_checkpoint import save_tf_checkpoint
+            return save_tf_checkpoint(self, str(path))
         np.savez(path, **{n.replace('/', '.'): w for n, w in zip(self.weight_names, self.get_weights())})
 
     def load_weights(self, path):
+        if os.path.exists(str(path) + '.index'):
+            from .tf_checkpoint import load_tf_checkpoint
+            return load_tf_checkpoint(self, str(path))
         with np.load(path if str(path).endswith('.npz') else str(path) + '.npz') as z:
             self.set_weights({n: z[n.replace('/', '.')] for n in self.weight_names})
 

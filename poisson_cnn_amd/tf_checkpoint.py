@@ -274,8 +274,8 @@ def write_bundle(prefix, tensors, with_object_graph=True):
         f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
 
 
-def read_bundle(prefix, verify=True):
-    """-> dict checkpoint key -> numpy array (the object-graph entry is skipped)."""
+def read_bundle(prefix, verify=True, graph_out=None):
+    """-> dict checkpoint key -> numpy array (the object-graph entry is skipped; its serialized proto is appended to `graph_out` if given)."""
     items = _read_table(prefix + '.index', verify)
     if not items or items[0][0] != b'':
         raise ValueError('TensorBundle header entry missing')
@@ -296,6 +296,13 @@ def read_bundle(prefix, verify=True):
             else:
                 e[n] = v
         dtype = e.get(1, 0)
+        if key.decode() == OBJECT_GRAPH_KEY and graph_out is not None:
+            sid = e.get(3, 0)
+            if sid not in shards:
+                shards[sid] = np.memmap('%s.data-%05d-of-%05d' % (prefix, sid, nshards), dtype=np.uint8, mode='r')
+            raw = bytes(shards[sid][e.get(4, 0):e.get(4, 0) + e.get(5, 0)])
+            n, q = _read_varint(raw, 0)                             # string tensor: [varint length][4-byte masked crc of the lengths][bytes]
+            graph_out.append(raw[q + 4:q + 4 + n])
         if dtype == DT_STRING or key.decode() == OBJECT_GRAPH_KEY:
             continue
         if dtype not in DT_INV:
@@ -308,6 +315,37 @@ def read_bundle(prefix, verify=True):
             raise ValueError('checksum mismatch for %s' % key.decode())
         out[key.decode()] = np.frombuffer(raw, dtype=DT_INV[dtype].newbyteorder('<')).astype(DT_INV[dtype]).reshape(shape)
     return out
+
+
+def parse_object_graph(blob):
+    """TrackableObjectGraph -> list of nodes {children: {local_name: node_id}, attributes: {name: checkpoint_key}}."""
+    nodes = []
+    for num, _, body in _parse(blob):
+        if num != 1:
+            continue
+        nd = {'children': {}, 'attributes': {}}
+        for n, _, v in _parse(body):
+            if n == 1:
+                f = {a: b for a, _, b in _parse(v)}
+                nd['children'][f.get(2, b'').decode()] = f.get(1, 0)
+            elif n == 2:
+                f = {a: b for a, _, b in _parse(v)}
+                nd['attributes'][f.get(1, b'').decode()] = f.get(3, b'').decode()
+        nodes.append(nd)
+    return nodes
+
+
+def resolve_checkpoint_key(nodes, object_path):
+    """Walks `children.local_name` edges from the root along the components of a Keras object path and returns the leaf's VARIABLE_VALUE
+    checkpoint key - the key TensorFlow itself chose for that variable (the first path its traversal found), whatever string that is.
+    None when the graph has no such path."""
+    cur = 0
+    for comp in object_path.split('/'):
+        nxt = nodes[cur]['children'].get(comp)
+        if nxt is None or nxt >= len(nodes):
+            return None
+        cur = nxt
+    return nodes[cur]['attributes'].get('VARIABLE_VALUE')
 
 
 # ----------------------------------------------------------------------------------------------------------------- Keras object paths of the models
@@ -345,12 +383,61 @@ def _block(m, names, blk, theirs):
             m[n] = theirs + '/upsample_layer' + n[len(blk.name + '/deconv'):]
 
 
+def _dbcnn_paths(model):
+    """Dirichlet_BC_NN_Legacy_2 (models/Dirichlet_BC_NN_Legacy.py:47-95): self.boundary_convolutions = [conv, (BatchNormalization), resnet] per stage,
+    self.domain_info_dense_layers, self.final_convolutions = [conv, resnet] per stage followed by the regular convolutions.  (The parallel
+    *_ops lists hold the same layer objects; TensorFlow names a variable after the first attribute path that reaches it.)"""
+    import re
+    names = model.weight_names
+    per = 3 if model.use_batchnorm else 2
+    nst = 1 + max([int(re.match(r'final/stage(\d+)/', n).group(1)) for n in names if n.startswith('final/stage')] + [-1])
+    m = {}
+    for n in names:
+        q = n.split('/')
+        if q[0] == 'bc':
+            k = int(q[1][5:])
+            if q[2] == 'conv':
+                m[n] = 'boundary_convolutions/%d/%s' % (per * k, q[3])
+            elif q[2] == 'bn':
+                m[n] = 'boundary_convolutions/%d/%s' % (per * k + 1, q[3])
+            else:                                                       # res/conv{i} | res/bn{i}
+                sub = 'conv_layers/%s' % q[3][4:] if q[3].startswith('conv') else 'batchnorm%s' % q[3][2:]
+                m[n] = 'boundary_convolutions/%d/%s/%s' % (per * k + per - 1, sub, q[4])
+        elif q[0] == 'mlp':
+            m[n] = 'domain_info_dense_layers/%s/%s' % (q[1][5:], q[2])
+        elif q[0] == 'final' and q[1].startswith('stage'):
+            k = int(q[1][5:])
+            if q[2] == 'conv':
+                m[n] = 'final_convolutions/%d/%s' % (2 * k, q[3])
+            else:
+                sub = 'conv_layers/%s' % q[3][4:] if q[3].startswith('conv') else 'batchnorm%s' % q[3][2:]
+                m[n] = 'final_convolutions/%d/%s/%s' % (2 * k + 1, sub, q[4])
+        elif q[0] == 'final' and q[1].startswith('out'):
+            m[n] = 'final_convolutions/%d/%s' % (2 * nst + int(q[1][3:]), q[2])
+    return m
+
+
 def keras_object_paths(model):
-    """Our parameter name -> the reference model's Keras object path (attribute names of models/Homogeneous_Poisson_NN_Legacy.py:41-115)."""
+    """Our parameter name -> the reference model's Keras object path: Homogeneous_Poisson_NN_Legacy (attribute names of
+    models/Homogeneous_Poisson_NN_Legacy.py:41-115), Dirichlet_BC_NN_Legacy_2, and Poisson_CNN_Legacy (self.hpnn / self.dbcnn,
+    models/Poisson_CNN_Legacy.py:8-9) - the three models the reference's training scripts save through ModelCheckpoint
+    (train/hpnn_legacy_train.py, train/dbcnn_legacy_train.py, train/pcnn_end_to_end.py; train/utils.py:10-29)."""
     from . import layers as L
-    from .models import Homogeneous_Poisson_NN_Legacy
+    from .models import Homogeneous_Poisson_NN_Legacy, Dirichlet_BC_NN_Legacy_2, Poisson_CNN_Legacy
+    if isinstance(model, Poisson_CNN_Legacy):
+        m = {'hpnn/' + n: 'hpnn/' + v for n, v in keras_object_paths(model.hpnn).items()}
+        m.update({'dbcnn/' + n: 'dbcnn/' + v for n, v in keras_object_paths(model.dbcnn).items()})
+        return m
+    if isinstance(model, Dirichlet_BC_NN_Legacy_2):
+        m = _dbcnn_paths(model)
+        missing = [n for n in model.weight_names if n not in m]
+        if missing or len(set(m.values())) != len(m):
+            raise RuntimeError('no unique Keras object path for %s' % (missing[:5],))
+        return m
     if not isinstance(model, Homogeneous_Poisson_NN_Legacy):
-        raise NotImplementedError('TensorFlow-format checkpoints are mapped for Homogeneous_Poisson_NN_Legacy (flat .npz works for every model)')
+        raise NotImplementedError('TensorFlow-format checkpoints are mapped for Homogeneous_Poisson_NN_Legacy, Dirichlet_BC_NN_Legacy_2 and Poisson_CNN_Legacy - '
+                                  'the models the reference can construct and train; the two train/hpnn_train.py classes raise NameError in the '
+                                  'reference, so no TensorFlow checkpoint of them can exist (flat .npz works for every model)')
     names = model.weight_names
     m = {}
     idx = 0
@@ -383,19 +470,37 @@ def keras_object_paths(model):
     return m
 
 
+def _tf_shape(name, w):
+    """The tensor as TensorFlow holds it: our 1-D boundary convolutions keep their Conv1D kernels (k, Cin, Cout) as (1, k, Cin, Cout)."""
+    w = np.asarray(w)
+    return w.reshape(w.shape[1:]) if (name.endswith('/kernel') and w.ndim == 4 and w.shape[0] == 1 and '/bc/' in '/' + name) else w
+
+
 def save_tf_checkpoint(model, prefix):
     paths = keras_object_paths(model)
-    write_bundle(prefix, {paths[n] + SUFFIX: w for n, w in zip(model.weight_names, model.get_weights())})
+    write_bundle(prefix, {paths[n] + SUFFIX: _tf_shape(n, w) for n, w in zip(model.weight_names, model.get_weights())})
 
 
 def load_tf_checkpoint(model, prefix):
-    """Loads variables by Keras object path; optimizer slots and anything else in the checkpoint are ignored."""
+    """Loads variables by Keras object path.  The key of each variable is looked up in the checkpoint's own object graph (walk of the
+    `children.local_name` edges along the path -> the VARIABLE_VALUE attribute's checkpoint_key): TensorFlow names a key after the first path
+    its traversal finds, which need not be the literal `<path>/.ATTRIBUTES/VARIABLE_VALUE`; only a checkpoint without a graph entry falls back
+    to that literal.  Optimizer slots and anything else in the checkpoint are ignored.  (Cross-reading with TensorFlow itself is untested here:
+    there is no TensorFlow in the build environment - DESIGN.md section 7.)"""
     paths = keras_object_paths(model)
-    tensors = read_bundle(prefix)
+    graph = []
+    tensors = read_bundle(prefix, graph_out=graph)
+    nodes = parse_object_graph(graph[0]) if graph else None
     weights = {}
+    ours = dict(zip(model.weight_names, model.get_weights()))
     for n in model.weight_names:
-        key = paths[n] + SUFFIX
+        key = resolve_checkpoint_key(nodes, paths[n]) if nodes else None
+        if key is None or key not in tensors:
+            key = paths[n] + SUFFIX
         if key not in tensors:
             raise ValueError('checkpoint %s has no variable %s (expected for %s)' % (prefix, key, n))
-        weights[n] = tensors[key]
+        t = tensors[key]
+        if t.size != ours[n].size:
+            raise ValueError('checkpoint variable %s has shape %s, the model\'s %s has %s' % (key, t.shape, n, ours[n].shape))
+        weights[n] = t.reshape(ours[n].shape)
     model.set_weights(weights)

@@ -144,3 +144,82 @@ def test_hpnn_checkpoint_uses_the_reference_object_paths(tmp_path):
     T.write_bundle(str(d / 'short'), t)
     with pytest.raises(ValueError, match='post_merge_conv/kernel'):
         m2.load_weights(str(d / 'short'))
+
+
+def test_dbcnn_and_pcnn_checkpoints_use_the_reference_object_paths(tmp_path):
+    """Dirichlet_BC_NN_Legacy_2 (models/Dirichlet_BC_NN_Legacy.py:47-95) and Poisson_CNN_Legacy (self.hpnn / self.dbcnn): object paths, Conv1D
+    kernel shapes as TensorFlow holds them, the object-graph proto lists every variable, bit-exact round trips."""
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.models import Dirichlet_BC_NN_Legacy_2, Homogeneous_Poisson_NN_Legacy, Poisson_CNN_Legacy
+    dcfg = configs.dbcnn_tiny()['model']
+    db = Dirichlet_BC_NN_Legacy_2(**dcfg, device='cpu', seed=1)
+    paths = T.keras_object_paths(db)
+    per = 3 if db.use_batchnorm else 2
+    assert paths['bc/stage0/conv/kernel'] == 'boundary_convolutions/0/kernel'
+    assert paths['bc/stage1/res/conv2/bias'] == 'boundary_convolutions/%d/conv_layers/2/bias' % (per + per - 1)
+    if db.use_batchnorm:
+        assert paths['bc/stage1/bn/moving_mean'] == 'boundary_convolutions/%d/moving_mean' % (per + 1)
+        assert paths['bc/stage2/res/bn1/gamma'] == 'boundary_convolutions/%d/batchnorm1/gamma' % (2 * per + per - 1)
+    assert paths['mlp/dense1/kernel'] == 'domain_info_dense_layers/1/kernel'
+    assert paths['final/stage0/conv/bias'] == 'final_convolutions/0/bias' and paths['final/stage0/res/conv1/kernel'] == 'final_convolutions/1/conv_layers/1/kernel'
+    assert paths['final/out1/kernel'] == 'final_convolutions/3/kernel'
+    d = tmp_path / 'db'
+    d.mkdir()
+    db.save_weights(str(d / 'chkpt.checkpoint'), save_format='tf')
+    graph = []
+    t = T.read_bundle(str(d / 'chkpt.checkpoint'), graph_out=graph)
+    assert t['boundary_convolutions/0/kernel' + T.SUFFIX].ndim == 3                     # tf.keras.layers.Conv1D kernel: (k, Cin, Cout)
+    nodes = T.parse_object_graph(graph[0])
+    for n in db.weight_names:                                                            # the object graph lists every variable of the model
+        assert T.resolve_checkpoint_key(nodes, paths[n]) == paths[n] + T.SUFFIX
+    db2 = Dirichlet_BC_NN_Legacy_2(**dcfg, device='cpu', seed=2)
+    db2.load_weights(str(d / 'chkpt.checkpoint'))
+    for a, b in zip(db.get_weights(), db2.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    # the loader follows the checkpoint's OWN graph: a checkpoint whose keys are not the literal `<path>/.ATTRIBUTES/VARIABLE_VALUE` strings
+    # (TensorFlow names a key after the first path its traversal finds) loads as long as its graph leads there
+    renamed = {}
+    for k, v in t.items():
+        renamed[k.replace('boundary_convolutions/', 'boundary_convolution_ops/')] = v
+    # re-encode: children edges keep the attribute names, the leaves' checkpoint_key point at the renamed tensors
+    def graph_with_keys(keys_by_path):
+        nds = [{'children': [], 'attr': None}]
+        index = {'': 0}
+        for path, key in keys_by_path.items():
+            cur, prefix = 0, ''
+            for comp in path.split('/'):
+                prefix = comp if not prefix else prefix + '/' + comp
+                if prefix not in index:
+                    index[prefix] = len(nds)
+                    nds.append({'children': [], 'attr': None})
+                    nds[cur]['children'].append((index[prefix], comp))
+                cur = index[prefix]
+            nds[cur]['attr'] = (path, key)
+        out = b''
+        for nd in nds:
+            body = b''.join(T._msg(1, T._field(1, 0, T._varint(i)) + T._msg(2, name.encode())) for i, name in nd['children'])
+            if nd['attr'] is not None:
+                body += T._msg(2, T._msg(1, b'VARIABLE_VALUE') + T._msg(2, nd['attr'][0].encode()) + T._msg(3, nd['attr'][1].encode()))
+            out += T._msg(1, body)
+        return out
+    g2 = graph_with_keys({paths[n]: (paths[n] + T.SUFFIX).replace('boundary_convolutions/', 'boundary_convolution_ops/') for n in db.weight_names})
+    orig = T._object_graph
+    T._object_graph = lambda keys: g2
+    try:
+        T.write_bundle(str(d / 'renamed'), renamed)
+    finally:
+        T._object_graph = orig
+    db3 = Dirichlet_BC_NN_Legacy_2(**dcfg, device='cpu', seed=3)
+    db3.load_weights(str(d / 'renamed'))
+    for a, b in zip(db.get_weights(), db3.get_weights()):
+        np.testing.assert_array_equal(a, b)
+    # Poisson_CNN_Legacy: the two sub-models under their attribute names
+    full = configs.hpnn_tiny()['model']
+    pc = Poisson_CNN_Legacy(Homogeneous_Poisson_NN_Legacy(**full, device='cpu', seed=4), Dirichlet_BC_NN_Legacy_2(**dcfg, device='cpu', seed=5))
+    pp = T.keras_object_paths(pc)
+    assert pp['hpnn/pre/conv0/kernel'] == 'hpnn/pre_bottleneck_convolutions/0/kernel' and pp['dbcnn/mlp/dense0/bias'] == 'dbcnn/domain_info_dense_layers/0/bias'
+    pc.save_weights(str(d / 'pcnn'), save_format='tf')
+    pc2 = Poisson_CNN_Legacy(Homogeneous_Poisson_NN_Legacy(**full, device='cpu', seed=6), Dirichlet_BC_NN_Legacy_2(**dcfg, device='cpu', seed=7))
+    pc2.load_weights(str(d / 'pcnn'))
+    for a, b in zip(pc.get_weights(), pc2.get_weights()):
+        np.testing.assert_array_equal(a, b)
