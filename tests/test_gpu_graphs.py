@@ -1,0 +1,78 @@
+"""hipGraph capture of whole model steps (poisson_cnn_amd/graphs.py): a replayed step is the same kernels on the same buffers as the eager
+step, so results must be bit-identical - inference and training (loss, gradients, weights after two optimizer steps) of the boundary
+network, the end-to-end model and the homogeneous network; a shape other than the captured one is refused."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dbcnn(seed):
+    from oracle import dbcnn as odb
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.models import Dirichlet_BC_NN_Legacy_2
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import Adam
+    full = configs.dbcnn_tiny()
+    m = Dirichlet_BC_NN_Legacy_2(**full['model'])
+    m.set_weights(odb.init_params(full['model'], seed=seed, gain=1.3, randomize_all=True))
+    m.compile(loss=loss_wrapper(global_batch_size=3, **full['training']['loss_parameters']), optimizer=Adam(learning_rate=1e-3))
+    return m
+
+
+def _dbcnn_batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    bc = torch.cumsum(torch.randn(3, 1, 44, generator=g) * 0.1, 2).cuda()
+    dx = (torch.rand(3, 1, generator=g) * 4.5e-2 + 5e-3).cuda()
+    tgt = (torch.randn(3, 1, 40, 44, generator=g) * 0.1).cuda()
+    return bc, dx, tgt
+
+
+def test_dbcnn_graph_replay_is_bit_identical_to_eager():
+    from poisson_cnn_amd.graphs import GraphedInference, GraphedTrainStep
+    eager, graphed = _dbcnn(5), _dbcnn(5)
+    bc, dx, tgt = _dbcnn_batch(1)
+    inf = GraphedInference(graphed, [bc, dx, 40])
+    bc2, dx2, tgt2 = _dbcnn_batch(2)
+    assert torch.equal(inf([bc2, dx2, 40]), eager([bc2, dx2, 40]))
+    assert torch.equal(inf([bc, dx, 40]), eager([bc, dx, 40]))
+    with pytest.raises(ValueError, match='captured for'):
+        inf([bc, dx, 36])
+    step = GraphedTrainStep(graphed, ((bc, dx), tgt))
+    assert torch.equal(eager.store.flat_w, graphed.store.flat_w)                  # capture leaves the weights alone
+    for data in (((bc, dx), tgt), ((bc2, dx2), tgt2)):
+        le = eager.train_step(data)
+        lg = step(data)
+        assert float(le['loss']) == float(lg['loss']) and float(le['mse']) == float(lg['mse'])
+        assert torch.equal(eager.store.flat_g, graphed.store.flat_g)
+        assert torch.equal(eager.store.flat_w, graphed.store.flat_w)
+    assert graphed.optimizer.iterations == 2
+
+
+def test_hpnn_graph_replay_is_bit_identical_to_eager():
+    from oracle import hpnn as ohpnn
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.graphs import GraphedTrainStep
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    from poisson_cnn_amd.train import Adam
+    full = configs.hpnn_tiny()
+    models = []
+    for _ in range(2):
+        m = Homogeneous_Poisson_NN_Legacy(**full['model'])
+        m.set_weights(ohpnn.init_params(full['model'], seed=3, gain=1.4, randomize_all=True))
+        m.compile(loss=loss_wrapper(global_batch_size=2, **full['training']['loss_parameters']), optimizer=Adam(learning_rate=1e-3))
+        models.append(m)
+    eager, graphed = models
+    rng = np.random.default_rng(7)
+    rhs = torch.tensor(rng.uniform(-1, 1, (2, 1, 40, 44)).astype(np.float32)).cuda()
+    dx = torch.tensor(rng.uniform(5e-3, 5e-2, (2, 1)).astype(np.float32)).cuda()
+    tgt = torch.tensor((rng.standard_normal((2, 1, 40, 44)) * 0.1).astype(np.float32)).cuda()
+    import os
+    step = GraphedTrainStep(graphed, ((rhs, dx), tgt))
+    eager.ctx.use_side = False                                                     # same single-stream launch order as the captured step
+    for _ in range(2):
+        le, lg = eager.train_step(((rhs, dx), tgt)), step(((rhs, dx), tgt))
+        assert float(le['loss']) == float(lg['loss'])
+        assert torch.equal(eager.store.flat_w, graphed.store.flat_w)

@@ -12,6 +12,7 @@ from poisson_cnn_amd import configs, ops
 from poisson_cnn_amd.losses import loss_wrapper
 from poisson_cnn_amd.models import Dirichlet_BC_NN_Legacy_2, Homogeneous_Poisson_NN_Legacy, Poisson_CNN_Legacy
 from poisson_cnn_amd.train import Adam
+from poisson_cnn_amd.graphs import GraphedInference, GraphedTrainStep
 
 
 def timeit(fn, steps=3, warmup=1):
@@ -26,7 +27,7 @@ def timeit(fn, steps=3, warmup=1):
 
 
 def main():
-    ops.set_math_mode(os.environ.get('PCNN_MATH', 'split_f16'))
+    ops.set_math_mode(os.environ.get('PCNN_MATH', 'fp32'))
     g = torch.Generator().manual_seed(0)
     H = W = 288
     # ---- dbcnn.json, batch 50
@@ -41,7 +42,13 @@ def main():
     print('Dirichlet_BC_NN_Legacy_2 (dbcnn.json, %d params): train step, %d x %dx%d: %.1f ms -> %.1f grids/s' % (model.count_params(), N, H, W, 1e3 * t, N / t))
     t = timeit(lambda: model([bc, dx, H]))
     print('Dirichlet_BC_NN_Legacy_2 inference, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, W, 1e3 * t, N / t))
-    del model
+    step = GraphedTrainStep(model, ((bc, dx), tgt))
+    t = timeit(lambda: step(((bc, dx), tgt)), steps=10)
+    print('Dirichlet_BC_NN_Legacy_2 train step as ONE hipGraph replay + eager Adam, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, W, 1e3 * t, N / t))
+    inf = GraphedInference(model, [bc, dx, H])
+    t = timeit(lambda: inf([bc, dx, H]), steps=10)
+    print('Dirichlet_BC_NN_Legacy_2 inference as ONE hipGraph replay, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, W, 1e3 * t, N / t))
+    del model, step, inf
     # ---- pcnn_end_to_end.json, batch 5
     cfg = configs.pcnn_end_to_end()
     N = cfg['dataset']['batch_size']
@@ -56,6 +63,12 @@ def main():
     print('Poisson_CNN_Legacy (pcnn_end_to_end.json, %d params): train step, %d x %dx%d: %.1f ms -> %.1f grids/s' % (model.count_params(), N, H, W, 1e3 * t, N / t))
     t = timeit(lambda: model(inp))
     print('Poisson_CNN_Legacy inference, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, W, 1e3 * t, N / t))
+    step = GraphedTrainStep(model, (inp, tgt))
+    t = timeit(lambda: step((inp, tgt)), steps=10)
+    print('Poisson_CNN_Legacy train step as ONE hipGraph replay + eager Adam, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, W, 1e3 * t, N / t))
+    inf = GraphedInference(model, inp)
+    t = timeit(lambda: inf(inp), steps=10)
+    print('Poisson_CNN_Legacy inference as ONE hipGraph replay, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, W, 1e3 * t, N / t))
 
 
 if __name__ == '__main__':
