@@ -351,6 +351,11 @@ int pcnn_layernorm_fwd(pcnn_handle h, int N, int F, const float* x, const float*
 int pcnn_layernorm_bwd(pcnn_handle h, int N, int F, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dy,
                        float* dx, float* dgamma, float* dbeta);
 
+/* Row softmax of an (N, F) matrix - the 'softmax' activation of a tf.keras Dense layer (models/Dirichlet_BC_NN_Metalearning.py:69-76, its
+ * __main__ config :236-239) - and its backward dx = y (dy - sum_f dy y).  dx may alias dy. */
+int pcnn_softmax_fwd(pcnn_handle h, int N, int F, const float* x, float* y);
+int pcnn_softmax_bwd(pcnn_handle h, int N, int F, const float* y, const float* dy, float* dx);
+
 /* ---- Dirichlet_BC_NN_Legacy_2 / Poisson_CNN_Legacy (kernels in csrc/dbcnn.hip) ------------------------------ */
 /* out[n,y,0:3] = {bc[n,y], 1, cos(pi y/(L-1))}: the boundary input with its positional embeddings
  * (models/Dirichlet_BC_NN_Legacy.py:113-124,136-139); 1-D tensors are NHWC with H = 1 */

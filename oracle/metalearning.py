@@ -28,12 +28,16 @@ def hyper(p, name, dense_input, acts, use_layernorm=False):
     return kb
 
 
-def mconv(p, name, x, dense_input, k, cin, cout, acts, *, same=True, mode='CONSTANT', value=0.0, act='linear', stride=1, use_bias=True, use_layernorm=False):
+def mconv(p, name, x, dense_input, k, cin, cout, acts, *, same=True, mode='CONSTANT', value=0.0, act='linear', stride=1, use_bias=True, use_layernorm=False,
+          kh=None):
+    """kh = 1: the dimensions = 1 layer (tf.nn.conv1d, layers/metalearning_conv.py:115-116) on (N, C, 1, L) tensors - a (1, k) kernel whose padding on
+    the unit axis is [0, 0] (:103-107 with ks = 1)."""
     kb = hyper(p, name, dense_input, acts, use_layernorm)
-    nk = k * k * cin * cout
+    kh = k if kh is None else kh
+    nk = kh * k * cin * cout
     outs = []
     for n in range(x.shape[0]):
-        kern = kb[n, :nk].reshape(k, k, cin, cout)
+        kern = kb[n, :nk].reshape(kh, k, cin, cout)
         bias = kb[n, nk:] if use_bias else None
         if same:
             outs.append(T.padded_conv2d(x[n:n + 1], kern, bias, mode, value, act, stride=stride))

@@ -35,6 +35,9 @@ def activation(x, name):
         return np.tanh(x)
     if name == 'relu':
         return np.maximum(x, 0)
+    if name == 'softmax':                                   # Keras: over the last axis
+        e = np.exp(x - x.max(axis=-1, keepdims=True))
+        return e / e.sum(axis=-1, keepdims=True)
     raise ValueError(name)
 
 
@@ -47,7 +50,7 @@ def canonical_activation(name):
     for pref in ('tf.nn.', 'tf.keras.activations.', 'tf.math.'):
         if n.startswith(pref):
             n = n[len(pref):]
-    if n in ('linear', 'leaky_relu', 'tanh', 'relu'):
+    if n in ('linear', 'leaky_relu', 'tanh', 'relu', 'softmax'):
         return n
     raise ValueError('unsupported activation %r' % (name,))
 

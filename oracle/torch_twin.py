@@ -39,6 +39,8 @@ def activation(x, name):
         return torch.tanh(x)
     if name == 'relu':
         return torch.clamp_min(x, 0)
+    if name == 'softmax':                                   # Keras: over the last axis
+        return torch.softmax(x, dim=-1)
     raise ValueError(name)
 
 

@@ -537,6 +537,53 @@ __global__ void layernorm_bwd_params_kernel(int N, int F, const float* __restric
 }
 }  // namespace
 
+// ---------------------------------------------------------------- softmax over the feature axis of an (N, F) matrix
+// tf.keras activation 'softmax' of a Dense layer (the last domain-info layer of models/Dirichlet_BC_NN_Metalearning.py:69-76,236-239).
+// One wavefront per row; bwd: dx = y (dy - sum_f dy y).
+namespace {
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__global__ __launch_bounds__(64) void softmax_fwd_kernel(int F, const float* __restrict__ x, float* __restrict__ y) {
+  const float* xr = x + (int64_t)blockIdx.x * F;
+  float* yr = y + (int64_t)blockIdx.x * F;
+  float m = -INFINITY;
+  for (int f = threadIdx.x; f < F; f += 64) m = fmaxf(m, xr[f]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int f = threadIdx.x; f < F; f += 64) s += expf(xr[f] - m);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int f = threadIdx.x; f < F; f += 64) yr[f] = expf(xr[f] - m) * inv;
+}
+__global__ __launch_bounds__(64) void softmax_bwd_kernel(int F, const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx) {
+  const int64_t base = (int64_t)blockIdx.x * F;
+  float s = 0.f;
+  for (int f = threadIdx.x; f < F; f += 64) s += dy[base + f] * y[base + f];
+  s = wave_sum(s);
+  for (int f = threadIdx.x; f < F; f += 64) dx[base + f] = y[base + f] * (dy[base + f] - s);
+}
+}  // namespace
+
+extern "C" int pcnn_softmax_fwd(pcnn_handle h, int N, int F, const float* x, float* y) {
+  PCNN_REQUIRE(h, h && x && y && N >= 1 && F >= 1, "pcnn_softmax_fwd: bad argument");
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(N), dim3(64), 0, h->stream, F, x, y);
+  PCNN_CHECK_LAUNCH(h, "pcnn_softmax_fwd");
+  return 0;
+}
+
+extern "C" int pcnn_softmax_bwd(pcnn_handle h, int N, int F, const float* y, const float* dy, float* dx) {
+  PCNN_REQUIRE(h, h && y && dy && dx && N >= 1 && F >= 1, "pcnn_softmax_bwd: bad argument");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(N), dim3(64), 0, h->stream, F, y, dy, dx);
+  PCNN_CHECK_LAUNCH(h, "pcnn_softmax_bwd");
+  return 0;
+}
+
 extern "C" int pcnn_layernorm_fwd(pcnn_handle h, int N, int F, const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
                                   float* rstd) {
   PCNN_REQUIRE(h, h && x && gamma && beta && y && mean && rstd && N >= 1 && F >= 1, "pcnn_layernorm_fwd: bad argument");

@@ -2,7 +2,7 @@
 
     from poisson_cnn_amd.keras_layers import (Conv2D, apply_advanced_padding_and_call_conv_layer, resnet, bottleneck_block_multilinearupsample,
                                               bottleneck_block_deconvupsample, deconvupscale, Upsample, Scaling, SpatialPyramidPool,
-                                              JacobiIterationLayer)
+                                              JacobiIterationLayer, MergeWithAttention)
 
 Every class takes the reference's constructor kwargs (strings such as "tf.nn.leaky_relu" are accepted for activations), builds lazily on
 its first call (own parameter bucket, Keras-default initialisers), and is called as `layer(inputs)` with the reference's input lists:
@@ -12,6 +12,7 @@ its first call (own parameter bucket, Keras-default initialisers), and is called
     Scaling([x_to_scale, other])                      layers/Scaling.py:48-49
     SpatialPyramidPool(x)                             layers/SpatialPyramidPool.py:51
     JacobiIterationLayer([guess, rhs, dx])            layers/JacobiIterationLayer.py:57
+    MergeWithAttention([x_0, ..., x_{n-1}])           layers/MergeWithAttention.py:30
     resnet(x)                                         blocks/resnet.py:29
     bottleneck_block_multilinearupsample([x, domain_sizes]),  bottleneck_block_deconvupsample(x)      blocks/bottleneck_block.py:70,100
 
@@ -453,6 +454,54 @@ class Scaling(_Layer):
         d = self.layer.backward(self._in(dy))
         self._post_backward()
         return self._out(d)
+
+
+class MergeWithAttention(_Layer):
+    """layers/MergeWithAttention.py:4-33: a list of n same-shape tensors -> sum_n x_n * sm[n, c] with the trainable attention_weights (n, C),
+    sm = exp(w) / sum(exp(w)) normalised over ALL n*C entries (:31), 'uniform' initialiser (:27).  Built on the first call from the input list,
+    or at construction when n_channels and n_inputs are both given (:12-19)."""
+
+    def __init__(self, data_format='channels_first', n_channels=None, n_inputs=None, device=None, seed=0):
+        super().__init__(data_format, device, seed)
+        if (n_channels is None) != (n_inputs is None):
+            raise ValueError('Both n_channels and n_inputs must be None, or both must be an integer value')
+        if n_channels is not None:
+            self._build(int(n_inputs), int(n_channels))
+
+    def _build(self, n, C):
+        self._begin_build()
+        self.store.add('attention_weights', (n, C), 'uniform')
+        self._end_build()
+        self.n, self.C = n, C
+        self._zero = torch.zeros(C, dtype=torch.float32, device=self.device)
+
+    def _softmax(self):
+        e = torch.exp(self.store.w['attention_weights'])
+        return (e / e.sum()).contiguous()
+
+    def call(self, inputs, training=False):
+        xs = [self._in(x) for x in inputs]
+        if not self.built:
+            self._build(len(xs), xs[0].shape[-1])
+        if len(xs) != self.n or any(tuple(x.shape) != tuple(xs[0].shape) for x in xs) or xs[0].shape[-1] != self.C:
+            raise ValueError('MergeWithAttention was built for %d inputs of %d channels and needs same-shape inputs' % (self.n, self.C))
+        sm = self._softmax()
+        out = ops.channel_affine(xs[0], sm[0], self._zero)
+        for i in range(1, self.n):
+            ops.channel_affine(xs[i], sm[i], self._zero, residual=out, out=out)
+        self._saved = (xs, sm) if training else None
+        return self._out(out)
+
+    def backward(self, dy):
+        xs, sm = self._saved
+        dy = self._in(dy)
+        dsm = torch.empty_like(sm)
+        dxs = []
+        for i in range(self.n):
+            dxs.append(self._out(ops.channel_affine(dy, sm[i], self._zero)))
+            ops.epilogue_bwd(dy, xs[i], s_dy_a=dsm[i], ws=self.ctx.ws)      # dsm[i, c] = sum dy * x_i
+        self.store.g['attention_weights'].copy_(sm * (dsm - (dsm * sm).sum()))   # softmax over the whole (n, C) table
+        return dxs
 
 
 class JacobiIterationLayer(_Layer):

@@ -101,6 +101,8 @@ class ParamStore:
                 v = np.zeros(shape, dtype=np.float32)
             elif init == 'ones':
                 v = np.ones(shape, dtype=np.float32)
+            elif init == 'uniform':                                  # Keras' 'uniform' = RandomUniform(-0.05, 0.05)
+                v = rng.uniform(-0.05, 0.05, size=shape).astype(np.float32)
             else:
                 raise ValueError(init)
             self.w[name].copy_(torch.from_numpy(v))
@@ -478,10 +480,13 @@ class bottleneck_block_multilinearupsample(_bottleneck_base):
 # ----------------------------------------------------------------------------- dense / scaling / jacobi
 class Dense:
     """tf.keras.layers.Dense.  use_bias=False allocates no bias (the metalearning hyper-networks pass their `use_bias` into every Dense layer,
-    layers/metalearning_conv.py:113,128)."""
+    layers/metalearning_conv.py:113,128).  activation 'softmax' = the linear layer followed by the row-softmax kernel."""
 
     def __init__(self, store, name, din, units, activation='linear', use_bias=True):
-        self.store, self.name, self.act = store, name, canonical_activation(activation)
+        self.store, self.name, self.act = store, name, canonical_activation(activation, dense=True)
+        self.softmax = self.act == 'softmax'
+        if self.softmax:
+            self.act = 'linear'
         self.use_bias = bool(use_bias)
         store.add(name + '/kernel', (din, units), 'glorot')
         if self.use_bias:
@@ -489,6 +494,8 @@ class Dense:
 
     def forward(self, x, training=True):
         y = ops.dense_fwd(x, self.store.w[self.name + '/kernel'], self.store.w[self.name + '/bias'] if self.use_bias else None, self.act)
+        if self.softmax:
+            y = ops.softmax_fwd(y)
         self.saved = (x, y) if training else None
         return y
 
@@ -501,7 +508,29 @@ class Dense:
         if self.use_bias:
             db = g[self.name + '/bias']
             db.zero_()
+        if self.softmax:
+            dy = ops.softmax_bwd(y, dy.contiguous())
         return ops.dense_bwd(x, self.store.w[self.name + '/kernel'], y, dy, self.act, g[self.name + '/kernel'], db, need_dx)
+
+
+class LayerNormalization:
+    """tf.keras.layers.LayerNormalization() between Dense layers (axis -1, epsilon 1e-3; models/Dirichlet_BC_NN_Metalearning.py:73-75)."""
+
+    def __init__(self, store, name, features):
+        self.store, self.name = store, name
+        store.add(name + '/gamma', (features,), 'ones')
+        store.add(name + '/beta', (features,), 'zeros')
+
+    def forward(self, x, training=True):
+        y, st = ops.layernorm_fwd(x, self.store.w[self.name + '/gamma'], self.store.w[self.name + '/beta'])
+        self.saved = (x, st) if training else None
+        return y
+
+    def backward(self, dy, need_dx=True):
+        x, st = self.saved
+        self.saved = None
+        g = self.store.g
+        return ops.layernorm_bwd(x, self.store.w[self.name + '/gamma'], st, dy.contiguous(), g[self.name + '/gamma'], g[self.name + '/beta'])
 
 
 class Scaling:

@@ -150,9 +150,12 @@ class metalearning_conv(_Hyper):
         return (self.k // 2, self.k // 2 - (1 - self.k % 2)) if self.same else (0, 0)
 
     def forward(self, x, dense_input, training=True):
-        """x (N,H,W,Cin) NHWC - (N,L,Cin) for a 1-D layer -, dense_input (N,F)."""
-        if self.ndims == 1:
+        """x (N,H,W,Cin) NHWC - (N,L,Cin) or (N,1,L,Cin) for a 1-D layer, the result has the same rank -, dense_input (N,F)."""
+        self._squeeze = self.ndims == 1 and x.dim() == 3
+        if self._squeeze:
             x = x.unsqueeze(1)
+        if self.ndims == 1 and x.shape[1] != 1:
+            raise ValueError('a 1-D metalearning_conv takes (N,L,C) or (N,1,L,C) tensors')
         if not self.built:
             self.build(x.shape[3], dense_input.shape[1])
         N, H, W, _ = x.shape
@@ -169,13 +172,13 @@ class metalearning_conv(_Hyper):
         self.saved = (x, kb, y) if training else None
         if self.stride > 1:
             y = ops.subsample(y, self.stride)
-        return y.squeeze(1) if self.ndims == 1 else y
+        return y.squeeze(1) if self._squeeze else y
 
     def backward(self, dy, need_dx=True):
         """Returns (dx, d_dense_input); parameter gradients of the hyper-network go to store.g."""
         x, kb, y = self.saved
         self.saved = None
-        if self.ndims == 1:
+        if self._squeeze:
             dy = dy.unsqueeze(1)
         if self.stride > 1:
             dy = ops.subsample_bwd(dy, (y.shape[1], y.shape[2]), self.stride)
@@ -202,7 +205,7 @@ class metalearning_conv(_Hyper):
             else:
                 gp = ops.grouped_conv2d_fwd(dz, kb, wshape, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + pty + pby, W + pt + pb), flip_transpose=True)
                 ops.pad_fold_bwd(gp, (H, W), ((pty, pby), (pt, pb)), mode, out=dx)
-        if need_dx and self.ndims == 1:
+        if need_dx and self._squeeze:
             dx = dx.squeeze(1)
         return dx, self._emit_backward(dkb)
 
@@ -366,6 +369,8 @@ class metalearning_resnet(_Block):
 
     def __call__(self, inputs, training=False):
         x, dense_input = inputs
+        if self.convs[0].ndims == 1:            # dimensions = 1: (N, C, L) -> (N, 1, L, C) and back
+            return self.forward(x.permute(0, 2, 1).unsqueeze(1).contiguous(), dense_input.contiguous(), training=training).squeeze(1).permute(0, 2, 1)
         return self.forward(x.permute(0, 2, 3, 1).contiguous(), dense_input.contiguous(), training=training).permute(0, 3, 1, 2)
 
 

@@ -500,6 +500,20 @@ def layernorm_bwd(x, gamma, stats, dy, dgamma, dbeta):
     return dx
 
 
+def softmax_fwd(x):
+    N, F = x.shape
+    y = empty((N, F), x.device)
+    handle().call('pcnn_softmax_fwd', c_int(N), c_int(F), _p(x), _p(y))
+    return y
+
+
+def softmax_bwd(y, dy):
+    N, F = y.shape
+    dx = empty((N, F), y.device)
+    handle().call('pcnn_softmax_bwd', c_int(N), c_int(F), _p(y), _p(dy), _p(dx))
+    return dx
+
+
 def spp_max_fwd(x, bins):
     N, H, W, C = x.shape
     assert x.is_contiguous()

@@ -9,10 +9,15 @@ _ACTIVATIONS = {
 }
 
 
-def canonical_activation(a):
+_SOFTMAX = ('softmax', 'tf.nn.softmax', 'tf.keras.activations.softmax')
+
+
+def canonical_activation(a, dense=False):
     """Name -> kernel activation enum name.  Replaces the reference's eval() of "tf.nn.*" strings
-    (utils/convert_tf_object_names.py:13-18) with a lookup table."""
+    (utils/convert_tf_object_names.py:13-18) with a lookup table.  'softmax' exists for Dense layers only (dense=True)."""
     key = a.lower() if isinstance(a, str) else a
+    if dense and key in _SOFTMAX:
+        return 'softmax'
     if key not in _ACTIVATIONS:
         raise ValueError('unsupported activation %r (supported: %s)' % (a, sorted(k for k in _ACTIVATIONS if k)))
     return _ACTIVATIONS[key]
@@ -30,7 +35,7 @@ def convert_tf_object_names(x):
 
 def _check(item):
     if isinstance(item, str) and 'tf.' in item:
-        canonical_activation(item)   # raises for anything this build cannot map
+        canonical_activation(item, dense=True)   # raises for anything this build cannot map
     return item
 
 
