@@ -238,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void spec64_fwd_kernel(FwdParams p) {
         const int m = 8 * (r >> 2) + 4 * hv + (r & 3);
         int r0 = base + 2 * m, r1 = r0 + 64;
         if (jj == 0 && special) { r0 = ry_row(h, m); r1 = 64 + r0; }      // the two real columns: half-complex rows of fx = 0 and fx = 32
-        out[(unsigned)(r0 * RS + cv)] = Z[jj][0][r];
-        out[(unsigned)(r1 * RS + cv)] = Z[jj][1][r];
+        __builtin_nontemporal_store(Z[jj][0][r], &out[(unsigned)(r0 * RS + cv)]);      // streamed once, read by the next kernel: see spectral_conv.hip
+        __builtin_nontemporal_store(Z[jj][1][r], &out[(unsigned)(r1 * RS + cv)]);
       }
       Z[jj][0] = zero16(); Z[jj][1] = zero16();
     }
