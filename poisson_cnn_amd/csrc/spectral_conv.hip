@@ -797,7 +797,10 @@ int pick_tile(pcnn_handle h, const pcnn_conv_desc* d) {
   if (forced == 32 || !can64) return 32;
   if (forced == 64) return 64;
   const int Vy = 65 - d->kh, Vx = 65 - d->kw;
-  return (d->kh >= 13 && d->kw >= 13 && pcnn_cdiv(d->Ho, Vy) * pcnn_cdiv(d->Wo, Vx) >= 36) ? 64 : 32;
+  const int tiles = pcnn_cdiv(d->Ho, Vy) * pcnn_cdiv(d->Wo, Vx);
+  // 11 and 12 taps: ahead only on large images (1024^2, 16->32: 2.77 -> 2.66 ms forward, 4.48 -> 4.30 fused backward; 512^2: 0.80 -> 0.93)
+  if (d->kh >= 11 && d->kw >= 11 && d->kh < 13 && d->kw < 13) return tiles >= 256 ? 64 : 32;
+  return (d->kh >= 13 && d->kw >= 13 && tiles >= 36) ? 64 : 32;
 }
 
 }  // namespace

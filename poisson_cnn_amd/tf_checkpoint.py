@@ -417,6 +417,42 @@ def _dbcnn_paths(model):
     return m
 
 
+def _dbcnn_meta_paths(model):
+    """Dirichlet_BC_NN_Metalearning (models/Dirichlet_BC_NN_Metalearning.py:43-93): self.boundary_convolutions = [metalearning_conv, metalearning_resnet]
+    per stage, self.domain_info_dense_layers = [Dense, (LayerNormalization, Dense)...], self.final_convolutions = [metalearning_conv,
+    metalearning_resnet] per stage followed by the regular convolutions.  A metalearning_conv keeps its hyper-network in self.dense_layers
+    (layers/metalearning_conv.py:127-129: the Dense layers, then the optional LayerNormalization); a metalearning_resnet is conv0 / conv1 / conv2 /
+    batchnorm0 / batchnorm1 (blocks/metalearning_resnet.py:10-25)."""
+    nmeta = len(model.final_meta)
+
+    def hyper(q):                                       # [..., 'dense<i>' | 'layernorm', var] -> dense_layers/<i>/<var>
+        if q[0] == 'layernorm':
+            ndense = 1 + max(int(n.split('/')[-2][5:]) for n in model.weight_names if n.startswith(prefix) and n.split('/')[-2].startswith('dense'))
+            return 'dense_layers/%d/%s' % (ndense, q[1])
+        return 'dense_layers/%s/%s' % (q[0][5:], q[1])
+
+    m = {}
+    for n in model.weight_names:
+        q = n.split('/')
+        if q[0] in ('bc', 'final') and q[1].startswith('stage'):
+            k = int(q[1][5:])
+            top = 'boundary_convolutions' if q[0] == 'bc' else 'final_convolutions'
+            if q[2] == 'conv':
+                prefix = '/'.join(q[:3]) + '/'
+                m[n] = '%s/%d/%s' % (top, 2 * k, hyper(q[3:]))
+            elif q[3].startswith('bn'):
+                m[n] = '%s/%d/batchnorm%s/%s' % (top, 2 * k + 1, q[3][2:], q[4])
+            else:
+                prefix = '/'.join(q[:4]) + '/'
+                m[n] = '%s/%d/%s/%s' % (top, 2 * k + 1, q[3], hyper(q[4:]))
+        elif q[0] == 'final':
+            m[n] = 'final_convolutions/%d/%s' % (nmeta + int(q[1][3:]), q[2])
+        elif q[0] == 'mlp':
+            k = int(q[1][5:] if q[1].startswith('dense') else q[1][2:])
+            m[n] = 'domain_info_dense_layers/%d/%s' % (2 * k if q[1].startswith('dense') else 2 * k - 1, q[2])
+    return m
+
+
 def keras_object_paths(model):
     """Our parameter name -> the reference model's Keras object path: Homogeneous_Poisson_NN_Legacy (attribute names of
     models/Homogeneous_Poisson_NN_Legacy.py:41-115), Dirichlet_BC_NN_Legacy_2, and Poisson_CNN_Legacy (self.hpnn / self.dbcnn,
@@ -428,15 +464,16 @@ def keras_object_paths(model):
         m = {'hpnn/' + n: 'hpnn/' + v for n, v in keras_object_paths(model.hpnn).items()}
         m.update({'dbcnn/' + n: 'dbcnn/' + v for n, v in keras_object_paths(model.dbcnn).items()})
         return m
-    if isinstance(model, Dirichlet_BC_NN_Legacy_2):
-        m = _dbcnn_paths(model)
+    from .dbcnn_models import Dirichlet_BC_NN_Metalearning
+    if isinstance(model, (Dirichlet_BC_NN_Legacy_2, Dirichlet_BC_NN_Metalearning)):
+        m = _dbcnn_paths(model) if isinstance(model, Dirichlet_BC_NN_Legacy_2) else _dbcnn_meta_paths(model)
         missing = [n for n in model.weight_names if n not in m]
         if missing or len(set(m.values())) != len(m):
             raise RuntimeError('no unique Keras object path for %s' % (missing[:5],))
         return m
     if not isinstance(model, Homogeneous_Poisson_NN_Legacy):
-        raise NotImplementedError('TensorFlow-format checkpoints are mapped for Homogeneous_Poisson_NN_Legacy, Dirichlet_BC_NN_Legacy_2 and Poisson_CNN_Legacy - '
-                                  'the models the reference can construct and train; the two train/hpnn_train.py classes raise NameError in the '
+        raise NotImplementedError('TensorFlow-format checkpoints are mapped for Homogeneous_Poisson_NN_Legacy, Dirichlet_BC_NN_Legacy_2, Poisson_CNN_Legacy and '
+                                  'Dirichlet_BC_NN_Metalearning - the models the reference can construct; the two train/hpnn_train.py classes raise NameError in the '
                                   'reference, so no TensorFlow checkpoint of them can exist (flat .npz works for every model)')
     names = model.weight_names
     m = {}
