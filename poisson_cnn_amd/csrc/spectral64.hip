@@ -21,6 +21,14 @@
 #include <algorithm>
 #include <stdlib.h>
 
+// Removal studies (what a kernel costs without its loads / stores) exist only in a diagnostic build: -DPCNN_REMOVAL_STUDY, bits from the
+// environment variable PCNN_DBG64 (forward: 1 no stores, 2 no loads; inverse: 4 no epilogue, 8 no loads).  The shipped library compiles them out.
+#ifdef PCNN_REMOVAL_STUDY
+#define DBG64(flags, bit) ((flags) & (bit))
+#else
+#define DBG64(flags, bit) 0
+#endif
+
 namespace pcnn_spec {
 
 namespace {
@@ -78,7 +86,7 @@ __device__ __forceinline__ int pad_sel(int i, int n, int mode) {
 template <bool MASKED>
 __device__ __forceinline__ void load_row64(const FwdParams& p, const Ctx64& cx, int y, int half, float (&lo)[16], float (&hi)[16]) {
   if (MASKED && y >= cx.ylim) return;
-  if (p.cpt & 2) return;                                    // removal study (PCNN_DBG64): no window loads
+  if (DBG64(p.cpt, 2)) return;                              // removal study: no window loads
   const int sy = pad_sel(cx.wy0 + y, p.H, p.pad_mode);
   const float* row = cx.img + (int64_t)sy * p.W * p.ld;
   if (cx.fast) {
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void spec64_fwd_kernel(FwdParams p) {
       const int base = 128 + 128 * (fx - 1) + h;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if ((p.cpt & 1) && r > 0) continue;                      // removal study (PCNN_DBG64 bit 0): one store instead of sixteen
+        if (DBG64(p.cpt, 1) && r > 0) continue;                  // removal study: one store instead of sixteen
         const int m = 8 * (r >> 2) + 4 * hv + (r & 3);
         int r0 = base + 2 * m, r1 = r0 + 64;
         if (jj == 0 && special) { r0 = ry_row(h, m); r1 = 64 + r0; }      // the two real columns: half-complex rows of fx = 0 and fx = 32
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
   auto load_pair = [&](const InvItem& it, int tau, float (&z)[32]) {
     int g4v = lane >> 4, cv = c;
     asm volatile("" : "+v"(g4v), "+v"(cv));                   // opaque: the row offsets are formed per call, not hoisted out of the item loop
-    if (p.cpt & 2) return;                                     // removal study (PCNN_DBG64): no spectrum loads
+    if (DBG64(p.cpt, 2)) return;                               // removal study: no spectrum loads
     const int iq = cv & 3;
     const float* in = p.sp + sp_item(it.tg, ROWS) + 16 * it.q + (cv & ~3);
     const int j = 4 * tau + s;
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
           const int y = wave + 8 * i;
-          if (y < ib.vy && nv > 0 && !(p.cpt & 1)) {             // (p.cpt & 1: removal study, PCNN_DBG64 - no epilogue)
+          if (y < ib.vy && nv > 0 && !DBG64(p.cpt, 1)) {         // (removal study: no epilogue)
             const int64_t rowpix = p.flip ? ((int64_t)n * p.Ho + (p.Ho - 1 - y0 - y)) * p.Wo + (p.Wo - 1 - x0) : ((int64_t)n * p.Ho + y0 + y) * p.Wo + x0;
             float* yrow = p.y + rowpix * p.ldy;
             float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
@@ -566,7 +574,11 @@ void build_tables64(float* tab, int* slots) {
     for (int fy = 0; fy < T; ++fy) put(2 * T + 2 * T * (fx - 1) + fy, 2 * T + 2 * T * (fx - 1) + T + fy, 0);
 }
 
+#ifdef PCNN_REMOVAL_STUDY
 static int dbg64() { static const int v = getenv("PCNN_DBG64") ? atoi(getenv("PCNN_DBG64")) : 0; return v; }
+#else
+static int dbg64() { return 0; }
+#endif
 
 void launch_fwd64(pcnn_handle h, FwdParams p, int ntile) {
   p.ntile = ntile;
