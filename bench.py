@@ -18,11 +18,19 @@ over ranks:
   * `split_f16` block: the opt-in 3 x fp16 split mode, timed the same way in the same run, with
     `accuracy_vs_fp32`: forward output and flat gradient of THIS benchmark batch in split mode against fp32 mode (rel-L2 and
     max componentwise error), measured before the timed regions.
-`roofline` describes the dominant kernel (fused pad+conv forward / data-gradient): algorithmic FLOP of all its launches in the timed
-region / their summed duration from HIP events on the launch stream.  `roofline.hbm_bound` is the north star's "conv forward vs HBM
-roofline" figure: the conv launches whose arithmetic intensity is below the fp32 ridge (3x3 tail, <= 8 channels), algorithmic bytes / time.
-`roofline.traffic` comes from separate `rocprofv3 --pmc` passes (committed summary, tools/pmc_summary.py) and is reported only when the
-summary's source stamp matches the kernel sources of this tree; otherwise null with the reason in `traffic_source`.
+`roofline` (bound "hbm") describes ALL convolution launches of the timed steps - forward, data gradient, weight gradient; the tiled spectral
+route dominates them and is bound by the tile spectra it streams, not by the matrix pipes: `achieved` = HBM bytes the convolution kernels of one
+step really move (`traffic`: 2 x FETCH_SIZE + WRITE_SIZE from separate `rocprofv3 --pmc` passes, committed as profiles/r03_<workload>_pmc_summary_
+<mode>.json by tools/collect_pmc.sh, used only when the summary's source stamp matches the kernel sources of this tree - otherwise the
+algorithmic bytes, with the reason in `traffic_source`) / the summed duration of those launches in THIS run (HIP events on the launch stream);
+`frac` = achieved / 8 TB/s; `mfma_busy` the matrix-pipe busy fraction of the same kernels; `kernels` the per-kernel table of the stamped summary
+(launches per step, ms per step from the rocprofv3 --kernel-trace --stats CSV, MB per launch, TB/s, fraction).  `direct_conv_equivalent` is the
+direct convolution's FLOP over the same time - a speed-up measure, not a roofline fraction.  `roofline.hbm_bound` is the north star's "conv
+forward vs HBM roofline" figure: the conv launches whose arithmetic intensity is below the fp32 ridge (3x3 tail, <= 8 channels), algorithmic
+bytes / time, with the transposed-convolution and resize forward kernels beside it.
+The default c4 run appends a `c3` block (32 x 512^2, fp32: ms/step, grids/s, the same roofline figures) so that both halves of BASELINE.json's
+metric are timed by one command (--no-c3 skips it); `rank_ms_per_step` lists every rank's own step time, `collective_ms` the gradient
+all-reduce timed on its own (N > 1).
 `cpu_baseline` times the oracle's torch-CPU twin of the same graph (fp32, host cores) on one 512^2 grid - a stand-in for the reference's
 TF-CPU path, which cannot run here.  `dataset` is the on-device 512^2 FD reference-solution generator next to its scipy stand-in.
 """

@@ -10,7 +10,11 @@
  *    plus an explicit channel stride `ld*` (floats between consecutive pixels), so a kernel can read/write a
  *    channel slice of a wider buffer (this is how tf.concat(axis=1), models/Homogeneous_Poisson_NN_Legacy.py:224,
  *    is realised without a copy).
- *  - The caller owns every buffer.  The library owns only its handle (stream + last error string).
+ *  - The caller owns every tensor and every workspace that appears as an argument.  The handle owns three scratch regions it grows on demand
+ *    (hipMalloc on first use, freed by pcnn_destroy): the packed-filter scratch of the direct convolutions (KBs), the x-interpolated rows of the
+ *    two-pass resize, and the SPECTRAL WORKSPACE of the tiled spectral convolutions - tables, the filter spectrum and the tile spectra of the
+ *    launch in flight, up to ~14 GB for an 8 x 1024^2 x 32-channel layer.  pcnn_set_workspace_limit caps the latter (the route then runs in
+ *    smaller tile chunks); growing it synchronises the stream, so a training loop reaches its high-water mark in the first step.
  *  - Every call is asynchronous on the handle's stream and returns 0 on success, non-zero on error
  *    (pcnn_last_error(handle) gives the message).  No exceptions cross the boundary.
  *  - One handle per (thread, device, stream).
@@ -75,8 +79,9 @@ int pcnn_get_math_mode(pcnn_handle h);
 enum { PCNN_SPECTRAL_AUTO = -1, PCNN_SPECTRAL_OFF = 0, PCNN_SPECTRAL_FORCE = 1 };
 int pcnn_set_spectral_mode(pcnn_handle h, int mode);
 int pcnn_get_spectral_mode(pcnn_handle h);
-/* Tile size of the spectral route: 0 (default; environment PCNN_SPEC_T) = per layer - 64 x 64 tiles for 11..15 taps on images of >= 36 such
- * tiles, 32 x 32 otherwise; 32 / 64 = that size wherever the layer allows it (64: 9..15 taps, more than 16 channels on one side). */
+/* Tile size of the spectral route: 0 (default; environment PCNN_SPEC_T) = per layer - 64 x 64 tiles for 13..15 taps on images of >= 36 such
+ * tiles and for 11..12 taps on images of >= 256 such tiles, 32 x 32 otherwise (decided on ONE image: a sample's arithmetic never depends on
+ * its batch neighbours); 32 / 64 = that size wherever the layer allows it (64: 9..15 taps, more than 16 channels on one side). */
 int pcnn_set_spectral_tile(pcnn_handle h, int tile);
 int pcnn_get_spectral_tile(pcnn_handle h);
 /* The ONE buffer a handle owns besides small scratch: the spectral workspace (tile spectra of the layer in flight, mixing matrices,
