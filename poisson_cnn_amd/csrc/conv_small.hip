@@ -20,6 +20,10 @@ bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d);
 bool pcnn_conv_small_wgrad_eligible(const pcnn_conv_desc* d);
 size_t pcnn_conv_small_wgrad_workspace(const pcnn_conv_desc* d);
 
+#ifndef PCNN_SMALL_STUDY
+#define PCNN_SMALL_STUDY 0       // diagnostic builds only: 1 no FMA loop, 2 no global loads in the tile staging, 4 one epilogue store instead of all
+#endif
+
 namespace {
 
 constexpr int STH = 8, STW = 32;                       // output tile: 8 rows x 32 columns = 256 pixels = 256 threads
@@ -81,7 +85,8 @@ __device__ __forceinline__ void stage_tile_batched(float* __restrict__ lds, cons
     const int sy = pad_index_sel(y0 + r - pt, H, pad_mode), sx = pad_index_sel(x0 + c - pl, W, pad_mode);
     const bool ok = u < TOTAL && sy >= 0 && sx >= 0;
     const int64_t idx = ok ? ((int64_t)sy * W + sx) * ldx + 4 * q : 0;
-    v[i] = *reinterpret_cast<const f32x4*>(xin + idx);
+    if (PCNN_SMALL_STUDY & 2) v[i] = (f32x4){(float)u, 1.f, 2.f, 3.f};
+    else v[i] = *reinterpret_cast<const f32x4*>(xin + idx);
     okm |= ok ? (1u << i) : 0u;
   }
   const f32x4 padv = {pad_value, pad_value, pad_value, pad_value};
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, (CI * CO <= 64 ? 8 : 4)) void conv_small_fwd_k
   for (int o = 0; o < CO; ++o) acc[o] = 0.f;
   const float* wp = p.wp;                                 // [K*K][CI][CO], zero padded: uniform addresses -> scalar loads
 #pragma unroll 1
-  for (int i = 0; i < K; ++i)                                // filter rows stay a loop: K*K*CI*CO unrolled FMAs would not fit the register file
+  for (int i = 0; i < ((PCNN_SMALL_STUDY & 1) ? 0 : K); ++i)  // filter rows stay a loop: K*K*CI*CO unrolled FMAs would not fit the register file
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const float* px = lds + ((r + i) * TC + (c + j)) * CIS;
