@@ -518,15 +518,21 @@ __global__ __launch_bounds__(256, 4) void spec_mix_lds_kernel(MixParams p) {
 // M_f from the filter spectrum Wsp[ci * gout + go][row][co % 32] (conj: correlation).
 // M[slot][go][gi][k = 32 part_in + ci % 32][n = 32 part_out + co % 32]
 // cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and M_f is block diagonal - a tile's channels mix only among themselves.
-__global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout, int cpt, int rows) {
-  const int64_t total = (int64_t)(rows / 2) * gout * gin * 64 * 64;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int nn = i & 63; int64_t r = i >> 6; const int k = r & 63; r >>= 6; const int gi = r % gin; r /= gin; const int go = r % gout; const int slot = r / gout;
+// One workgroup per 64 x 64 matrix (blockIdx = (slot, go, gi)): thread t writes elements t, t + 256, ... - row k = element / 64 is uniform per
+// wave half, so the filter-spectrum reads are whole 128-byte channel rows and no index needs a run-time division (the grid-stride form took
+// 15 us per layer, twice per layer and step).
+__global__ __launch_bounds__(256) void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout, int cpt, int rows) {
+  const int slot = blockIdx.x, go = blockIdx.y, gi = blockIdx.z;
+  const int4 sl = slots[slot];
+  float* out = M + (((int64_t)slot * gout + go) * gin + gi) * 4096;
+#pragma unroll 4
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    const int nn = e & 63, k = e >> 6;
     const int pin = k >> 5, pout = nn >> 5;
-    const int cil = (k & 31) % cpt, co = (nn & 31) % cpt;
-    const bool same_tile = (k & 31) / cpt == (nn & 31) / cpt;
+    const int kc = k & 31, nc = nn & 31;
+    const int cil = kc % cpt, co = nc % cpt;                  // cpt is a power of two >= 4
+    const bool same_tile = kc / cpt == nc / cpt;
     const int ci = gi * 32 + cil;
-    const int4 sl = slots[slot];
     float v = 0.f;
     if (ci < Cin && same_tile) {
       const float* wg = wsp + pcnn_spec::sp_item(ci * gout + go, rows) + co;
@@ -534,7 +540,7 @@ __global__ void spec_build_mix_kernel(const float* __restrict__ wsp, const int4*
       if (sl.z == 1) v = (pin == 0 && pout == 0) ? wr : ((pin == 1 && pout == 1) ? wi : 0.f);     // two real frequencies packed in one slot
       else v = pin == pout ? wr : (pin == 0 ? -wi : wi);                                          // [[Hr, Hi], [-Hi, Hr]], H = conj(W)
     }
-    M[i] = v;
+    out[e] = v;
   }
 }
 
@@ -598,11 +604,12 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
 // C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
 // Output: spectrum of a one-tile image with Cin*Cout channels, group = ci, lane = co.
 // cpt < 32 (tile packing): the wanted products are the 32 / cpt diagonal blocks (tile with itself); they are summed here.
-__global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin, float isign, int cpt, int rows) {
+// One workgroup per (slot, channel group): no run-time divisions, every partial-sum read a whole 128-byte row.
+__global__ __launch_bounds__(256) void spec_wcombine_kernel(const float* __restrict__ part, const int4* __restrict__ slots, float* __restrict__ csp, int S, int gin, int Cin, float isign, int cpt, int rows) {
   const int nslot = rows / 2;
-  const int64_t total = (int64_t)nslot * gin * 1024;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int e = i & 1023; int64_t r = i >> 10; const int gi = r % gin; const int slot = r / gin;
+  const int slot = blockIdx.x, gi = blockIdx.y;
+  const int4 sl = slots[slot];
+  for (int e = threadIdx.x; e < 1024; e += 256) {
     const int cil = e >> 5, co = e & 31, ci = gi * 32 + cil;
     if (ci >= Cin || cil >= cpt || co >= cpt) continue;
     float P[4] = {0.f, 0.f, 0.f, 0.f};
@@ -612,7 +619,6 @@ __global__ void spec_wcombine_kernel(const float* __restrict__ part, const int4*
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) P[qd] += b[qd * 1024];
       }
-    const int4 sl = slots[slot];
     // P[0] = Xr^T Dr, P[1] = Xi^T Dr, P[2] = Xr^T Di, P[3] = Xi^T Di
     const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : isign * (P[1] - P[2]);     // isign = -1: conj(X^) D^ instead of X^ conj(D^)
     csp[pcnn_spec::sp_item(ci, rows) + sl.x * RS + co] = cr;
@@ -856,7 +862,8 @@ FwdParams filter_params(const Geom& gm, const float* w, float* wsp, int kh, int 
   fw.x = w; fw.sp = wsp; fw.tab = gm.tab; fw.H = kh; fw.W = kw; fw.C = Cin * Cout; fw.ld = Cin * Cout; fw.groups = Cin * gout;
   fw.cstride = gout > 1 ? 32 : Cout; fw.cvalid = gout > 1 ? 32 : Cout;     // group ci * gout + go holds output channels 32 go .. 32 go + 31
   fw.tiles_x = 1; fw.tiles_y = 1; fw.tile0 = 0; fw.ntile = 1; fw.Vy = gm.T; fw.Vx = gm.T; fw.oy = 0; fw.ox = 0;
-  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = gm.T; fw.xlim = gm.T; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
+  // the filter is a kh x kw corner of its tile: the masked form of the transform skips the zero rows / columns (same sums: only zero products are dropped)
+  fw.pad_mode = PCNN_PAD_CONSTANT; fw.pad_value = 0.f; fw.ylim = kh; fw.xlim = kw; fw.ext_y = 1 << 30; fw.ext_x = 1 << 30;
   fw.pack = 1; fw.cpt = 32; fw.tgx = 1;
   return fw;
 }
@@ -895,7 +902,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   float* xs = reinterpret_cast<float*>(r); r += xs_b;
   float* ys = reinterpret_cast<float*>(r);
   launch_fwd(h, gm, filter_params(gm, w, wsp, d->kh, d->kw, d->Cin, d->Cout, gout), 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, gm.slots, Mm, d->Cin, gin, gout, cpt, rows);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(nslot, gout, gin), dim3(256), 0, h->stream, wsp, gm.slots, Mm, d->Cin, gin, gout, cpt, rows);
   PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
   FwdParams fx;
   fx.x = x; fx.sp = xs; fx.tab = gm.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
@@ -963,7 +970,7 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
     launch_fwd(h, gm, fz, nt);
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gin), dim3(256), 0, h->stream, wm);
   }
-  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, gm.slots, csp, S, gin, d->Cin, 1.0f, cpt, rows);
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gin), dim3(256), 0, h->stream, part, gm.slots, csp, S, gin, d->Cin, 1.0f, cpt, rows);
   launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 0), 1);
   PCNN_CHECK_LAUNCH(h, "spectral weight gradient");
   return 0;
@@ -1015,7 +1022,7 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   // flipped filter spectrum -> mixing matrices of the data gradient (input groups: dz's, output groups: dx's)
   PCNN_REQUIRE(h, gx == 1 || dg->Cout == 64, "pcnn_conv2d_bwd_spectral: %d input channels unsupported (<= 32 or 64)", d->Cin);
   launch_fwd(h, gm, filter_params(gm, w_flipped, wsp, d->kh, d->kw, dg->Cin, dg->Cout, gx), 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(1024), dim3(256), 0, h->stream, wsp, gm.slots, Mm, dg->Cin, gz, gx, cpt, rows);
+  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(nslot, gx, gz), dim3(256), 0, h->stream, wsp, gm.slots, Mm, dg->Cin, gz, gx, cpt, rows);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral (filter spectrum)");
   FwdParams fz;                                          // dz windows with halo: the data gradient's input transform
   fz.x = dz; fz.sp = zs; fz.tab = gm.tab; fz.H = dg->H; fz.W = dg->W; fz.C = dg->Cin; fz.ld = dg->ldx; fz.groups = gz; fz.cstride = 32; fz.cvalid = 32;
@@ -1048,7 +1055,7 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gx), dim3(256), 0, h->stream, wm);
   }
   float* csp = wsp;                                      // the filter spectrum is no longer needed
-  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(1024), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);
+  hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gx), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);
   launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 1), 1);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral");
   return 0;
