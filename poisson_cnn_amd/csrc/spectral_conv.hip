@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ per-frequency channel mixing
-struct MixParams { const float* xs; float* ys; const float* M; const int4* slots; int ntile, gin, gout, rows; };      // rows: spectrum rows per item (T*T)
+struct MixParams { const float* xs; float* ys; const float* wsp; const int4* slots; int ntile, gin, gout, rows, Cin, cpt; };   // wsp: filter spectrum; Cin: its input channels; cpt: lanes per packed tile      // rows: spectrum rows per item (T*T)
 
 // K order inside one 64-row block of M_f (one input channel group): step ks = 16 p + j pairs channel j (lanes 0-31) with channel 16 + j
 // (lanes 32-63) of part p (0: real row, 1: imaginary row) - so a lane's A operands are 16 CONSECUTIVE channels of its tile's row.
@@ -393,15 +393,29 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   const int slot = blockIdx.x, go = blockIdx.z;
   const int4 sl = p.slots[slot];
   const int rr = sl.x, ri = sl.y;
+  // M_f = [[Hr, Hi], [-Hi, Hr]], H = conj(W^), straight from the filter spectrum Wsp[ci * gout + go][row][co] (conj: correlation): this lane's
+  // 16 input channels j + 16 half of its output channel c - 32 loads of L2-resident rows.  A slot that packs two real frequencies (sl.z == 1)
+  // is block diagonal in (real row, imaginary row).  cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and M_f is block
+  // diagonal - a tile's channels mix only among themselves.  (Until round 3 a separate kernel wrote these matrices to a buffer: one more
+  // launch per convolution and 64 loads per lane here.)
   float breg[GIN][32][2];
+  {
+    const int co = c % p.cpt;
+    const bool real2 = sl.z == 1;
 #pragma unroll
-  for (int gi = 0; gi < GIN; ++gi)
+    for (int gi = 0; gi < GIN; ++gi)
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) {
-      const int k = (ks >> 4) * 32 + (ks & 15) + 16 * half;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) breg[gi][ks][nt] = p.M[((((int64_t)slot * p.gout + go) * GIN + gi) * 64 + k) * 64 + nt * 32 + c];
-    }
+      for (int j = 0; j < 16; ++j) {
+        const int kc = j + 16 * half, ci = gi * 32 + kc % p.cpt;
+        float wr = 0.f, wi = 0.f;
+        if (ci < p.Cin && kc / p.cpt == c / p.cpt) {
+          const float* wg = p.wsp + pcnn_spec::sp_item(ci * p.gout + go, p.rows) + co;
+          wr = wg[rr * RS]; wi = wg[ri * RS];
+        }
+        breg[gi][j][0] = wr;                     breg[gi][j][1] = real2 ? 0.f : -wi;          // K part 0 (real input rows)
+        breg[gi][16 + j][0] = real2 ? 0.f : wi;  breg[gi][16 + j][1] = real2 ? wi : wr;       // K part 1 (imaginary input rows)
+      }
+  }
   const int nMt = (p.ntile + 31) >> 5;
   const int mstride = gridDim.y * 4;
   auto load_a = [&](int mt, int gi, f32x4 (&a)[2][4]) {
@@ -450,98 +464,6 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   // tile's stores), so the waits for its operands do not have to cover a first pass that has no stores pending
   m_tile(mt);
   for (mt += mstride; mt < nMt; mt += mstride) m_tile(mt);
-}
-
-// The same product with M_f held in LDS (16 KB per input channel group, shared by the workgroup's four waves) instead of 64 registers per
-// lane: under 128 registers a CU holds 16 waves instead of 8, i.e. twice the operand loads in flight - the kernel is bound by the latency of
-// its 128-byte row gathers (64 KB in flight per CU cover ~4 TB/s), not by the matrix pipes (one ds_read_b32 per MFMA is far below the LDS rate).
-template <int GIN>
-__global__ __launch_bounds__(256, 4) void spec_mix_lds_kernel(MixParams p) {
-  __shared__ float Bl[GIN * 32 * 2 * 64];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
-  const int slot = blockIdx.x, go = blockIdx.z;
-  const int4 sl = p.slots[slot];
-  const int rr = sl.x, ri = sl.y;
-  for (int i = tid; i < GIN * 32 * 2 * 64; i += 256) {
-    const int l = i & 63, nt = (i >> 6) & 1, ks = (i >> 7) & 31, gi = i >> 12;
-    const int k = (ks >> 4) * 32 + (ks & 15) + 16 * (l >> 5);
-    Bl[i] = p.M[((((int64_t)slot * p.gout + go) * GIN + gi) * 64 + k) * 64 + nt * 32 + (l & 31)];
-  }
-  __syncthreads();
-  const int nMt = (p.ntile + 31) >> 5;
-  const int mstride = gridDim.y * 4;
-  auto load_a = [&](int mt, int gi, f32x4 (&a)[2][4]) {
-    const int tile = min(mt * 32 + c, p.ntile - 1);
-    const float* base = p.xs + pcnn_spec::sp_item((int64_t)tile * GIN + gi, p.rows) + 16 * half;
-#pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-      a[0][j4] = *reinterpret_cast<const f32x4*>(base + rr * RS + 4 * j4);
-      a[1][j4] = *reinterpret_cast<const f32x4*>(base + ri * RS + 4 * j4);
-    }
-  };
-  f32x4 a[2][4], an[2][4];
-  int mt = blockIdx.y * 4 + wave;
-  if (mt >= nMt) return;
-  load_a(mt, 0, a);
-  auto m_tile = [&](int mt) {
-    f32x16 acc[2] = {zero16(), zero16()};
-#pragma unroll
-    for (int gi = 0; gi < GIN; ++gi) {
-      if (gi + 1 < GIN) load_a(mt, gi + 1, an);
-      else if (mt + mstride < nMt) load_a(mt + mstride, 0, an);
-#pragma unroll
-      for (int ks = 0; ks < 32; ++ks) {
-        const float av = a[ks >> 4][(ks & 15) >> 2][ks & 3];
-        acc[0] = mfma(av, Bl[((gi * 32 + ks) * 2 + 0) * 64 + lane], acc[0]);
-        acc[1] = mfma(av, Bl[((gi * 32 + ks) * 2 + 1) * 64 + lane], acc[1]);
-        if ((ks & 3) == 3) asm volatile("" ::: "memory");           // keeps the LDS reads in groups of eight: unfenced, all 64 are hoisted (spills)
-      }
-#pragma unroll
-      for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) a[pp][j4] = an[pp][j4];
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int row = nt ? ri : rr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int trow = mt * 32 + acc_row(r, half);
-        p.ys[pcnn_spec::sp_item((int64_t)trow * p.gout + go, p.rows) + row * RS + c] = acc[nt][r];
-      }
-    }
-  };
-  m_tile(mt);
-  for (mt += mstride; mt < nMt; mt += mstride) m_tile(mt);
-}
-
-// M_f from the filter spectrum Wsp[ci * gout + go][row][co % 32] (conj: correlation).
-// M[slot][go][gi][k = 32 part_in + ci % 32][n = 32 part_out + co % 32]
-// cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and M_f is block diagonal - a tile's channels mix only among themselves.
-// One workgroup per 64 x 64 matrix (blockIdx = (slot, go, gi)): thread t writes elements t, t + 256, ... - row k = element / 64 is uniform per
-// wave half, so the filter-spectrum reads are whole 128-byte channel rows and no index needs a run-time division (the grid-stride form took
-// 15 us per layer, twice per layer and step).
-__global__ __launch_bounds__(256) void spec_build_mix_kernel(const float* __restrict__ wsp, const int4* __restrict__ slots, float* __restrict__ M, int Cin, int gin, int gout, int cpt, int rows) {
-  const int slot = blockIdx.x, go = blockIdx.y, gi = blockIdx.z;
-  const int4 sl = slots[slot];
-  float* out = M + (((int64_t)slot * gout + go) * gin + gi) * 4096;
-#pragma unroll 4
-  for (int e = threadIdx.x; e < 4096; e += 256) {
-    const int nn = e & 63, k = e >> 6;
-    const int pin = k >> 5, pout = nn >> 5;
-    const int kc = k & 31, nc = nn & 31;
-    const int cil = kc % cpt, co = nc % cpt;                  // cpt is a power of two >= 4
-    const bool same_tile = kc / cpt == nc / cpt;
-    const int ci = gi * 32 + cil;
-    float v = 0.f;
-    if (ci < Cin && same_tile) {
-      const float* wg = wsp + pcnn_spec::sp_item(ci * gout + go, rows) + co;
-      const float wr = wg[sl.x * RS], wi = wg[sl.y * RS];
-      if (sl.z == 1) v = (pin == 0 && pout == 0) ? wr : ((pin == 1 && pout == 1) ? wi : 0.f);     // two real frequencies packed in one slot
-      else v = pin == pout ? wr : (pin == 0 ? -wi : wi);                                          // [[Hr, Hi], [-Hi, Hr]], H = conj(W)
-    }
-    out[e] = v;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ weight gradient
@@ -769,15 +691,8 @@ void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
 }
 
 void launch_mix(pcnn_handle h, const Geom& gm, MixParams mx, int gin, int gout, int nt) {
-  static const int variant = getenv("PCNN_SPEC_MIX") ? atoi(getenv("PCNN_SPEC_MIX")) : 0;        // 0: M_f in registers, 1: M_f in LDS (16 waves per CU)
   mx.slots = gm.slots; mx.rows = gm.rows; mx.ntile = nt;
   const int nMt = pcnn_cdiv(nt, 32);
-  if (variant == 1) {
-    const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 6));
-    if (gin == 1) hipLaunchKernelGGL(spec_mix_lds_kernel<1>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
-    else hipLaunchKernelGGL(spec_mix_lds_kernel<2>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
-    return;
-  }
   const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
   if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
   else hipLaunchKernelGGL(spec_mix_kernel<2>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
@@ -887,22 +802,20 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   const int64_t ntile = (int64_t)d->N * tiles_y * tgx;                       // tile groups (= tiles when pack == 1)
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gin = pcnn_cdiv(d->Cin, 32), gout = pcnn_cdiv(d->Cout, 32);
-  const int rows = Tg * Tg, nslot = rows / 2;
-  // workspace: [filter spectrum | M | input spectra | output spectra]
-  const size_t wsp_b = align256(sp_bytes((size_t)d->Cin * gout, rows)), M_b = align256((size_t)nslot * gin * gout * 64 * 64 * 4);
+  const int rows = Tg * Tg;
+  // workspace: [filter spectrum | input spectra | output spectra]
+  const size_t wsp_b = align256(sp_bytes((size_t)d->Cin * gout, rows));
   auto xs_bytes = [&](int ch) { return align256(sp_bytes((size_t)ch * gin, rows)); };
   auto ys_bytes = [&](int ch) { return align256(sp_bytes((size_t)pad32(ch) * gout, rows)); };
-  const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / (gin > gout ? gin : gout), ntile), [&](int ch) { return wsp_b + M_b + xs_bytes(ch) + ys_bytes(ch); });
+  const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / (gin > gout ? gin : gout), ntile), [&](int ch) { return wsp_b + xs_bytes(ch) + ys_bytes(ch); });
   const size_t xs_b = xs_bytes(chunk), ys_b = ys_bytes(chunk);
   char* r;
-  if (int rc = ensure_workspace(h, wsp_b + M_b + xs_b + ys_b, &r)) return rc;
+  if (int rc = ensure_workspace(h, wsp_b + xs_b + ys_b, &r)) return rc;
   const Geom gm = geom_of(h, Tg);
   float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
-  float* Mm = reinterpret_cast<float*>(r); r += M_b;
   float* xs = reinterpret_cast<float*>(r); r += xs_b;
   float* ys = reinterpret_cast<float*>(r);
   launch_fwd(h, gm, filter_params(gm, w, wsp, d->kh, d->kw, d->Cin, d->Cout, gout), 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(nslot, gout, gin), dim3(256), 0, h->stream, wsp, gm.slots, Mm, d->Cin, gin, gout, cpt, rows);
   PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
   FwdParams fx;
   fx.x = x; fx.sp = xs; fx.tab = gm.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
@@ -918,7 +831,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
   if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
   MixParams mx;
-  mx.xs = xs; mx.ys = ys; mx.M = Mm; mx.gin = gin; mx.gout = gout;
+  mx.xs = xs; mx.ys = ys; mx.wsp = wsp; mx.gin = gin; mx.gout = gout; mx.Cin = d->Cin; mx.cpt = cpt;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
     fx.tile0 = (int)t0; iv.tile0 = (int)t0;
@@ -1003,18 +916,17 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
   const int gz = 1, gx = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();       // channel groups of dz (<= 32 channels) and of x / dx
   const int rows = Tg * Tg, nslot = rows / 2;
-  // workspace: [filter spectrum | M | dz spectra (gz) | dx spectra (gx) | x-tile spectra (gx) | partial sums]; C^ reuses the filter-spectrum slot
-  const size_t wsp_b = align256(sp_bytes((size_t)std::max(dg->Cin * gx, d->Cin), rows)), M_b = align256((size_t)nslot * gz * gx * 64 * 64 * 4);
+  // workspace: [filter spectrum | dz spectra (gz) | dx spectra (gx) | x-tile spectra (gx) | partial sums]; C^ reuses the filter-spectrum slot
+  const size_t wsp_b = align256(sp_bytes((size_t)std::max(dg->Cin * gx, d->Cin), rows));
   const size_t part_b = align256((size_t)S * nslot * gx * 4 * 1024 * 4);
   auto zs_bytes = [&](int ch) { return align256(sp_bytes((size_t)ch * gz, rows)); };
   auto ys_bytes = [&](int ch) { return align256(sp_bytes((size_t)pad32(ch) * gx, rows)); };
-  const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / gx, ntile), [&](int ch) { return wsp_b + M_b + part_b + 4096 + zs_bytes(ch) + 2 * ys_bytes(ch); });
+  const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / gx, ntile), [&](int ch) { return wsp_b + part_b + 4096 + zs_bytes(ch) + 2 * ys_bytes(ch); });
   const size_t zs_b = zs_bytes(chunk), ys_b = ys_bytes(chunk);
   char* r;
-  if (int rc = ensure_workspace(h, wsp_b + M_b + zs_b + 2 * ys_b + part_b + 4096, &r)) return rc;
+  if (int rc = ensure_workspace(h, wsp_b + zs_b + 2 * ys_b + part_b + 4096, &r)) return rc;
   const Geom gm = geom_of(h, Tg);
   float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
-  float* Mm = reinterpret_cast<float*>(r); r += M_b;
   float* zs = reinterpret_cast<float*>(r); r += zs_b;
   float* ys = reinterpret_cast<float*>(r); r += ys_b;
   float* xs = reinterpret_cast<float*>(r); r += ys_b;
@@ -1022,7 +934,6 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   // flipped filter spectrum -> mixing matrices of the data gradient (input groups: dz's, output groups: dx's)
   PCNN_REQUIRE(h, gx == 1 || dg->Cout == 64, "pcnn_conv2d_bwd_spectral: %d input channels unsupported (<= 32 or 64)", d->Cin);
   launch_fwd(h, gm, filter_params(gm, w_flipped, wsp, d->kh, d->kw, dg->Cin, dg->Cout, gx), 1);
-  hipLaunchKernelGGL(spec_build_mix_kernel, dim3(nslot, gx, gz), dim3(256), 0, h->stream, wsp, gm.slots, Mm, dg->Cin, gz, gx, cpt, rows);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral (filter spectrum)");
   FwdParams fz;                                          // dz windows with halo: the data gradient's input transform
   fz.x = dz; fz.sp = zs; fz.tab = gm.tab; fz.H = dg->H; fz.W = dg->W; fz.C = dg->Cin; fz.ld = dg->ldx; fz.groups = gz; fz.cstride = 32; fz.cvalid = 32;
@@ -1042,7 +953,7 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
   if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
   MixParams mx;
-  mx.xs = zs; mx.ys = ys; mx.M = Mm; mx.gin = gz; mx.gout = gx;
+  mx.xs = zs; mx.ys = ys; mx.wsp = wsp; mx.gin = gz; mx.gout = gx; mx.Cin = dg->Cin; mx.cpt = cpt;
   WMixParams wm;
   wm.xs = xs; wm.ds = zs; wm.part = part; wm.slots = gm.slots; wm.gin = gx; wm.S = S / 4; wm.rows = rows; wm.nslot = nslot;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
@@ -1054,7 +965,7 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
     launch_fwd(h, gm, fxm, nt);
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gx), dim3(256), 0, h->stream, wm);
   }
-  float* csp = wsp;                                      // the filter spectrum is no longer needed
+  float* csp = wsp;                                      // the filter spectrum is no longer needed: every mixing launch above has read it (same stream)
   hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gx), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);
   launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 1), 1);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral");
