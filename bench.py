@@ -66,6 +66,12 @@ def parse_args(argv=None):
     ap.add_argument('--modes', default='split_f16,fp32', help='math modes to time, in order; the LAST one is the headline (default: split_f16,fp32)')
     ap.add_argument('--math', default=None, choices=['split_f16', 'fp32'], help='time only this mode (profiling runs)')
     ap.add_argument('--cpu-baseline-hw', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline-1024', action='store_true', help='skip the 1024^2 leg of the CPU baseline (1 warm-up + 2 reps, about a minute)')
+    ap.add_argument('--launch-timeout', type=float, default=3000.0, help='bare N > 1 launch: seconds after which the parent stops every rank and exits 124')
+    ap.add_argument('--timeout', type=float, default=600.0, help='seconds a rank waits in a rendezvous / barrier / collective before it gives up (process-group timeout)')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'bench_detail.json'),
+                    help='where rank 0 writes the FULL result (per-kernel tables, provenance strings); stdout carries only the compact line')
+    ap.add_argument('--fail-rank', type=int, default=-1, help=argparse.SUPPRESS)       # tests: this rank exits 3 before the first barrier
     ap.add_argument('--overlap-wgrad', type=int, default=0, choices=[0, 1],
                     help='1: run the weight gradients on a second HIP stream, overlapping them with the data-gradient convolutions (the library '
                          'default; ~3 %% faster end to end).  Default 0 here: with two kernels sharing the chip a launch\'s duration is no '
@@ -75,27 +81,83 @@ def parse_args(argv=None):
 
 # ----------------------------------------------------------------------------------------------------------------- self-launch
 def self_launch(args):
-    """Bare `python bench.py --gpus N`: one child process per rank, started before this process has imported torch or touched a GPU."""
+    """Bare `python bench.py --gpus N`: one child process per rank, started before this process has imported torch or touched a GPU.
+
+    The parent POLLS its children: when one exits non-zero (or the whole run exceeds --launch-timeout) the others - which would otherwise sit
+    in a barrier / RCCL collective until the driver's limit - are terminated (SIGTERM, then SIGKILL; fresh processes only, nothing is
+    re-exec'ed), the failing rank's stderr tail is printed and the parent exits non-zero within seconds.  Ranks != 0 keep their stderr (a
+    temporary file each, relayed on failure); only their stdout is dropped, so that rank 0's JSON line is the only line on stdout."""
+    import tempfile
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, errs = [], []
+    tmp = tempfile.mkdtemp(prefix='pcnn_bench_')
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        err = None if r == 0 else open(os.path.join(tmp, 'rank%d.stderr' % r), 'w+')
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=err))
+
+    def tail(r, n=30):
+        if errs[r] is None:
+            return '(rank 0 writes to this stderr directly)'
+        errs[r].flush()
+        errs[r].seek(0)
+        return ''.join(errs[r].readlines()[-n:])
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    deadline = time.monotonic() + args.launch_timeout
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                print('[bench] rank %d exited with status %d; stopping the other ranks.  Its stderr tail:\n%s' % (r, c, tail(r)), file=sys.stderr, flush=True)
+                stop_all()
+                rc = abs(c) or 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                live = [r for r, c in enumerate(codes) if c is None]
+                print('[bench] --launch-timeout %.0f s exceeded with ranks %s still running; stopping them' % (args.launch_timeout, live), file=sys.stderr, flush=True)
+                for r in live[:2]:
+                    print('[bench] rank %d stderr tail:\n%s' % (r, tail(r)), file=sys.stderr, flush=True)
+                stop_all()
+                rc = 124
+                break
+            time.sleep(0.1)
+    finally:
+        for e in errs:
+            if e is not None:
+                e.close()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
     return rc
 
 
 # ----------------------------------------------------------------------------------------------------------------- CPU baselines
-def cpu_baseline(sample_hw=512, seed=0):
-    """fwd+bwd of the identical layer graph on the host cores (oracle twin, fp32) for ONE sample_hw^2 grid: 1 warm-up + >= 2 timed reps."""
+def cpu_baseline(sample_hw=512, seed=0, with_1024=True):
+    """fwd+bwd of the identical layer graph on the host cores (oracle twin, fp32) for ONE sample_hw^2 grid: 2 warm-ups, then the MEDIAN of
+    5 timed reps; optionally one 1024^2 grid beside it (1 warm-up + 2 reps: a bounded sample of the c4 workload's grid size)."""
     import numpy as np
     import torch
     from oracle import hpnn as ohpnn, torch_twin, loss as oloss
@@ -109,32 +171,37 @@ def cpu_baseline(sample_hw=512, seed=0):
         torch.set_num_threads(cores)
         p = ohpnn.init_params(cfg, seed=seed)
         pt = {k: torch.tensor(v, dtype=torch.float32, requires_grad=not k.endswith(('moving_mean', 'moving_variance'))) for k, v in p.items()}
-        rng = np.random.default_rng(seed)
-        H = W = sample_hw
-        rhs = torch.tensor(rng.uniform(-1, 1, (1, 1, H, W)), dtype=torch.float32)
-        dx = torch.tensor(rng.uniform(5e-3, 5e-2, (1, 1)), dtype=torch.float32)
-        tgt = torch.tensor(rng.standard_normal((1, 1, H, W)) * 0.1, dtype=torch.float32)
         L = oloss.loss_wrapper(global_batch_size=1, **full['training']['loss_parameters'])
 
-        def step():
-            for v in pt.values():
-                v.grad = None
-            pred = ohpnn.forward(torch_twin, cfg, pt, rhs, dx)
-            loss = L(tgt, pred, rhs, np.concatenate([dx.numpy(), dx.numpy()], 1))
-            loss.backward()
-        step()                      # warm-up (oneDNN primitive creation)
-        t0 = time.perf_counter()
-        reps = 0
-        while reps < 2 or (time.perf_counter() - t0 < 20.0 and reps < 5):
-            step()
-            reps += 1
-        dt = (time.perf_counter() - t0) / reps
+        def measure(hw, warm, reps):
+            rng = np.random.default_rng(seed)
+            rhs = torch.tensor(rng.uniform(-1, 1, (1, 1, hw, hw)), dtype=torch.float32)
+            dx = torch.tensor(rng.uniform(5e-3, 5e-2, (1, 1)), dtype=torch.float32)
+            tgt = torch.tensor(rng.standard_normal((1, 1, hw, hw)) * 0.1, dtype=torch.float32)
+            times = []
+            for i in range(warm + reps):
+                for v in pt.values():
+                    v.grad = None
+                t0 = time.perf_counter()
+                pred = ohpnn.forward(torch_twin, cfg, pt, rhs, dx)
+                loss = L(tgt, pred, rhs, np.concatenate([dx.numpy(), dx.numpy()], 1))
+                loss.backward()
+                if i >= warm:
+                    times.append(time.perf_counter() - t0)
+            return sorted(times)[len(times) // 2] if len(times) % 2 else 0.5 * (sorted(times)[len(times) // 2 - 1] + sorted(times)[len(times) // 2]), times
+        H = sample_hw
+        dt, times = measure(H, 2, 5)
+        out = {'value': 1.0 / dt, 'unit': 'grids/s (%dx%d grids, fwd+bwd)' % (H, H), 'cores': cores, 'kind': 'port',
+               'grids_per_s_1024_equivalent': H * H / dt / (1024.0 * 1024.0), 'seconds_per_rep': times,
+               'sample': '2 warm-ups + median of %d timed reps of fwd+bwd on one %dx%d grid (%.2f s each), oracle torch-CPU twin in fp32 on %d threads - stand-in for TF-CPU'
+                         % (len(times), H, H, dt, cores)}
+        if with_1024 and H != 1024:
+            d2, t2 = measure(1024, 1, 2)
+            out['at_1024'] = {'value': 1.0 / d2, 'unit': 'grids/s (1024x1024 grids, fwd+bwd)', 'seconds_per_rep': t2,
+                              'sample': '1 warm-up + %d timed reps on one 1024x1024 grid (%.1f s each)' % (len(t2), d2)}
     finally:
         torch_twin.set_dtype(torch.float64)
-    return {'value': 1.0 / dt, 'unit': 'grids/s (%dx%d grids, fwd+bwd)' % (H, W), 'cores': cores, 'kind': 'port',
-            'grids_per_s_1024_equivalent': H * W / dt / (1024.0 * 1024.0),
-            'sample': '1 warm-up + %d timed reps of fwd+bwd on one %dx%d grid (%.2f s each), oracle torch-CPU twin in fp32 on %d threads - stand-in for TF-CPU'
-                      % (reps, H, W, dt, cores)}
+    return out
 
 
 def dataset_block():
@@ -192,10 +259,80 @@ def launch_check(args, dp):
         print(json.dumps({'metric': 'launch-check (no model)', 'dry_run': True, 'value': args.steps / elapsed, 'unit': 'all-reduces/s (22.2 MB fp32 bucket)',
                           'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                          'config': {'workload': 'launch-check', 'collective': dp.collective_name(), 'parallelism': 'dp%d' % dp.world_size}}), flush=True)
+                          'config': {'workload': 'launch-check', 'collective': dp.collective_name(), 'parallelism': 'dp%d' % dp.world_size,
+                                     'ranks_seen': dp.ranks_seen(), 'rccl': dp.rccl_version()}}), flush=True)
 
 
-PROFILE_ROUND = 'r03'
+PROFILE_ROUND = 'r04'
+COMPACT_LIMIT = 3072      # bytes: the driver keeps ~8.6 KB of stdout; round 3's 23 KB line arrived cut and unparseable
+
+
+def _r(x, nd=4):
+    """round floats for the compact line (None and non-floats pass through)"""
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(d):
+    """The ONE line rank 0 prints: every field of the driver's contract plus the headline figures of each block, <= COMPACT_LIMIT bytes.
+    Everything else (per-kernel tables, provenance strings, per-round timings) is in the detail file (--detail, default bench_detail.json)."""
+    if d.get('dry_run'):
+        return d
+    rf = d.get('roofline') or {}
+    hbm = rf.get('hbm_bound') or {}
+    dom = max((k for k in (rf.get('kernels') or []) if k.get('ms_per_step')), key=lambda k: k['ms_per_step'], default=None)
+    cfg = d.get('config') or {}
+    out = {k: d.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    out['value'], out['ms_per_step'] = _r(out['value'], 3), _r(out['ms_per_step'], 3)
+    out['config'] = {'workload': cfg.get('workload'), 'global_batch': cfg.get('global_batch'), 'grid': cfg.get('grid'), 'parallelism': cfg.get('parallelism'),
+                     'math': cfg.get('math'), 'collective': cfg.get('collective'), 'ranks_seen': cfg.get('ranks_seen'), 'rccl': cfg.get('rccl')}
+    out['rank_ms_per_step'] = {k: _r(v, 3) for k, v in (d.get('rank_ms_per_step') or {}).items()}
+    out['collective_ms'] = _r(d.get('collective_ms'), 4)
+    out['roofline'] = {'bound': rf.get('bound'), 'kernel': 'all conv launches of a step (spectral + direct + narrow)', 'achieved': _r(rf.get('achieved'), 1),
+                       'peak': rf.get('peak'), 'unit': rf.get('unit'), 'frac': _r(rf.get('frac')), 'traffic': rf.get('traffic'),
+                       'achieved_is': 'executed PMC bytes / HIP-event time' if rf.get('traffic') else 'algorithmic bytes / HIP-event time (no stamped PMC summary)',
+                       'algorithmic_bytes': rf.get('algorithmic_bytes_per_step'), 'algorithmic_frac': _r((rf.get('algorithmic_GBs') or 0.0) / (rf.get('peak') or 1.0)),
+                       'traffic_over_algorithmic': _r(rf.get('traffic_over_algorithmic'), 3), 'mfma_busy': _r(rf.get('mfma_busy')),
+                       'conv_ms_per_step': _r(rf.get('conv_kernel_ms_per_step'), 2), 'hbm_bound_frac': _r(hbm.get('frac')),
+                       'fused_stage_frac': _r((rf.get('fused_stage') or {}).get('frac')),
+                       'dominant_kernel': None if dom is None else {'name': str(dom['kernel'])[:40], 'ms_per_step': _r(dom['ms_per_step'], 2),
+                                                                    'avg_launch_ms': _r(dom.get('avg_launch_ms')), 'hbm_frac': _r(dom.get('hbm_frac'), 3),
+                                                                    'mfma_busy': _r(dom.get('mfma_busy_frac'), 3)}}
+    cb = d.get('cpu_baseline')
+    if cb:
+        out['cpu_baseline'] = {'value': _r(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'), 'kind': cb.get('kind'), 'sample': str(cb.get('sample'))[:160]}
+        if cb.get('at_1024'):
+            out['cpu_baseline']['value_1024'] = _r(cb['at_1024'].get('value'), 5)
+    c3 = d.get('c3')
+    if c3:
+        out['c3'] = {'value': _r(c3.get('value'), 3), 'unit': c3.get('unit'), 'ms_per_step': _r(c3.get('ms_per_step'), 3), 'roofline_frac': _r((c3.get('roofline') or {}).get('frac')),
+                     'hbm_bound_frac': _r(((c3.get('roofline') or {}).get('hbm_bound') or {}).get('frac'))}
+    sp = d.get('split_f16')
+    if sp:
+        acc = sp.get('accuracy_vs_fp32') or {}
+        out['split_f16'] = {'value': _r(sp.get('value'), 3), 'ms_per_step': _r(sp.get('ms_per_step'), 3), 'fwd_rel_l2': (acc.get('forward_output') or {}).get('rel_l2'),
+                            'grad_rel_l2': (acc.get('flat_gradient') or {}).get('rel_l2')}
+    ds = d.get('dataset')
+    if ds:
+        out['dataset'] = {'error': str(ds['error'])[:120]} if 'error' in ds else {'value': _r(ds.get('value'), 1), 'unit': 'samples/s at 512^2', 'frac': _r(ds.get('fp64_mfma_frac')),
+                                                                                  'bound': 'fp64 mfma'}
+    out['detail'] = d.get('detail_file')
+    return out
+
+
+def emit(detail, path):
+    """rank 0: the full result to `path` (best effort) and to stderr as one '[bench-detail]' line; the compact line - and nothing else - to stdout."""
+    try:
+        with open(path, 'w') as f:
+            json.dump(detail, f, indent=1)
+        detail['detail_file'] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        detail['detail_file'] = 'not written: %r' % (e,)
+    line = json.dumps(compact_line(detail))
+    if len(line) > COMPACT_LIMIT:          # cannot happen with the fixed field list above; never let it pass silently
+        raise RuntimeError('compact bench line is %d bytes (limit %d)' % (len(line), COMPACT_LIMIT))
+    print(line, flush=True)
+
+
 
 
 def pmc_summary(math, workload):
@@ -218,7 +355,10 @@ def run(args):
     import torch
     from poisson_cnn_amd import configs, ops, parallel
     os.environ['PCNN_WGRAD_STREAM'] = str(args.overlap_wgrad)
-    dp = parallel.DataParallel.from_env()
+    if args.fail_rank >= 0 and int(os.environ.get('RANK', '0')) == args.fail_rank:       # tests: a rank that dies before its first barrier
+        print('[bench] rank %d: --fail-rank asked for this exit' % args.fail_rank, file=sys.stderr, flush=True)
+        sys.exit(3)
+    dp = parallel.DataParallel.from_env(timeout_s=args.timeout)
     if dp.world_size != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, dp.world_size))
     if args.workload == 'launch-check':
@@ -386,7 +526,8 @@ def run(args):
         'config': {'workload': '%s: Homogeneous_Poisson_NN_Legacy(hpnn.json) full train step (fwd+bwd+loss+Adam%s), %d x %dx%d Dirichlet grids per GPU'
                                % (args.workload, ('+' + dp.collective_name()) if dp.world_size > 1 else '', per_gpu, H, W),
                    'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': head, 'library_default_math': 'fp32',
-                   'overlap_wgrad': bool(args.overlap_wgrad), 'final_loss': hb['final_loss'], 'collective': dp.collective_name() if dp.world_size > 1 else None},
+                   'overlap_wgrad': bool(args.overlap_wgrad), 'final_loss': hb['final_loss'], 'collective': dp.collective_name() if dp.world_size > 1 else None,
+                   'ranks_seen': dp.ranks_seen(), 'rccl': dp.rccl_version()},
         'rank_ms_per_step': hb['rank_ms_per_step'], 'collective_ms': coll_ms,
         'roofline': hb['roofline'],
     }
@@ -396,14 +537,14 @@ def run(args):
         out['c3'] = c3
     if dp.world_size == 1 and not args.no_cpu_baseline:
         note('cpu baseline (bounded sample: one %d^2 grid) ...' % args.cpu_baseline_hw)
-        out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_hw)
+        out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_hw, with_1024=(args.workload == 'c4' and not args.no_cpu_baseline_1024))
     if dp.world_size == 1 and not args.no_dataset:
         note('dataset generator block ...')
         try:
             out['dataset'] = dataset_block()
         except Exception as e:   # the headline must not die on the side measurement
             out['dataset'] = {'error': repr(e)}
-    print(json.dumps(out), flush=True)
+    emit(out, args.detail)
 
 
 def main():

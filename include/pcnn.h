@@ -91,6 +91,11 @@ int pcnn_get_spectral_tile(pcnn_handle h);
  * library may take.  Growth happens inside a convolution call (stream synchronise + free + allocate) until the largest layer shape has
  * been seen: call the largest shape once up front, or set the cap, to keep allocation out of the steady state. */
 int pcnn_set_workspace_limit(pcnn_handle h, size_t bytes);
+/* hipGraph safety (poisson_cnn_amd/graphs.py; no reference counterpart - TensorFlow's tf.function graphs own their scratch): a graph
+ * captured on this handle's stream has the handle-owned buffers' addresses baked in.  retain = 1: a buffer the handle outgrows (or that a
+ * lower pcnn_set_workspace_limit releases) is NOT freed but parked until pcnn_destroy, so that earlier captures keep replaying into valid
+ * memory; later calls use the new, larger buffer.  retain = 0 (default): outgrown buffers are freed after a stream synchronise. */
+int pcnn_set_workspace_retain(pcnn_handle h, int retain);
 
 /* ---- 2-D convolution: tf.pad + tf.nn.conv2d(VALID) + bias + activation (+ BN affine) (+ residual) ----------
  * Replaces pad_and_apply_convolution (utils/apply_advanced_padding_and_call_conv_layer.py:16-20), Keras
@@ -226,6 +231,10 @@ int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo,
  * emitted by the layer's hyper-network) and layers/metalearning_deconvupscale.py:104-137 (conv2d_transpose, kernel = stride).  Sample n
  * uses the filter at w + n * w_sample_stride (HWIO (kh,kw,Cin,Cout); transposed convolution (f,f,Cout,Cin)) and the bias at
  * bias + n * bias_sample_stride.  d->N = batch, <= 32 output channels, <= 31 taps; 1-D layers are kh = 1.
+ *   _deconv_*  conv2d_transpose(kernel = stride = f, padding='SAME') exactly as TensorFlow crops it (layers/metalearning_deconvupscale.py:13-16):
+ *           the coarse grid must be H = ceil(Ho / f), W = ceil(Wo / f) (TensorFlow raises otherwise, and so do these calls) and output pixel
+ *           Y reads coarse row (Y + py) / f through tap (Y + py) % f with py = (H f - Ho) / 2 (likewise in x) - the same offset as
+ *           pcnn_deconv_fwd.  _bwd_filter sums strips of coarse rows in a fixed order (deterministic; partials in the handle's scratch).
  *   _fwd    flip_transpose = 0: y = act(conv(pad(x), w_n) + b_n).  flip_transpose = 1: the same kernel as the DATA gradient - x is dz, the
  *           stored filter is the forward filter (kh,kw,Cout_of_this_call,Cin_of_this_call), read flipped and transposed.
  *   _wgrad  dw_n = filter gradient of sample n (not summed over the batch); workspace: pcnn_grouped_conv2d_wgrad_workspace(d) bytes. */

@@ -269,7 +269,7 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
     const size_t need = ((size_t)d->kh * d->kw * cin_pad + cin_pad + 16) * NTh * 32 * sizeof(float);
     if (h->scratch_bytes < need) {
       // grown on demand; stream-ordered reuse is safe because pack and conv run back to back on the handle's stream
-      if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+      if (h->scratch) { pcnn_release(h, h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
       size_t cap = need < (4u << 20) ? (4u << 20) : need;
       if (hipMalloc(&h->scratch, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_conv2d_fwd: cannot allocate %zu B of filter scratch", cap);
       h->scratch_bytes = cap;

@@ -266,7 +266,7 @@ int pcnn_conv2d_fwd_split(pcnn_handle h, const pcnn_conv_desc* d, const float* x
   const int64_t plane_halfs = ((int64_t)ng * nT2 + 4) * 2 * NT * 32 * 8;       // + spare steps for the prefetch past the end
   const size_t need = 256 + (size_t)plane_halfs * 2 * sizeof(_Float16);
   if (h->scratch_bytes < need) {
-    if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+    if (h->scratch) { pcnn_release(h, h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
     const size_t cap = need < (4u << 20) ? (4u << 20) : need;
     if (hipMalloc(&h->scratch, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_conv2d_fwd: cannot allocate %zu B of filter scratch", cap);
     h->scratch_bytes = cap;

@@ -444,7 +444,7 @@ int pcnn_conv_small_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, 
   const int CI = pad4(d->Cin), CO = pad4(d->Cout), taps = d->kh * d->kw;
   const size_t need = (size_t)taps * CI * CO * sizeof(float);
   if (h->scratch_bytes < need) {
-    if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+    if (h->scratch) { pcnn_release(h, h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
     const size_t cap = 4u << 20;
     if (hipMalloc(&h->scratch, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_conv2d_fwd: cannot allocate %zu B of filter scratch", cap);
     h->scratch_bytes = cap;

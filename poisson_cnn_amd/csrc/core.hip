@@ -22,6 +22,7 @@ extern "C" int pcnn_destroy(pcnn_handle h) {
   if (h && h->scratch) (void)hipFree(h->scratch);
   if (h && h->spec_ws) (void)hipFree(h->spec_ws);
   if (h && h->aux_ws) (void)hipFree(h->aux_ws);
+  if (h) for (void* p : h->retired) (void)hipFree(p);
   if (h && h->comm) pcnn_comm_release(h);
   delete h;
   return 0;
@@ -30,6 +31,12 @@ extern "C" int pcnn_destroy(pcnn_handle h) {
 extern "C" int pcnn_set_stream(pcnn_handle h, void* hip_stream) {
   if (!h) return 1;
   h->stream = static_cast<hipStream_t>(hip_stream);
+  return 0;
+}
+
+extern "C" int pcnn_set_workspace_retain(pcnn_handle h, int retain) {
+  if (!h) return 1;
+  h->retain = retain ? 1 : 0;
   return 0;
 }
 

@@ -393,7 +393,7 @@ extern "C" int pcnn_loss_partials_p(pcnn_handle h, int N, int64_t hw, const floa
   // scratch for the split sums: N * 64 * 4 floats from the handle's filter scratch (stream-ordered with every other user of it)
   const size_t need = (size_t)N * LOSS_SPLITS * 4 * sizeof(float);
   if (h->scratch_bytes < need) {
-    if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+    if (h->scratch) { pcnn_release(h, h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
     const size_t cap = need < (4u << 20) ? (4u << 20) : need;
     if (hipMalloc(&h->scratch, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_loss_partials: cannot allocate %zu B of scratch", cap);
     h->scratch_bytes = cap;

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void deconv_bwd_filter_mfma_kernel(DeconvParam
 
 static bool ensure_scratch(pcnn_handle h, size_t need) {
   if (h->scratch_bytes >= need) return true;
-  if (h->scratch) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
+  if (h->scratch) { pcnn_release(h, h->scratch); h->scratch = nullptr; h->scratch_bytes = 0; }
   const size_t cap = need < (4u << 20) ? (4u << 20) : need;
   if (hipMalloc(&h->scratch, cap) != hipSuccess) return false;
   h->scratch_bytes = cap;

@@ -149,11 +149,14 @@ __global__ void grouped_wgrad_reduce_kernel(GroupedWgradParams p) {
   }
 }
 
-// ---- transposed convolution with kernel = stride f: y[n][Y][X][co] = b[n][co] + sum_ci x[n][Y / f][X / f][ci] K[n][Y % f][X % f][co][ci]
+// ---- transposed convolution with kernel = stride f, TensorFlow's padding='SAME' (layers/metalearning_deconvupscale.py:13-16,28-30):
+//   y[n][Y][X][co] = b[n][co] + sum_ci x[n][(Y + py) / f][(X + px) / f][ci] K[n][(Y + py) % f][(X + px) % f][co][ci],
+//   py = (H f - Ho) / 2, px = (W f - Wo) / 2 - the crop offset of conv2d_transpose when the coarse grid overhangs the output (H = ceil(Ho / f)),
+//   the same convention as deconv_mfma.hip and oracle/np_ops.py:conv2d_transpose_same.
 struct GroupedDeconvParams {
-  const float* x; const float* k; const float* bias; const float* dy; float* y; float* dx; float* dk; float* dbias;
+  const float* x; const float* k; const float* bias; const float* dy; float* y; float* dx; float* dk; float* dbias; float* part;
   long long k_stride, b_stride;
-  int N, H, W, Cin, Ho, Wo, Cout, f;
+  int N, H, W, Cin, Ho, Wo, Cout, f, py, px, S, rows_per_strip;
 };
 
 __global__ __launch_bounds__(256) void grouped_deconv_fwd_kernel(GroupedDeconvParams p) {
@@ -162,18 +165,19 @@ __global__ __launch_bounds__(256) void grouped_deconv_fwd_kernel(GroupedDeconvPa
   const float* K = p.k + (int64_t)n * p.k_stride;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < per; t += (int64_t)gridDim.x * blockDim.x) {
     const int co = t % p.Cout; const int64_t pix = t / p.Cout; const int X = pix % p.Wo, Y = pix / p.Wo;
-    const int yy = Y / p.f, xx = X / p.f;
+    const int Yp = Y + p.py, Xp = X + p.px;
+    const int yy = Yp / p.f, xx = Xp / p.f;
     float a = p.bias ? p.bias[(int64_t)n * p.b_stride + co] : 0.f;
     if (yy < p.H && xx < p.W) {
       const float* xv = p.x + (((int64_t)n * p.H + yy) * p.W + xx) * p.Cin;
-      const float* kv = K + (((int64_t)(Y % p.f) * p.f + X % p.f) * p.Cout + co) * p.Cin;
+      const float* kv = K + (((int64_t)(Yp - yy * p.f) * p.f + (Xp - xx * p.f)) * p.Cout + co) * p.Cin;
       for (int ci = 0; ci < p.Cin; ++ci) a = fmaf(xv[ci], kv[ci], a);
     }
     p.y[(int64_t)n * per + t] = a;
   }
 }
 
-// dx[n][y][x][ci] = sum over the f x f taps and co of dy[n][f y + a][f x + b][co] K[n][a][b][co][ci]
+// dx[n][y][x][ci] = sum over the f x f taps and co of dy[n][f y + u - py][f x + v - px][co] K[n][u][v][co][ci] (fine pixels outside the output: none)
 __global__ __launch_bounds__(256) void grouped_deconv_bwd_data_kernel(GroupedDeconvParams p) {
   const int n = blockIdx.y;
   const int64_t per = (int64_t)p.H * p.W * p.Cin;
@@ -183,8 +187,8 @@ __global__ __launch_bounds__(256) void grouped_deconv_bwd_data_kernel(GroupedDec
     float a = 0.f;
     for (int u = 0; u < p.f; ++u)
       for (int v = 0; v < p.f; ++v) {
-        const int Y = p.f * y + u, X = p.f * x + v;
-        if (Y < p.Ho && X < p.Wo) {
+        const int Y = p.f * y + u - p.py, X = p.f * x + v - p.px;
+        if (Y >= 0 && Y < p.Ho && X >= 0 && X < p.Wo) {
           const float* g = p.dy + (((int64_t)n * p.Ho + Y) * p.Wo + X) * p.Cout;
           const float* kv = K + ((int64_t)(u * p.f + v) * p.Cout) * p.Cin + ci;
           for (int co = 0; co < p.Cout; ++co) a = fmaf(g[co], kv[(int64_t)co * p.Cin], a);
@@ -194,36 +198,55 @@ __global__ __launch_bounds__(256) void grouped_deconv_bwd_data_kernel(GroupedDec
   }
 }
 
-// dK[n][a][b][co][ci] = sum over (y, x) of dy[n][f y + a][f x + b][co] x[n][y][x][ci]; dbias[n][co] = sum of dy[n][.][.][co].  One workgroup per
-// (sample, tap), threads over (co, ci) pairs, pixels walked in a fixed order: deterministic.
+// dK[n][u][v][co][ci] = sum over (y, x) of dy[n][f y + u - py][f x + v - px][co] x[n][y][x][ci]; dbias[n][co] = sum of dy[n][.][.][co].
+// Workgroup = (tap, strip of coarse rows, sample), threads over the (co, ci) pairs, a strip's pixels walked in a fixed order; the S strip
+// partials (and the strips' bias partials, written by the tap-0 workgroups) are summed in a fixed order by the reduce kernel: deterministic.
+// part layout: [n][s][f f Cout Cin | Cout].
 __global__ __launch_bounds__(256) void grouped_deconv_bwd_filter_kernel(GroupedDeconvParams p) {
-  const int n = blockIdx.y, tap = blockIdx.x, u = tap / p.f, v = tap % p.f;
+  const int n = blockIdx.z, s = blockIdx.y, tap = blockIdx.x, u = tap / p.f, v = tap % p.f;
   const int npair = p.Cout * p.Cin;
+  const int64_t rec = (int64_t)p.f * p.f * npair + p.Cout;
+  float* out = p.part + ((int64_t)n * p.S + s) * rec;
+  const int y0 = s * p.rows_per_strip, y1 = min(p.H, y0 + p.rows_per_strip);
   for (int e = threadIdx.x; e < npair; e += 256) {
     const int co = e / p.Cin, ci = e - co * p.Cin;
     float a = 0.f;
-    for (int y = 0; y < p.H; ++y) {
-      const int Y = p.f * y + u;
-      if (Y >= p.Ho) break;
+    for (int y = y0; y < y1; ++y) {
+      const int Y = p.f * y + u - p.py;
+      if (Y < 0 || Y >= p.Ho) continue;
       for (int x = 0; x < p.W; ++x) {
-        const int X = p.f * x + v;
-        if (X >= p.Wo) break;
+        const int X = p.f * x + v - p.px;
+        if (X < 0 || X >= p.Wo) continue;
         a = fmaf(p.dy[(((int64_t)n * p.Ho + Y) * p.Wo + X) * p.Cout + co], p.x[(((int64_t)n * p.H + y) * p.W + x) * p.Cin + ci], a);
       }
     }
-    p.dk[(int64_t)n * p.k_stride + (int64_t)tap * npair + e] = a;
+    out[(int64_t)tap * npair + e] = a;
   }
-  if (tap == 0 && p.dbias) {
+  if (tap == 0) {                                  // bias partial of this strip: its fine rows are f y0 - py .. f y1 - py (a partition of 0..Ho)
     __shared__ float red[256];
+    const int Y0 = max(0, p.f * y0 - p.py), Y1 = min(p.Ho, p.f * y1 - p.py);
+    const int64_t cnt = (int64_t)max(0, Y1 - Y0) * p.Wo;
+    const float* g = p.dy + ((int64_t)n * p.Ho + Y0) * p.Wo * p.Cout;
     for (int co = 0; co < p.Cout; ++co) {
       float a = 0.f;
-      for (int64_t t = threadIdx.x; t < (int64_t)p.Ho * p.Wo; t += 256) a += p.dy[((int64_t)n * p.Ho * p.Wo + t) * p.Cout + co];
+      for (int64_t t = threadIdx.x; t < cnt; t += 256) a += g[t * p.Cout + co];
       red[threadIdx.x] = a;
       __syncthreads();
       for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
-      if (threadIdx.x == 0) p.dbias[(int64_t)n * p.b_stride + co] = red[0];
+      if (threadIdx.x == 0) out[(int64_t)p.f * p.f * npair + co] = red[0];
       __syncthreads();
     }
+  }
+}
+
+__global__ void grouped_deconv_filter_reduce_kernel(GroupedDeconvParams p) {
+  const int64_t nk = (int64_t)p.f * p.f * p.Cout * p.Cin, rec = nk + p.Cout, total = (int64_t)p.N * rec;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = t / rec, e = t - n * rec;
+    float a = 0.f;
+    for (int s = 0; s < p.S; ++s) a += p.part[(n * p.S + s) * rec + e];
+    if (e < nk) p.dk[n * p.k_stride + e] = a;
+    else if (p.dbias) p.dbias[n * p.b_stride + (e - nk)] = a;
   }
 }
 
@@ -277,13 +300,17 @@ extern "C" int pcnn_grouped_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d,
 static GroupedDeconvParams deconv_params(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int f, long long ks, long long bs) {
   GroupedDeconvParams p;
   p.x = nullptr; p.k = nullptr; p.bias = nullptr; p.dy = nullptr; p.y = nullptr; p.dx = nullptr; p.dk = nullptr; p.dbias = nullptr;
+  p.part = nullptr; p.S = 1; p.rows_per_strip = H;
   p.k_stride = ks; p.b_stride = bs; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout; p.f = f;
+  p.py = (H * f - Ho) / 2; p.px = (W * f - Wo) / 2;          // conv2d_transpose 'SAME' crop offset (the geometry is checked by the callers below)
   return p;
 }
 
 extern "C" int pcnn_grouped_deconv_fwd(pcnn_handle h, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int f, const float* x, const float* k,
                                        long long k_sample_stride, const float* bias, long long bias_sample_stride, float* y) {
   PCNN_REQUIRE(h, h && x && k && y && f >= 1, "pcnn_grouped_deconv_fwd: bad argument");
+  PCNN_REQUIRE(h, N >= 1 && Cin >= 1 && Cout >= 1 && Ho >= 1 && Wo >= 1 && H == pcnn_cdiv(Ho, f) && W == pcnn_cdiv(Wo, f),
+               "%s: padding='SAME' with stride %d needs a coarse grid of ceil(%d / %d) x ceil(%d / %d), got %d x %d", "pcnn_grouped_deconv_fwd", f, Ho, f, Wo, f, H, W);
   GroupedDeconvParams p = deconv_params(N, H, W, Cin, Ho, Wo, Cout, f, k_sample_stride, bias_sample_stride);
   p.x = x; p.k = k; p.bias = bias; p.y = y;
   const int64_t per = (int64_t)Ho * Wo * Cout;
@@ -295,6 +322,8 @@ extern "C" int pcnn_grouped_deconv_fwd(pcnn_handle h, int N, int H, int W, int C
 extern "C" int pcnn_grouped_deconv_bwd_data(pcnn_handle h, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int f, const float* dy, const float* k,
                                             long long k_sample_stride, float* dx) {
   PCNN_REQUIRE(h, h && dy && k && dx && f >= 1, "pcnn_grouped_deconv_bwd_data: bad argument");
+  PCNN_REQUIRE(h, N >= 1 && Cin >= 1 && Cout >= 1 && Ho >= 1 && Wo >= 1 && H == pcnn_cdiv(Ho, f) && W == pcnn_cdiv(Wo, f),
+               "%s: padding='SAME' with stride %d needs a coarse grid of ceil(%d / %d) x ceil(%d / %d), got %d x %d", "pcnn_grouped_deconv_bwd_data", f, Ho, f, Wo, f, H, W);
   GroupedDeconvParams p = deconv_params(N, H, W, Cin, Ho, Wo, Cout, f, k_sample_stride, 0);
   p.dy = dy; p.k = k; p.dx = dx;
   const int64_t per = (int64_t)H * W * Cin;
@@ -306,9 +335,21 @@ extern "C" int pcnn_grouped_deconv_bwd_data(pcnn_handle h, int N, int H, int W, 
 extern "C" int pcnn_grouped_deconv_bwd_filter(pcnn_handle h, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int f, const float* x, const float* dy,
                                               float* dk, long long k_sample_stride, float* dbias, long long bias_sample_stride) {
   PCNN_REQUIRE(h, h && x && dy && dk && f >= 1, "pcnn_grouped_deconv_bwd_filter: bad argument");
+  PCNN_REQUIRE(h, N >= 1 && Cin >= 1 && Cout >= 1 && Ho >= 1 && Wo >= 1 && H == pcnn_cdiv(Ho, f) && W == pcnn_cdiv(Wo, f),
+               "%s: padding='SAME' with stride %d needs a coarse grid of ceil(%d / %d) x ceil(%d / %d), got %d x %d", "pcnn_grouped_deconv_bwd_filter", f, Ho, f, Wo, f, H, W);
   GroupedDeconvParams p = deconv_params(N, H, W, Cin, Ho, Wo, Cout, f, k_sample_stride, bias_sample_stride);
   p.x = x; p.dy = dy; p.dk = dk; p.dbias = dbias;
-  hipLaunchKernelGGL(grouped_deconv_bwd_filter_kernel, dim3((unsigned)(f * f), (unsigned)N), dim3(256), 0, h->stream, p);
+  p.S = std::max(1, std::min(32, H / 2)); p.rows_per_strip = pcnn_cdiv(H, p.S); p.S = pcnn_cdiv(H, p.rows_per_strip);
+  const int64_t rec = (int64_t)f * f * Cout * Cin + Cout;
+  const size_t need = (size_t)N * p.S * rec * sizeof(float);
+  if (h->aux_ws_bytes < need) {                              // handle-owned scratch (shared with the two-pass resize; one stream per handle)
+    if (h->aux_ws) { pcnn_release(h, h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
+    if (hipMalloc(&h->aux_ws, need) != hipSuccess) PCNN_FAIL(h, "pcnn_grouped_deconv_bwd_filter: cannot allocate %zu B of scratch", need);
+    h->aux_ws_bytes = need;
+  }
+  p.part = static_cast<float*>(h->aux_ws);
+  hipLaunchKernelGGL(grouped_deconv_bwd_filter_kernel, dim3((unsigned)(f * f), (unsigned)p.S, (unsigned)N), dim3(256), 0, h->stream, p);
+  hipLaunchKernelGGL(grouped_deconv_filter_reduce_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64((int64_t)N * rec, 256), 1024)), dim3(256), 0, h->stream, p);
   PCNN_CHECK_LAUNCH(h, "pcnn_grouped_deconv_bwd_filter");
   return 0;
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 #include "../../include/pcnn.h"
 
 struct pcnn_handle_s {
@@ -21,11 +22,22 @@ struct pcnn_handle_s {
   size_t aux_ws_bytes = 0;
   int spectral_mode = -1;         // PCNN_SPECTRAL_AUTO (cost model) / _OFF / _FORCE, see pcnn_set_spectral_mode
   int spectral_tile = 0;          // 0: per layer (pick_tile), 32 / 64: that tile size wherever the layer allows it, see pcnn_set_spectral_tile
+  int retain = 0;                 // pcnn_set_workspace_retain: outgrown handle-owned buffers are kept (a captured hipGraph may still replay into them)
+  std::vector<void*> retired;     // ... here, until pcnn_destroy
   void* comm = nullptr;           // RCCL communicator (ncclComm_t) of pcnn_comm_init, see collective.hip
   int comm_rank = 0, comm_size = 0;
 };
 
 void pcnn_comm_release(pcnn_handle_s* h);   // collective.hip
+
+// A handle-owned buffer is being outgrown (or capped): free it once the stream has drained - unless the caller declared that recorded work
+// (a hipGraph captured on this handle's stream) may still use it; then it is parked until pcnn_destroy.
+static inline void pcnn_release(pcnn_handle_s* h, void* p) {
+  if (!p) return;
+  if (h->retain) { h->retired.push_back(p); return; }
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(p);
+}
 
 #define PCNN_FAIL(h, ...)                                   \
   do {                                                      \

@@ -551,7 +551,7 @@ extern "C" int pcnn_sample_scale_bwd(pcnn_handle h, int N, int64_t per, const fl
   PCNN_REQUIRE(h, h && x && g && dy && dx && dg, "pcnn_sample_scale_bwd: null argument");
   const size_t need = (size_t)N * SS_SPLIT * sizeof(float);
   if (h->aux_ws_bytes < need) {                              // handle-owned scratch (shared with the two-pass resize; one stream per handle)
-    if (h->aux_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
+    if (h->aux_ws) { pcnn_release(h, h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
     const size_t cap = need < (1u << 20) ? (1u << 20) : need;
     if (hipMalloc(&h->aux_ws, cap) != hipSuccess) PCNN_FAIL(h, "pcnn_sample_scale_bwd: cannot allocate %zu B of scratch", cap);
     h->aux_ws_bytes = cap;

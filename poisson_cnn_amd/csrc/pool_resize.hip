@@ -507,7 +507,7 @@ extern "C" int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int 
     // two passes: x interpolation of the hc coarse rows into the handle's scratch, then the row-uniform y pass
     const size_t need = (size_t)N * hc * Wo * C * sizeof(float);
     if (h->aux_ws_bytes < need) {
-      if (h->aux_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
+      if (h->aux_ws) { pcnn_release(h, h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
       if (hipMalloc(&h->aux_ws, need) != hipSuccess) PCNN_FAIL(h, "pcnn_resize_fwd: cannot allocate %zu B of scratch", need);
       h->aux_ws_bytes = need;
     }

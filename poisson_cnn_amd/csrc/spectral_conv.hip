@@ -621,7 +621,7 @@ int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, char** rest) {
   if (h->spec_ws_limit && need > h->spec_ws_limit)
     PCNN_FAIL(h, "spectral convolution: %zu B of workspace needed, the caller allows %zu B (pcnn_set_workspace_limit)", need, h->spec_ws_limit);
   if (h->spec_ws_bytes < need) {
-    if (h->spec_ws) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->spec_ws); h->spec_ws = nullptr; h->spec_ws_bytes = 0; }
+    if (h->spec_ws) { pcnn_release(h, h->spec_ws); h->spec_ws = nullptr; h->spec_ws_bytes = 0; }
     size_t cap = need + need / 8;
     if (h->spec_ws_limit && cap > h->spec_ws_limit) cap = h->spec_ws_limit;
     if (hipMalloc(&h->spec_ws, cap) != hipSuccess) PCNN_FAIL(h, "spectral convolution: cannot allocate %zu B of workspace", cap);
@@ -730,8 +730,7 @@ extern "C" int pcnn_set_workspace_limit(pcnn_handle h, size_t bytes) {
   if (!h) return 1;
   h->spec_ws_limit = bytes;
   if (bytes && h->spec_ws && h->spec_ws_bytes > bytes) {       // what the handle already holds beyond the new cap goes back to the caller's pool
-    (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->spec_ws);
+    pcnn_release(h, h->spec_ws);
     h->spec_ws = nullptr; h->spec_ws_bytes = 0;
   }
   return 0;

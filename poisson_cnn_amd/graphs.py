@@ -1,18 +1,23 @@
 """hipGraph capture of a whole model step (torch.cuda.CUDAGraph is hipGraph on ROCm).
 
-The boundary network Dirichlet_BC_NN_Legacy_2 and the end-to-end Poisson_CNN_Legacy issue ~1000 kernels of 10-20 us per training step on
-288 x 288 grids: on the host's launch path that is 60-70 ms of which the GPU computes a third.  A step on FIXED shapes is a fixed launch
-sequence (libpcnn has no host-side data dependence: no readbacks, workspaces grow only until the largest shape has been seen), so it is
-captured once and replayed: the launch-bound inner loop becomes one graph launch (MI355X guide: "capture launch-bound inner loops in
-hipGraphs").  Replays are bit-identical to eager steps - the same kernels in the same order on the same buffers.
+A step on FIXED shapes is a fixed launch sequence (libpcnn has no host-side data dependence: no readbacks, workspaces grow only until the
+largest shape has been seen), so it can be captured once and replayed as one graph launch; replays are bit-identical to eager steps - the
+same kernels in the same order on the same buffers.  MEASURED BENEFIT ON THE SHIPPED MODELS: NONE (dbcnn.json 60.6 vs
+59.4 ms, pcnn 68.7 vs 69.3 ms, hpnn unchanged) - rocprofv3 shows those steps are ~67 ms of kernel time, i.e. GPU-bound, not launch-bound;
+the feature is kept for hosts whose launch path is slower than this one's (many small grids per step), not as an optimisation of the benchmarks.
 
     step = GraphedTrainStep(model, ((bc, dx), target))        # warm-up + capture
     logs = step(((bc, dx), target))                            # copy inputs into the static buffers, replay, eager optimizer step
 
 The optimizer step stays eager (one launch per parameter bucket): its learning rate and iteration count are host scalars that change from
-step to step (ReduceLROnPlateau, Adam bias correction).  Data-parallel gradient reduction (model.grad_sync) runs eagerly between the two.
+step to step (ReduceLROnPlateau, Adam bias correction).  Data-parallel collectives - the gradient all-reduce (model.grad_sync) AND the
+2-element metric all-reduce (model.metric_sync) - are never recorded: they run eagerly after the replay, and the returned logs carry the
+optimizer's CURRENT learning rate.
 Shapes other than the captured ones need their own GraphedTrainStep (the reference's generators draw a new grid shape per batch: keep a
-small dict of them, or use the eager path)."""
+small dict of them, or use the eager path).  Scratch ownership: a capture keeps strong references to every model-level scratch buffer its
+launches address (Context.ws / ws_side / the flipped-filter scratch, ops._default_ws) and switches the capture stream's libpcnn handle to
+pcnn_set_workspace_retain, so a LATER capture or eager step on a larger shape - which makes those owners allocate bigger buffers - never
+frees memory an earlier graph still replays into."""
 import torch
 
 
@@ -44,22 +49,37 @@ class _Captured:
         if not torch.cuda.is_available():
             raise RuntimeError('hipGraph capture needs the GPU')
         self.model, self.device = model, model.device
-        for c in _ctxs(model):                                       # the weight-gradient side stream is an eager-mode overlap; one stream is captured
-            c.side_allowed = False
-            c.use_side = False
         self.stream = torch.cuda.Stream()
         self.warmup = max(1, int(warmup))
+        self._keep = []
 
     def _capture(self, fn):
-        torch.cuda.synchronize()
-        with torch.cuda.stream(self.stream):                          # libpcnn handles are per stream: the warm-up creates this stream's handle,
-            for _ in range(self.warmup):                              # its workspaces and every per-shape cache before anything is recorded
-                fn()
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            out = fn()
-        torch.cuda.synchronize()
+        from ctypes import c_int
+        from . import ops
+        ctxs = _ctxs(self.model)
+        saved = [(c, c.side_allowed, c.use_side) for c in ctxs]
+        for c in ctxs:                                                # the weight-gradient side stream is an eager-mode overlap; ONE stream is
+            c.side_allowed = False                                    # captured.  Restored below: later eager steps keep their overlap.
+            c.use_side = False
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.stream):                      # libpcnn handles are per stream: the warm-up creates this stream's handle,
+                for _ in range(self.warmup):                          # its workspaces and every per-shape cache before anything is recorded
+                    fn()
+                ops.handle().call('pcnn_set_workspace_retain', c_int(1))
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                out = fn()
+            torch.cuda.synchronize()
+        finally:
+            for c, allowed, use in saved:
+                c.side_allowed, c.use_side = allowed, use
+        # the recorded launches address these buffers; their owners drop them when a larger shape comes along - the graph must not
+        for c in ctxs:
+            self._keep += [c.ws.buf, c.ws_side.buf, c._wflip]
+        self._keep.append(ops._default_ws.buf)
+        self._keep = [b for b in self._keep if b is not None]
         return out
 
 
@@ -87,14 +107,15 @@ class GraphedTrainStep(_Captured):
         self.static_in = [_static(v, self.device) for v in inputs]
         self.static_y = _static(y, self.device)
         opt = model.optimizer
-        real_apply, real_sync = opt.apply_gradients, model.grad_sync
+        real_apply, real_sync, real_metric = opt.apply_gradients, model.grad_sync, getattr(model, 'metric_sync', None)
         snap = [(s, s.flat_w.clone(), s.flat_stats.clone()) for s in model.stores]
         opt.apply_gradients = lambda *a, **k: None
         model.grad_sync = None
+        model.metric_sync = None                                      # no collective inside the graph: the LOCAL loss / mse tensors are recorded
         try:
             self.logs = self._capture(lambda: model.train_step((self.static_in, self.static_y)))
         finally:
-            opt.apply_gradients, model.grad_sync = real_apply, real_sync
+            opt.apply_gradients, model.grad_sync, model.metric_sync = real_apply, real_sync, real_metric
             del opt.__dict__['apply_gradients']                       # back to the class's method (the instance attribute shadowed it)
         for s, w, st in snap:                                         # warm-up and capture ran the step without an optimizer: only the BN statistics
             s.flat_w.copy_(w); s.flat_stats.copy_(st)                 # of a training-mode-BN model could have moved
@@ -109,4 +130,9 @@ class GraphedTrainStep(_Captured):
             for s in m.stores:
                 m.grad_sync(s.flat_g)
         m.optimizer.apply_gradients()
-        return self.logs
+        logs = dict(self.logs)                                        # static local loss / mse tensors of the replay
+        if getattr(m, 'metric_sync', None) is not None:               # data parallel: the global metrics, eagerly, as train_step reports them
+            logs['loss'], logs['mse'] = m.metric_sync(logs['loss'], logs['mse'])
+        if 'lr' in logs:
+            logs['lr'] = m.optimizer.learning_rate                    # the host scalar as it is NOW (ReduceLROnPlateau), not at capture time
+        return logs

@@ -17,7 +17,9 @@ class DataParallel:
         self.rank, self.world_size, self.local_rank, self.backend = rank, world_size, local_rank, backend
 
     @classmethod
-    def from_env(cls, backend=None):
+    def from_env(cls, backend=None, timeout_s=None):
+        """timeout_s (or PCNN_DIST_TIMEOUT_S): how long a rank waits in the rendezvous / a collective before the process group gives up -
+        a rank that died before a barrier then costs the others this long, not the job's whole time limit."""
         ws = int(os.environ.get('WORLD_SIZE', '1'))
         rank = int(os.environ.get('RANK', '0'))
         lr = int(os.environ.get('LOCAL_RANK', '0'))
@@ -27,7 +29,11 @@ class DataParallel:
             backend = backend or os.environ.get('PCNN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
-            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+            import datetime
+            timeout_s = float(timeout_s if timeout_s is not None else os.environ.get('PCNN_DIST_TIMEOUT_S', 1800))
+            if backend == 'nccl':            # the RCCL watchdog aborts a collective that exceeds the timeout instead of hanging in it
+                os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
+            dist.init_process_group(backend=backend, rank=rank, world_size=ws, timeout=datetime.timedelta(seconds=timeout_s))
         if backend is None and dist.is_initialized():          # the caller's own process group: report and rendezvous over ITS backend
             backend = dist.get_backend()
         self = cls(rank, ws, lr, backend)
@@ -111,6 +117,19 @@ class DataParallel:
         if self.world_size == 1:
             return 'none (single rank)'
         return {'nccl': 'RCCL all-reduce', 'gloo': 'gloo all-reduce (CPU)'}.get(self.backend, '%s all-reduce' % self.backend)
+
+    def ranks_seen(self):
+        """World size as the process group itself reports it (1 without a group) - for reports: proof that N ranks really joined."""
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    def rccl_version(self):
+        """RCCL's version when the nccl backend carries the collectives, else None."""
+        if self.backend != 'nccl':
+            return None
+        try:
+            return '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001 - a report field must not kill the run
+            return 'unknown (%r)' % (e,)
 
     def barrier(self):
         if self.world_size > 1:

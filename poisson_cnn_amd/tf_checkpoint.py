@@ -537,7 +537,10 @@ def load_tf_checkpoint(model, prefix):
         if key not in tensors:
             raise ValueError('checkpoint %s has no variable %s (expected for %s)' % (prefix, key, n))
         t = tensors[key]
-        if t.size != ours[n].size:
-            raise ValueError('checkpoint variable %s has shape %s, the model\'s %s has %s' % (key, t.shape, n, ours[n].shape))
-        weights[n] = t.reshape(ours[n].shape)
+        want = tuple(ours[n].shape)
+        # shapes must MATCH - equal element counts are not enough (a kernel with Cin / Cout swapped, or another stage's kernel with the same
+        # product, would load scrambled).  The one exception is the rule _tf_shape applies on save: our (1, k, Cin, Cout) holds a Conv1D's (k, Cin, Cout).
+        if not (tuple(t.shape) == want or (len(want) == 4 and want[0] == 1 and tuple(t.shape) == want[1:])):
+            raise ValueError('checkpoint variable %s has shape %s, the model\'s %s has %s' % (key, tuple(t.shape), n, want))
+        weights[n] = t.reshape(want)
     model.set_weights(weights)

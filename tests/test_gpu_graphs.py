@@ -76,3 +76,67 @@ def test_hpnn_graph_replay_is_bit_identical_to_eager():
         le, lg = eager.train_step(((rhs, dx), tgt)), step(((rhs, dx), tgt))
         assert float(le['loss']) == float(lg['loss'])
         assert torch.equal(eager.store.flat_w, graphed.store.flat_w)
+
+
+def test_an_earlier_capture_survives_a_later_capture_of_a_larger_shape():
+    """a captured graph bakes in the addresses of model-level scratch (Context.ws / ws_side / flipped-filter scratch,
+    ops._default_ws) and of the capture stream's handle-owned workspaces; a later capture or eager step on a LARGER shape makes their owners
+    allocate bigger buffers.  The earlier graph must keep replaying into valid memory: capture A (small), capture B (larger, same model),
+    run eager steps on B's shape, empty the allocator's cache, then replay A and compare with an eager twin - bit-identical."""
+    from poisson_cnn_amd.graphs import GraphedInference, GraphedTrainStep
+
+    def batch(seed, L, H):
+        g = torch.Generator().manual_seed(seed)
+        bc = torch.cumsum(torch.randn(3, 1, L, generator=g) * 0.1, 2).cuda()
+        dx = (torch.rand(3, 1, generator=g) * 4.5e-2 + 5e-3).cuda()
+        tgt = (torch.randn(3, 1, H, L, generator=g) * 0.1).cuda()
+        return bc, dx, tgt
+    eager, graphed = _dbcnn(9), _dbcnn(9)
+    bcA, dxA, tgtA = batch(1, 44, 40)
+    bcB, dxB, tgtB = batch(2, 96, 88)
+    infA = GraphedInference(graphed, [bcA, dxA, 40])
+    stepA = GraphedTrainStep(graphed, ((bcA, dxA), tgtA))
+    ptrs = [b.data_ptr() for b in stepA._keep]
+    side = [(c.side_allowed, c.use_side) for c in [graphed.ctx]]
+    infB = GraphedInference(graphed, [bcB, dxB, 88])                  # larger shape: every scratch owner regrows
+    stepB = GraphedTrainStep(graphed, ((bcB, dxB), tgtB))
+    assert torch.equal(infB([bcB, dxB, 88]), eager([bcB, dxB, 88]))
+    for _ in range(2):                                                # eager steps on the larger shape as well
+        graphed.train_step(((bcB, dxB), tgtB)); eager.train_step(((bcB, dxB), tgtB))
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                          # anything the owners dropped and nobody else holds goes back to the driver
+    assert [b.data_ptr() for b in stepA._keep] == ptrs                # A's scratch is still A's
+    assert torch.equal(infA([bcA, dxA, 40]), eager([bcA, dxA, 40]))
+    le, lg = eager.train_step(((bcA, dxA), tgtA)), stepA(((bcA, dxA), tgtA))
+    assert float(le['loss']) == float(lg['loss']) and torch.equal(eager.store.flat_g, graphed.store.flat_g) and torch.equal(eager.store.flat_w, graphed.store.flat_w)
+    le, lg = eager.train_step(((bcB, dxB), tgtB)), stepB(((bcB, dxB), tgtB))
+    assert float(le['loss']) == float(lg['loss']) and torch.equal(eager.store.flat_w, graphed.store.flat_w)
+    assert [(c.side_allowed, c.use_side) for c in [graphed.ctx]] == side     # ADVICE r3 (low): capture restores the side-stream settings
+
+
+def test_graphed_step_keeps_collectives_and_the_learning_rate_out_of_the_graph():
+    """ADVICE r3 (medium): with data parallelism attached, train_step's metric all-reduce (model.metric_sync) must not be recorded in the graph;
+    it runs eagerly after each replay, like the gradient all-reduce, and logs['lr'] is the optimizer's current rate."""
+    from poisson_cnn_amd.graphs import GraphedTrainStep
+    m = _dbcnn(4)
+    bc, dx, tgt = _dbcnn_batch(3)
+    calls = {'grad': 0, 'metric': 0, 'capturing': False, 'in_capture': 0}
+
+    def grad_sync(flat):
+        calls['grad'] += 1
+        calls['in_capture'] += torch.cuda.is_current_stream_capturing()
+        return flat
+
+    def metric_sync(loss, mse):
+        calls['metric'] += 1
+        calls['in_capture'] += torch.cuda.is_current_stream_capturing()
+        return loss * 2, mse * 2                                       # a stand-in for the 2-rank sum
+    m.grad_sync, m.metric_sync = grad_sync, metric_sync
+    step = GraphedTrainStep(m, ((bc, dx), tgt))
+    assert calls['grad'] == 0 and calls['metric'] == 0                 # neither ran during warm-up or capture
+    local = float(step.logs['loss'])
+    m.optimizer.learning_rate = 5e-4
+    logs = step(((bc, dx), tgt))
+    assert calls == {'grad': 1, 'metric': 1, 'capturing': False, 'in_capture': 0}
+    assert float(logs['loss']) == 2 * float(step.logs['loss']) and logs['lr'] == 5e-4 and local == float(step.logs['loss'])
+    assert m.grad_sync is grad_sync and m.metric_sync is metric_sync

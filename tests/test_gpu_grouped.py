@@ -64,7 +64,36 @@ def test_grouped_one_dimensional_layer():
         assert rel(y[n, 0].cpu(), ref) < 2e-6
 
 
-@pytest.mark.parametrize('f,Cin,Cout,hc,wc,H,W', [(2, 5, 4, 20, 31, 40, 62), (3, 8, 8, 14, 10, 41, 29), (4, 3, 6, 9, 9, 36, 36)])
+# the last three shapes have a SAME crop offset (ceil(H / f) f - H) // 2 >= 1 in both axes (every shape used to have offset 0)
+DECONV = [(2, 5, 4, 20, 31, 40, 62), (3, 8, 8, 14, 10, 41, 29), (4, 3, 6, 9, 9, 36, 36), (3, 5, 4, 8, 9, 22, 25), (4, 6, 3, 3, 4, 10, 13), (8, 32, 32, 32, 32, 250, 250)]
+
+
+@pytest.mark.parametrize('f,Cin,Cout,hc,wc,H,W', DECONV)
+def test_grouped_deconv_matches_the_oracle(f, Cin, Cout, hc, wc, H, W):
+    """pcnn_grouped_deconv_fwd / _bwd_data / _bwd_filter against the fp64 oracle (oracle/torch_twin.conv2d_transpose_same + autograd) directly."""
+    from oracle import torch_twin as T
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(f + 17)
+    N = 3
+    nk = f * f * Cout * Cin
+    kshape = (f, f, Cout, Cin)
+    x = torch.randn(N, hc, wc, Cin, device='cuda', generator=g)
+    kb = torch.randn(N, nk + Cout, device='cuda', generator=g) * 0.3
+    dy = torch.randn(N, H, W, Cout, device='cuda', generator=g)
+    y = ops.grouped_deconv_fwd(x, kb, kshape, kb[:, nk:], (H, W), f)
+    dkb = torch.zeros_like(kb)
+    ops.grouped_deconv_bwd_filter(x, dy, f, dkb, dkb[:, nk:])
+    dx = ops.grouped_deconv_bwd_data(dy, kb, kshape, (hc, wc), f)
+    xt = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    kt = kb.double().cpu().requires_grad_(True)
+    yt = torch.cat([T.conv2d_transpose_same(xt[n:n + 1], kt[n, :nk].reshape(*kshape), kt[n, nk:], (H, W), f) for n in range(N)], 0)
+    (yt * dy.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    assert rel(y.cpu().permute(0, 3, 1, 2), yt.detach()) < 2e-6
+    assert rel(dx.cpu().permute(0, 3, 1, 2), xt.grad) < 2e-6
+    assert rel(dkb.cpu()[:, :nk], kt.grad[:, :nk]) < 5e-6 and rel(dkb.cpu()[:, nk:], kt.grad[:, nk:]) < 5e-6
+
+
+@pytest.mark.parametrize('f,Cin,Cout,hc,wc,H,W', DECONV)
 def test_grouped_deconv_matches_per_sample_launches(f, Cin, Cout, hc, wc, H, W):
     from poisson_cnn_amd import ops
     g = torch.Generator(device='cuda').manual_seed(f)

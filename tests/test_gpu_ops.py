@@ -501,18 +501,43 @@ def test_metalearning_conv_layernorm_and_stride():
     _ml_check(lay, w, fn, x, di, lambda: lay([dev(x), dev(di)], training=True))
 
 
-def test_metalearning_deconvupscale_and_resnet():
+# (f, coarse grid, output grid): the last three have a TensorFlow 'SAME' crop offset p = (ceil(H / f) f - H) // 2 >= 1 in BOTH axes - round 3's grouped
+# kernels dropped it and every test shape had p = 0
+DECONV_SHAPES = [(3, (7, 9), (20, 26)), (3, (8, 9), (22, 25)), (4, (3, 4), (10, 13)), (8, (32, 32), (250, 250))]
+
+
+@pytest.mark.parametrize('f,chw,ohw', DECONV_SHAPES)
+def test_metalearning_deconvupscale(f, chw, ohw):
+    """layers/metalearning_deconvupscale.py:13-16,28-30: conv2d_transpose(..., padding='SAME') per sample - forward, dK, dbias (through the
+    hyper-network's gradients), dx, d(dense input) against oracle/metalearning.mdeconv."""
     from oracle import metalearning as oml
-    from poisson_cnn_amd.metalearning import metalearning_deconvupscale, metalearning_resnet
+    from poisson_cnn_amd.metalearning import metalearning_deconvupscale
     rng = np.random.default_rng(32)
     N, Cin, F = 2, 5, 3
-    x, di = f32(rng.standard_normal((N, Cin, 7, 9))), f32(rng.standard_normal((N, F)))
-    up = metalearning_deconvupscale(3, 4, 3, dense_activations='tf.nn.tanh', pre_output_dense_units=[6, 8], seed=1)
-    shp = np.array([N, 4, 20, 26], dtype=np.int32)
+    x, di = f32(rng.standard_normal((N, Cin) + chw)), f32(rng.standard_normal((N, F)))
+    up = metalearning_deconvupscale(f, 4, f, dense_activations='tf.nn.tanh', pre_output_dense_units=[6, 8], seed=1)
+    shp = np.array([N, 4, ohw[0], ohw[1]], dtype=np.int32)
     up([dev(x), dev(di), shp])
     w = _ml_setup(up, rng)
-    _ml_check(up, w, lambda p, xt, dt: oml.mdeconv(p, 'metalearning_deconvupscale', xt, dt, 3, Cin, 4, ['tanh'] * 3, (20, 26)), x, di,
+    _ml_check(up, w, lambda p, xt, dt: oml.mdeconv(p, 'metalearning_deconvupscale', xt, dt, f, Cin, 4, ['tanh'] * 3, ohw), x, di,
               lambda: up([dev(x), dev(di), shp], training=True))
+
+
+def test_metalearning_deconvupscale_rejects_a_coarse_grid_that_is_not_same_padding():
+    """TensorFlow's conv2d_transpose raises when ceil(output / stride) != input (padding='SAME'); so does the library."""
+    from poisson_cnn_amd.metalearning import metalearning_deconvupscale
+    up = metalearning_deconvupscale(3, 4, 3, pre_output_dense_units=[6, 8], seed=1)
+    x, di = dev(f32(np.zeros((1, 5, 7, 9)))), dev(f32(np.zeros((1, 3))))
+    with pytest.raises(RuntimeError, match="SAME"):
+        up([x, di, np.array([1, 4, 22, 26], dtype=np.int32)])
+
+
+def test_metalearning_resnet():
+    from oracle import metalearning as oml
+    from poisson_cnn_amd.metalearning import metalearning_resnet
+    rng = np.random.default_rng(32)
+    N, F = 2, 3
+    di = f32(rng.standard_normal((N, F)))
     for use_bn in (False, True):
         x2 = f32(rng.standard_normal((N, 6, 15, 17)))
         blk = metalearning_resnet(6, 3, use_batchnorm=use_bn, padding_mode='SYMMETRIC', conv_activation='tf.nn.leaky_relu', dense_activations='tf.nn.tanh',
@@ -523,14 +548,15 @@ def test_metalearning_deconvupscale_and_resnet():
         _ml_check(blk, w, fn, x2, di, lambda: blk([dev(x2), dev(di)], training=True))
 
 
+@pytest.mark.parametrize('hw', [(18, 24), (22, 25)])       # (22, 25) / 3: coarse 8 x 9, SAME crop offset 1 in both axes of the transposed convolution
 @pytest.mark.parametrize('kind,method,use_resnet,use_bn', [('deconv', 'pool', True, True), ('deconv', 'conv', False, True), ('multilinear', 'conv', True, False),
                                                             ('multilinear', 'pool', False, True)])
-def test_metalearning_bottleneck_blocks(kind, method, use_resnet, use_bn):
+def test_metalearning_bottleneck_blocks(kind, method, use_resnet, use_bn, hw):
     from oracle import metalearning as oml
     from poisson_cnn_amd.metalearning import metalearning_bottleneck_block_deconvupsample, metalearning_bottleneck_block_multilinearupsample
     rng = np.random.default_rng(33)
     N, Cin, F = 2, 4, 3
-    x, di = f32(rng.standard_normal((N, Cin, 18, 24))), f32(rng.standard_normal((N, F)))
+    x, di = f32(rng.standard_normal((N, Cin) + hw)), f32(rng.standard_normal((N, F)))
     common = dict(ndims=2, downsampling_factor=3, filters=5, conv_kernel_size=3, n_convs=3, conv_padding_mode='SYMMETRIC', conv_conv_activation='tf.nn.leaky_relu',
                   conv_dense_activation='tf.nn.tanh', conv_pre_output_dense_units=[6, 8], use_resnet=use_resnet, downsampling_method=method,
                   conv_downsampling_kernel_size=5, pool_downsampling_method='average', use_batchnorm=use_bn, seed=4)

@@ -98,6 +98,75 @@ def test_bench_self_launches_two_ranks_end_to_end():
     assert 'gloo' in out['config']['collective'] and out['value'] > 0
 
 
+def _bare_bench(extra, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'launch-check', '--steps', '2', '--warmup', '1'] + extra,
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_self_launches_four_ranks_and_reports_the_ranks_it_saw():
+    """the bare N > 1 launch at world size 4 (gloo): one compact, parseable JSON line that states how many ranks the
+    process group itself saw."""
+    import json
+    r = _bare_bench(['--gpus', '4'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and len(lines[0]) < 3072, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 4 and out['config']['ranks_seen'] == 4 and out['config']['parallelism'] == 'dp4' and out['value'] > 0
+
+
+def test_bench_parent_returns_within_seconds_when_a_rank_dies_before_the_barrier():
+    """A rank that exits before its first barrier must not leave the others waiting in the rendezvous until the driver's limit: the parent
+    notices the exit, stops the other ranks, relays the failing rank's stderr and returns that rank's status."""
+    import time
+    t0 = time.monotonic()
+    r = _bare_bench(['--gpus', '3', '--fail-rank', '2', '--timeout', '900'], timeout=300)
+    took = time.monotonic() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert 'rank 2 exited with status 3' in r.stderr and '--fail-rank asked for this exit' in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]            # no result line from a failed run
+    assert took < 120, took                                                           # seconds (python + torch start-up), not the 900 s group timeout
+
+
+def test_bench_parent_enforces_the_launch_timeout():
+    import time
+    t0 = time.monotonic()
+    r = _bare_bench(['--gpus', '2', '--launch-timeout', '0.5'], timeout=120)
+    assert r.returncode == 124 and '--launch-timeout' in r.stderr
+    assert time.monotonic() - t0 < 60
+
+
+def test_compact_bench_line_from_a_recorded_full_result():
+    """round 3's bench line was 22 959 bytes and reached the driver cut off (parsed: null).  The compact line built from
+    that very record must parse, stay under the limit and still carry the contract's fields, `roofline` and `cpu_baseline`."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, 'profiles', 'r03_bench_c4.json')) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    full['detail_file'] = 'bench_detail.json'
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < bench.COMPACT_LIMIT <= 4096, len(line)
+    out = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in out, k
+    assert out['metric'] == full['metric'] and abs(out['value'] - full['value']) < 1e-3 and out['config']['workload'].startswith('c4')
+    rf = out['roofline']
+    assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0 and abs(rf['frac'] - full['roofline']['frac']) < 1e-4
+    assert rf['traffic'] == full['roofline']['traffic'] and rf['dominant_kernel']['name'].startswith('spec_mix')
+    assert abs(rf['hbm_bound_frac'] - full['roofline']['hbm_bound']['frac']) < 1e-4
+    cb = out['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] == 16 and cb['value'] > 0 and 'sample' in cb
+    assert out['c3']['value'] > 100 and out['split_f16']['fwd_rel_l2'] < 1e-5 and out['dataset']['value'] > 1e4
+
+
 def test_global_metrics_are_identical_on_all_ranks():
     """callbacks must see the GLOBAL loss.  Two ranks with different local (loss share, mse) get the same pair back."""
     ctx = mp.get_context('spawn')

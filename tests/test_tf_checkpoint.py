@@ -144,6 +144,14 @@ def test_hpnn_checkpoint_uses_the_reference_object_paths(tmp_path):
     T.write_bundle(str(d / 'short'), t)
     with pytest.raises(ValueError, match='post_merge_conv/kernel'):
         m2.load_weights(str(d / 'short'))
+    # a variable with the right element count but another layout (Cin / Cout swapped) must be refused, not reshaped
+    t = T.read_bundle(str(d / 'chkpt.checkpoint'))
+    key = 'final_convolutions/4/kernel' + T.SUFFIX                  # final/stage2/conv: (9, 9, 28, 24)
+    assert t[key].shape == (9, 9, 28, 24)
+    t[key] = np.ascontiguousarray(t[key].transpose(0, 1, 3, 2))
+    T.write_bundle(str(d / 'swapped'), t)
+    with pytest.raises(ValueError, match=r'\(9, 9, 24, 28\)'):
+        m2.load_weights(str(d / 'swapped'))
 
 
 def test_dbcnn_and_pcnn_checkpoints_use_the_reference_object_paths(tmp_path):
