@@ -791,6 +791,13 @@ def grouped_conv2d_wgrad(x, dz, w_shape, dw_all, *, pad_top, pad_left, pad_mode=
     return dw_all
 
 
+def grouped_uses_mfma(x_shape, w_shape, out_hw, what='fwd'):
+    """True when pcnn_grouped_conv2d_fwd (what = 'fwd': forward / data gradient) or _wgrad ('wgrad') takes the matrix-core route
+    (v_mfma_f32_4x4x1_16B_f32 grouped implicit GEMM) for this shape, False for the vector-ALU kernels (PCNN_GROUPED_VALU=1 forces those)."""
+    d = conv_desc(x_shape, x_shape[3], w_shape, out_hw, w_shape[3], 0, 0, 'CONSTANT', 0.0)
+    return bool(_lib.load().pcnn_grouped_conv2d_uses_mfma(byref(d), c_int(0 if what == 'fwd' else 1)))
+
+
 def grouped_bias_grad(dz, dbias_all):
     N, H, W, C = dz.shape
     handle().call('pcnn_grouped_bias_grad', c_int(N), ctypes.c_longlong(H * W), c_int(C), _p(dz), c_int(_ld(dz)), _p(dbias_all), ctypes.c_longlong(_row_stride(dbias_all)))

@@ -13,9 +13,60 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
+@pytest.fixture(params=['mfma', 'valu'])
+def route(request):
+    """Both implementations of the per-sample-filter convolution: the matrix-core grouped implicit GEMM (the default wherever the shape
+    allows it) and the vector-ALU kernels (PCNN_GROUPED_VALU=1; the library reads the variable at every call)."""
+    import os
+    if request.param == 'valu':
+        os.environ['PCNN_GROUPED_VALU'] = '1'
+    yield request.param
+    os.environ.pop('PCNN_GROUPED_VALU', None)
+
+
+# (k, Cin, Cout, H, W, padding): the reference's example layer (19 x 19, 3 -> 4, layers/metalearning_conv.py:171-184), the layer shapes of
+# configs.hpnn_metalearning(), odd / even / padded channel counts (Cin = 6 -> 8 lanes, Cout = 6 -> two register quads), ragged tile edges,
+# more than 64 K steps per filter row (two B registers in the weight gradient), even filter sizes, a 1-row image
+MFMA_SHAPES = [(19, 3, 4, 70, 93, 'CONSTANT'), (17, 4, 6, 50, 66, 'SYMMETRIC'), (15, 6, 8, 33, 130, 'REFLECT'), (13, 8, 8, 64, 64, 'CONSTANT'),
+               (7, 8, 6, 41, 29, 'SYMMETRIC'), (5, 1, 3, 23, 71, 'CONSTANT'), (4, 2, 5, 37, 65, 'REFLECT'), (3, 16, 7, 9, 200, 'CONSTANT'),
+               (11, 5, 1, 30, 30, 'SYMMETRIC'), (2, 7, 8, 1, 77, 'CONSTANT')]
+
+
+@pytest.mark.parametrize('k,Cin,Cout,H,W,mode', MFMA_SHAPES)
+def test_grouped_conv_mfma_route_matches_the_oracle(k, Cin, Cout, H, W, mode):
+    """The matrix-core route (forward, data gradient through the flipped / transposed pack, filter gradient) against fp64 torch autograd of
+    the oracle's padded convolution, sample by sample."""
+    from oracle import torch_twin as T
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(1000 * k + 10 * Cin + Cout)
+    N = 3
+    nk = k * k * Cin * Cout
+    wshape = (k, k, Cin, Cout)
+    pt, pb = k // 2, k // 2 - (1 - k % 2)
+    assert ops.grouped_uses_mfma((N, H, W, Cin), wshape, (H, W), 'fwd') and ops.grouped_uses_mfma((N, H, W, Cin), wshape, (H, W), 'wgrad')
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+    kb = torch.randn(N, nk + Cout, device='cuda', generator=g) / np.sqrt(k * k * Cin)
+    dz = torch.randn(N, H, W, Cout, device='cuda', generator=g)
+    y = ops.grouped_conv2d_fwd(x, kb, wshape, kb[:, nk:], pad_top=pt, pad_left=pt, out_hw=(H, W), pad_mode=mode, pad_value=0.25, act='tanh')
+    dkb = torch.zeros_like(kb)
+    ops.grouped_conv2d_wgrad(x, dz, wshape, dkb, pad_top=pt, pad_left=pt, pad_mode=mode, pad_value=0.25)
+    # data gradient of the LINEAR layer w.r.t. the padded input (the layers fold the padding afterwards): full correlation with the flipped filter
+    gp = ops.grouped_conv2d_fwd(dz, kb, wshape, None, pad_top=k - 1, pad_left=k - 1, out_hw=(H + k - 1, W + k - 1), flip_transpose=True)
+    xt = x.double().cpu().permute(0, 3, 1, 2)
+    kt = kb.double().cpu().requires_grad_(True)
+    dzt = dz.double().cpu().permute(0, 3, 1, 2)
+    for n in range(N):
+        xp = T.pad2d(xt[n:n + 1], ((pt, pb), (pt, pb)), mode, 0.25).requires_grad_(True)
+        z = T.conv2d_valid(xp, kt[n, :nk].reshape(*wshape), kt[n, nk:])
+        (z * dzt[n:n + 1]).sum().backward()
+        assert rel(y[n].cpu().permute(2, 0, 1), torch.tanh(z.detach())[0]) < 2e-6
+        assert rel(gp[n].cpu().permute(2, 0, 1), xp.grad[0]) < 2e-6
+    assert rel(dkb.cpu()[:, :nk], kt.grad[:, :nk]) < 5e-6
+
+
 @pytest.mark.parametrize('k,Cin,Cout,H,W,mode,act', [(5, 3, 4, 40, 37, 'CONSTANT', 'leaky_relu'), (19, 3, 4, 50, 61, 'SYMMETRIC', 'tanh'), (4, 6, 8, 33, 45, 'REFLECT', 'linear'),
                                                       (13, 8, 8, 64, 64, 'CONSTANT', 'leaky_relu'), (3, 20, 17, 30, 70, 'SYMMETRIC', 'linear'), (7, 5, 32, 41, 29, 'CONSTANT', 'tanh')])
-def test_grouped_conv_matches_per_sample_launches(k, Cin, Cout, H, W, mode, act):
+def test_grouped_conv_matches_per_sample_launches(k, Cin, Cout, H, W, mode, act, route):
     from poisson_cnn_amd import ops
     g = torch.Generator(device='cuda').manual_seed(k * 100 + Cin)
     N = 5
