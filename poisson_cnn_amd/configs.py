@@ -162,6 +162,19 @@ def hpnn_metalearning():
     return {'model': model, 'dataset': base['dataset'], 'training': base['training']}
 
 
+def dbcnn_metalearning_main():
+    """Constructor arguments of the reference's own example of Dirichlet_BC_NN_Metalearning (models/Dirichlet_BC_NN_Metalearning.py:219-250, run there
+    with batch 10 on a 101 x 75 grid, :211-213) - the only configuration of that model the reference holds."""
+    bccfg = {'filters': [4, 8, 16, 22], 'kernel_sizes': [19, 17, 15, 13, 11], 'padding_mode': 'SYMMETRIC', 'conv_activation': 'tf.nn.tanh',
+             'dense_activations': ['linear', 'linear', 'linear'], 'pre_output_dense_units': [16, 32], 'use_layernorm': True, 'use_bias': True}
+    sppcfg = {'levels': [[2], 3, 5, 8], 'pooling_type': 'average'}
+    mlpcfg = {'units': [250, 125, 22], 'activations': ['tf.nn.leaky_relu', 'tf.nn.leaky_relu', 'softmax']}
+    fccfg = {'filters': [32, 16, 8, 4, 2, 1], 'kernel_sizes': [7, 5, 3, 3, 3, 3], 'padding_mode': 'CONSTANT', 'constant_padding_value': 0.0,
+             'final_regular_conv_stages': 3, 'use_bias': True}
+    return dict(ndims=2, data_format='channels_first', boundary_conv_config=bccfg, spp_config=sppcfg, domain_info_mlp_config=mlpcfg,
+                final_convolutions_config=fccfg, postsmoother_iterations=0, use_batchnorm=True)
+
+
 def hpnn_metalearning_tiny():
     cfg = hpnn_metalearning()
     m = cfg['model']

@@ -197,11 +197,15 @@ class Homogeneous_Poisson_NN_Metalearning(_ChainModel):
     def _forward_body(self, x, d, training):
         for lyr in self.pre:
             x = lyr.forward(x, training) if isinstance(lyr, M._BatchNorm) else lyr.forward(x, d, training)
-        initial = x
-        res = self.bottleneck_blocks[0].forward(initial, d, training)
-        for b in self.bottleneck_blocks[1:]:
-            res = b.forward(torch.cat([initial, res], 3), d, training)               # tf.concat axis=1 (:249, :253)
-        o = torch.cat([initial, res], 3)                                             # :256
+        initial, c0 = x, self.c0
+        N, H, W, _ = initial.shape
+        inp = initial
+        for b in self.bottleneck_blocks:            # tf.concat([initial, result], axis=1) (:249, :253, :256): every block writes its result IN PLACE
+            cat = ops.empty((N, H, W, c0 + self.F), initial.device)      # next to a copy of `initial` (one buffer per block: each is a saved input)
+            ops.axpby(1.0, initial, 0.0, cat[..., :c0])
+            b.forward(inp, d, training, out=cat[..., c0:])
+            inp = cat
+        o = inp
         for lyr in self.final_meta:
             o = lyr.forward(o, d, training)
         for lyr in self.final_regular:

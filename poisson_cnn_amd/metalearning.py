@@ -281,10 +281,10 @@ class _BatchNorm:
         self.store, self.ctx, self.c = store, ctx, c
         self.off = store.add_bn(name, c)
 
-    def forward(self, a, training=True):
+    def forward(self, a, training=True, out=None):
         s = self.store
         self.saved = a if training else None
-        return ops.channel_affine(a, s.bn_scale[self.off:self.off + self.c], s.bn_shift[self.off:self.off + self.c])
+        return ops.channel_affine(a, s.bn_scale[self.off:self.off + self.c], s.bn_shift[self.off:self.off + self.c], out=out)
 
     def backward(self, dy):
         s = self.store
@@ -483,14 +483,18 @@ class metalearning_bottleneck_block_deconvupsample(_metalearning_bottleneck):
         if self.own_store:
             self.finalize()
 
-    def forward(self, x, dense_input, training=True):
+    def forward(self, x, dense_input, training=True, out=None):
+        """out: optional NHWC destination, possibly a channel slice of a wider buffer (the chained models write a block's result next to the
+        tensor it is concatenated with instead of copying both, models/Homogeneous_Poisson_NN_Metalearning.py:249-256)."""
         if not self.built:
             self.build(x.shape[3], dense_input.shape[1])
         if self.own_store:
             self._pre()
         o = self._down_and_stages(x, dense_input, training)
         o = self.upsample.forward(o, dense_input, self.out_hw(x.shape[1], x.shape[2]), training)
-        return self.bn.forward(o, training) if self.bn is not None else o
+        if self.bn is not None:
+            return self.bn.forward(o, training, out=out)
+        return o if out is None else ops.axpby(1.0, o, 0.0, out)
 
     def backward(self, dy):
         d = self.bn.backward(dy) if self.bn is not None else dy
@@ -524,14 +528,15 @@ class metalearning_bottleneck_block_multilinearupsample(_metalearning_bottleneck
         if self.own_store:
             self.finalize()
 
-    def forward(self, x, dense_input, training=True):
+    def forward(self, x, dense_input, training=True, out=None):
+        """out: optional NHWC destination (a channel slice of a wider buffer is fine: the resize kernel takes the channel stride)."""
         if not self.built:
             self.build(x.shape[3], dense_input.shape[1])
         if self.own_store:
             self._pre()
         o = self._down_and_stages(x, dense_input, training)
         self._coarse = (o.shape[1], o.shape[2])
-        return ops.resize_fwd(o, self.out_hw(x.shape[1], x.shape[2]), 'bilinear')
+        return ops.resize_fwd(o, self.out_hw(x.shape[1], x.shape[2]), 'bilinear', out=out)
 
     def backward(self, dy):
         d = ops.resize_bwd(dy, self._coarse, 'bilinear')

@@ -775,6 +775,16 @@ def grouped_conv2d_fwd(x, w_all, w_shape, bias_all=None, *, pad_top, pad_left, o
     Ho, Wo = out_hw
     y = out if out is not None else empty((N, Ho, Wo, Cout), x.device)
     d = conv_desc(x.shape, _ld(x), (kh, kw, Cin, Cout), (Ho, Wo), _ld(y), pad_top, pad_left, pad_mode, pad_value, act)
+    if _grouped_per_sample(d, 0):
+        # wide layers (beyond the grouped kernels' 32 output channels / 31 taps, or wide enough that the ordinary kernels - spectral route, 32-wide
+        # implicit GEMM - are the faster machine): one ordinary launch per sample with that sample's filter.  ADVICE r3: no channel count fails.
+        nk = kh * kw * Cin * Cout
+        for n in range(N):
+            wn = w_all[n, :nk].view(kh, kw, a, b)
+            wn = flip_transpose_weights(wn) if flip_transpose else wn
+            conv2d_fwd(x[n:n + 1], wn, bias_all[n] if bias_all is not None else None, pad_top=pad_top, pad_left=pad_left, out_hw=(Ho, Wo), pad_mode=pad_mode,
+                       pad_value=pad_value, act=act, out=y[n:n + 1])
+        return y
     handle().call('pcnn_grouped_conv2d_fwd', byref(d), _p(x), _p(w_all), ctypes.c_longlong(_row_stride(w_all)), _p(bias_all),
                   ctypes.c_longlong(_row_stride(bias_all) if bias_all is not None else 0), c_int(1 if flip_transpose else 0), _p(y))
     return y
@@ -784,11 +794,32 @@ def grouped_conv2d_wgrad(x, dz, w_shape, dw_all, *, pad_top, pad_left, pad_mode=
     """dw_all[n] (a row of the (N, F) gradient matrix) = filter gradient of sample n, one launch (+ a fixed-order reduction)."""
     kh, kw, Cin, Cout = w_shape
     d = conv_desc(x.shape, _ld(x), w_shape, (dz.shape[1], dz.shape[2]), _ld(dz), pad_top, pad_left, pad_mode, pad_value)
+    if _grouped_per_sample(d, 1):
+        nk = kh * kw * Cin * Cout
+        for n in range(x.shape[0]):
+            conv2d_wgrad(x[n:n + 1], dz[n:n + 1], w_shape, pad_top=pad_top, pad_left=pad_left, pad_mode=pad_mode, pad_value=pad_value,
+                         out=dw_all[n, :nk].view(kh, kw, Cin, Cout), ws=ws)
+        return dw_all
     lib = _lib.load()
     lib.pcnn_grouped_conv2d_wgrad_workspace.restype = c_size_t
     wsb = (ws or _default_ws).get(lib.pcnn_grouped_conv2d_wgrad_workspace(byref(d)), x.device)
     handle().call('pcnn_grouped_conv2d_wgrad', byref(d), _p(x), _p(dz), _p(dw_all), ctypes.c_longlong(_row_stride(dw_all)), _p(wsb))
     return dw_all
+
+
+def _grouped_per_sample(d, what):
+    """True when a per-sample-filter layer leaves the grouped kernels for one ordinary launch per sample: shapes beyond the grouped vector-ALU
+    kernels' limits (csrc/grouped_conv.hip: <= 32 output channels and <= 31 taps forward; Cin Cout <= 4096 and a 64 KB staging tile in the
+    filter gradient), and layers that are not eligible for the matrix-core grouped kernel but wide enough (Cin Cout >= 256) that the
+    ordinary kernels' matrix-core / spectral routes beat ~6 TFLOP/s of scalar FMAs (tools/bench_grouped.py: 7 x 7, 32 -> 32 at 10 x 200^2:
+    6.3 ms grouped)."""
+    if _lib.load().pcnn_grouped_conv2d_uses_mfma(byref(d), c_int(what)):
+        return False
+    if d.Cin * d.Cout >= 256 and not __import__('os').environ.get('PCNN_GROUPED_VALU'):     # (the developer switch keeps everything it can on the vector-ALU kernels)
+        return True
+    if what == 0:
+        return d.Cout > 32 or d.kh > 31 or d.kw > 31
+    return d.Cin * d.Cout > 4096 or ((128 + d.kw - 1) * d.Cin + 128 * d.Cout) * 4 > 64 * 1024
 
 
 def grouped_uses_mfma(x_shape, w_shape, out_hw, what='fwd'):

@@ -99,6 +99,34 @@ def test_grouped_conv_matches_per_sample_launches(k, Cin, Cout, H, W, mode, act,
         ops.set_spectral_mode('auto')
 
 
+@pytest.mark.parametrize('k,Cin,Cout,H,W', [(3, 6, 40, 20, 30), (5, 40, 6, 17, 33), (7, 32, 32, 40, 40)])
+def test_wide_per_sample_layers_leave_the_grouped_kernels(k, Cin, Cout, H, W):
+    """channel counts beyond the grouped kernels' limits (more than 32 output channels - in the data-gradient call that is the
+    forward layer's INPUT width) must not fail, and wide layers take the ordinary kernels, one launch per sample: forward, data gradient
+    and filter gradient against fp64 autograd."""
+    import torch.nn.functional as F
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(k + Cin)
+    N = 3
+    nk = k * k * Cin * Cout
+    wshape = (k, k, Cin, Cout)
+    pt = k // 2
+    x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
+    kb = torch.randn(N, nk + Cout, device='cuda', generator=g) / np.sqrt(k * k * Cin)
+    dz = torch.randn(N, H, W, Cout, device='cuda', generator=g)
+    y = ops.grouped_conv2d_fwd(x, kb, wshape, kb[:, nk:], pad_top=pt, pad_left=pt, out_hw=(H, W), act='leaky_relu')
+    dkb = torch.zeros_like(kb)
+    ops.grouped_conv2d_wgrad(x, dz, wshape, dkb, pad_top=pt, pad_left=pt)
+    gx = ops.grouped_conv2d_fwd(dz, kb, wshape, None, pad_top=k - 1 - pt, pad_left=k - 1 - pt, out_hw=(H, W), flip_transpose=True)
+    xt = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    kt = kb.double().cpu().requires_grad_(True)
+    z = torch.cat([F.conv2d(xt[n:n + 1], kt[n, :nk].reshape(*wshape).permute(3, 2, 0, 1), kt[n, nk:], padding=pt) for n in range(N)], 0)
+    (z * dz.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    assert rel(y.cpu().permute(0, 3, 1, 2), F.leaky_relu(z.detach(), 0.2)) < 2e-6
+    assert rel(gx.cpu().permute(0, 3, 1, 2), xt.grad) < 2e-6
+    assert rel(dkb.cpu()[:, :nk], kt.grad[:, :nk]) < 5e-6
+
+
 def test_grouped_one_dimensional_layer():
     """A 1-D convolution is kh = 1: what layers/metalearning_conv.py does with tf.nn.conv1d (dimensions = 1)."""
     import torch.nn.functional as F

@@ -1,5 +1,9 @@
-"""Times full training steps of the two 'next row' models on their shipped configurations (experiments/dbcnn.json: batch 50,
-experiments/pcnn_end_to_end.json: batch 5; grids of 288 x 288, the middle of the configs' 192...384 range) with on-device data."""
+"""Times full training steps of the 'next row' models on their shipped configurations (experiments/dbcnn.json: batch 50,
+experiments/pcnn_end_to_end.json: batch 5; grids of 288 x 288, the middle of the configs' 192...384 range) with on-device data, and of the two
+metalearning models on the only configurations the reference holds for them: Homogeneous_Poisson_NN_Metalearning with the
+hyper-parameters of its own example (models/Homogeneous_Poisson_NN_Metalearning.py:334-377 = configs.hpnn_metalearning()) at hpnn.json's batch
+size on 288 x 288 and 200 x 200 grids, Dirichlet_BC_NN_Metalearning at its __main__ block's batch 10 on 101 x 75 (:211-250).
+PCNN_GROUPED_VALU=1 times the metalearning models on the round-3 vector-ALU kernels (the matrix-core grouped kernels are the default)."""
 import os
 import sys
 import time
@@ -71,5 +75,42 @@ def main():
     print('Poisson_CNN_Legacy inference as ONE hipGraph replay, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, W, 1e3 * t, N / t))
 
 
+def metalearning():
+    from poisson_cnn_amd.hpnn_models import Homogeneous_Poisson_NN_Metalearning
+    from poisson_cnn_amd.dbcnn_models import Dirichlet_BC_NN_Metalearning
+    route = 'vector-ALU grouped kernels (PCNN_GROUPED_VALU)' if os.environ.get('PCNN_GROUPED_VALU') else 'matrix-core grouped kernels'
+    g = torch.Generator().manual_seed(1)
+    cfg = configs.hpnn_metalearning()
+    mc = {k: v for k, v in cfg['model'].items() if k != 'model_type'}
+    for N, H in ((cfg['dataset']['batch_size'], 288), (10, 200)):
+        model = Homogeneous_Poisson_NN_Metalearning(**mc)
+        model.compile(loss=loss_wrapper(global_batch_size=N, **cfg['training']['loss_parameters']), optimizer=Adam(**cfg['training']['optimizer_parameters']))
+        rhs = (torch.rand(N, 1, H, H, generator=g) * 2 - 1).cuda()
+        dx = (torch.rand(N, 1, generator=g) * 4.5e-2 + 5e-3).cuda()
+        tgt = (torch.randn(N, 1, H, H, generator=g) * 0.1).cuda()
+        t = timeit(lambda: model.train_step(((rhs, dx), tgt)))
+        print('Homogeneous_Poisson_NN_Metalearning (%d params, %s): train step, %d x %dx%d: %.1f ms -> %.1f grids/s' % (model.count_params(), route, N, H, H, 1e3 * t, N / t))
+        t = timeit(lambda: model([rhs, dx]))
+        print('Homogeneous_Poisson_NN_Metalearning inference, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, H, H, 1e3 * t, N / t))
+        del model
+    N, nx, ny = 10, 101, 75
+    model = Dirichlet_BC_NN_Metalearning(**configs.dbcnn_metalearning_main())
+    lossp = dict(configs.dbcnn()['training']['loss_parameters'])
+    model.compile(loss=loss_wrapper(global_batch_size=N, **lossp), optimizer=Adam(learning_rate=1e-4))
+    bc = torch.cumsum(torch.randn(N, 1, ny, generator=g) * 0.1, 2).cuda()
+    dx = (torch.rand(N, 1, generator=g) * 4.5e-2 + 5e-3).cuda()
+    dx2 = dx.repeat(1, 2).contiguous()
+    tgt = (torch.randn(N, 1, nx, ny, generator=g) * 0.1).cuda()
+    model([bc, dx2, nx])
+    t = timeit(lambda: model.train_step(((bc, dx), tgt)))
+    print('Dirichlet_BC_NN_Metalearning (__main__ configuration, %d params, %s): train step, %d x %dx%d: %.1f ms -> %.1f grids/s' % (model.count_params(), route, N, nx, ny, 1e3 * t, N / t))
+    t = timeit(lambda: model([bc, dx2, nx]))
+    print('Dirichlet_BC_NN_Metalearning inference, %d x %dx%d: %.1f ms -> %.1f grids/s' % (N, nx, ny, 1e3 * t, N / t))
+
+
 if __name__ == '__main__':
-    main()
+    if 'metalearning' in sys.argv[1:]:
+        metalearning()
+    else:
+        main()
+        metalearning()
