@@ -238,7 +238,7 @@ int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo,
  *   _fwd    flip_transpose = 0: y = act(conv(pad(x), w_n) + b_n).  flip_transpose = 1: the same kernel as the DATA gradient - x is dz, the
  *           stored filter is the forward filter (kh,kw,Cout_of_this_call,Cin_of_this_call), read flipped and transposed.
  *   _wgrad  dw_n = filter gradient of sample n (not summed over the batch); workspace: pcnn_grouped_conv2d_wgrad_workspace(d) bytes.
- *   Routes: layers of <= 8 output and <= 16 input channels (every layer of the reference's metalearning configurations) run as a GROUPED
+ *   Routes: layers of <= 16 output and <= 16 input channels (every layer of the reference's metalearning configurations) run as a GROUPED
  *   IMPLICIT GEMM on the matrix cores (v_mfma_f32_4x4x1_16B_f32: 4 output channels x 64 pixels x one (tap, channel) step per instruction,
  *   exact fp32, the filter of sixteen K steps in one register through the instruction's A-broadcast); wider layers on the vector ALUs.
  *   pcnn_grouped_conv2d_uses_mfma(d, what) reports the route (what = 0: _fwd, 1: _wgrad); environment PCNN_GROUPED_VALU=1 forces the

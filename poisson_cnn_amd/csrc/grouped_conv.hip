@@ -388,16 +388,16 @@ constexpr int GWR = 16, GWC = 64;
 struct GmWgradParams {
   const float* x; const float* dz; float* part;
   int N, H, W, Cin, ldx, Ho, Wo, Cout, lddz, kh, kw, pt, pl, pad_mode; float pad_value;
-  int S, nout, XRS, tiles_x, tiles;               // S workgroups per sample; XRS: floats per staged input row; tiles per sample
+  int S, nout, XRS, tiles_x, tiles, GR;           // S workgroups per sample; XRS: floats per staged input row; tiles per sample; rows per tile
 };
 
 template <int NI, int MC, int CO4>
 __global__ __launch_bounds__(256) void gm_wgrad_kernel(GmWgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int COP = 4 * CO4;
-  const int TR = GWR + p.kh - 1;
+  const int GR = p.GR, TR = GR + p.kh - 1;          // GR output rows per tile (16, or 8 when the staged rows are long)
   float* xs = lds;                                  // [TR][XRS]
-  float* zs = lds + TR * p.XRS;                     // [GWR][GWC][COP]
+  float* zs = lds + TR * p.XRS;                     // [GR][GWC][COP]
   const int s = blockIdx.x, n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i0 = wave * NI;
@@ -413,8 +413,8 @@ __global__ __launch_bounds__(256) void gm_wgrad_kernel(GmWgradParams p) {
   const int xw = (GWC + p.kw - 1) * p.Cin;          // meaningful floats of a staged input row
   for (int t = s; t < p.tiles; t += p.S) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const int y0 = ty * GWR, x0 = tx * GWC;
-    const int rows = min(GWR, p.Ho - y0);
+    const int y0 = ty * GR, x0 = tx * GWC;
+    const int rows = min(GR, p.Ho - y0);
     __syncthreads();                                // the previous tile's readers are done
     for (int rr = wave; rr < rows + p.kh - 1; rr += 4) {
       const int sy = pcnn_pad_index(y0 + rr - p.pt, p.H, p.pad_mode);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void gm_wgrad_kernel(GmWgradParams p) {
         if (ci >= p.Cin) { ci -= p.Cin; ++px; }
       }
     }
-    for (int e = threadIdx.x; e < GWR * GWC * COP; e += 256) {
+    for (int e = threadIdx.x; e < GR * GWC * COP; e += 256) {
       const int co = e % COP, px = (e / COP) % GWC, rr = e / (COP * GWC);
       zs[e] = (rr < rows && x0 + px < p.Wo && co < p.Cout) ? dzn[((int64_t)(y0 + rr) * p.Wo + x0 + px) * p.lddz + co] : 0.f;
     }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void gm_wgrad_kernel(GmWgradParams p) {
       for (int a = 0; a < NI; ++a) {
         const int ry = Y - (i0 + a);
         ok[a] = i0 + a < p.kh && ry >= 0 && ry < rows;                           // wave-uniform; the load below is unconditional (clamped row)
-        zoff[a] = (min(max(ry, 0), GWR - 1) * GWC + (lane >> 2)) * COP + (lane & 3);
+        zoff[a] = (min(max(ry, 0), GR - 1) * GWC + (lane >> 2)) * COP + (lane & 3);
       }
 #pragma unroll 1
       for (int xc = 0; xc < GWC / 16; ++xc) {
@@ -502,29 +502,33 @@ static GmFwdPlan gm_fwd_plan(const pcnn_conv_desc* d) {
   GmFwdPlan q{};
   q.ok = false;
   if (getenv("PCNN_GROUPED_VALU")) return q;                       // developer switch: the vector-ALU kernels only (A/B timing, tests of both routes)
-  if (d->Cout > 8 || d->Cin > 16) return q;
+  if (d->Cout > 16 || d->Cin > 16) return q;
   if (d->Cin & 1) { q.CP = 0; q.C = d->Cin; q.PS = d->Cin; q.vstride = 16; }
   else { q.CP = 2; while (q.CP < d->Cin) q.CP *= 2; q.C = q.CP; q.PS = q.CP + 1; q.vstride = (16 / q.CP) * q.PS; }
   q.MV = pcnn_cdiv(d->kw * q.C, 16);
   q.RS = std::max((64 + d->kw - 1) * q.PS, 63 * q.PS + q.MV * q.vstride);
-  q.CO4 = pcnn_cdiv(d->Cout, 4);
+  q.CO4 = d->Cout <= 4 ? 1 : (d->Cout <= 8 ? 2 : 4);                  // register quads per pixel (12 channels ride in 4 quads, the filter's 4th is zero)
   q.lds = (size_t)(GMR + d->kh - 1) * q.RS * sizeof(float);
   q.ok = q.lds <= 128 * 1024;
   return q;
 }
-struct GmWgradPlan { bool ok; int NI, MC, CO4, XRS, tiles_x, tiles, S; size_t lds; };
+struct GmWgradPlan { bool ok; int NI, MC, CO4, XRS, tiles_x, tiles, S, GR; size_t lds; };
 static GmWgradPlan gm_wgrad_plan(const pcnn_conv_desc* d) {
   GmWgradPlan q{};
   q.ok = false;
   if (getenv("PCNN_GROUPED_VALU")) return q;
-  if (d->Cout > 8 || d->kh > 20 || d->kw * d->Cin > 128) return q;
+  if (d->Cout > 16 || d->kh > 20 || d->kw * d->Cin > 192) return q;
   q.NI = pcnn_cdiv(d->kh, 4);
-  q.MC = pcnn_cdiv(d->kw * d->Cin, 64); q.CO4 = pcnn_cdiv(d->Cout, 4);
+  q.MC = pcnn_cdiv(d->kw * d->Cin, 64); q.CO4 = d->Cout <= 4 ? 1 : (d->Cout <= 8 ? 2 : 4);
+  if (q.NI * q.MC * q.CO4 > 20) return q;                            // accumulator quads per wave (80 registers)
   q.XRS = std::max((GWC + d->kw - 1) * d->Cin, (GWC - 1) * d->Cin + 64 * q.MC);
-  q.tiles_x = pcnn_cdiv(d->Wo, GWC); q.tiles = q.tiles_x * pcnn_cdiv(d->Ho, GWR);
+  for (q.GR = GWR; q.GR >= 4; q.GR /= 2) {                          // output rows per tile: as many as fit (the wave's NI - 1 extra input rows amortise over them)
+    q.lds = ((size_t)(q.GR + d->kh - 1) * q.XRS + (size_t)q.GR * GWC * 4 * q.CO4) * sizeof(float);
+    if (q.lds <= 128 * 1024) break;
+  }
+  q.tiles_x = pcnn_cdiv(d->Wo, GWC); q.tiles = q.tiles_x * pcnn_cdiv(d->Ho, q.GR);
   q.S = std::min(q.tiles, 64);
-  q.lds = ((size_t)(GWR + d->kh - 1) * q.XRS + (size_t)GWR * GWC * 4 * q.CO4) * sizeof(float);
-  q.ok = q.lds <= 128 * 1024;
+  q.ok = q.GR >= 4 && q.lds <= 128 * 1024;
   return q;
 }
 
@@ -545,9 +549,11 @@ static void gm_fwd_launch(int CO4, dim3 grid, size_t lds, hipStream_t st, const 
   if (lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gm_fwd_kernel<CP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gm_fwd_kernel<CP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gm_fwd_kernel<CP, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   if (CO4 == 1) hipLaunchKernelGGL((gm_fwd_kernel<CP, 1>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((gm_fwd_kernel<CP, 2>), grid, dim3(256), lds, st, p);
+  else if (CO4 == 2) hipLaunchKernelGGL((gm_fwd_kernel<CP, 2>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gm_fwd_kernel<CP, 4>), grid, dim3(256), lds, st, p);
 }
 
 extern "C" int pcnn_grouped_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, long long w_sample_stride, const float* bias,
@@ -608,19 +614,24 @@ extern "C" int pcnn_grouped_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d,
     g.x = x; g.dz = dz; g.part = static_cast<float*>(workspace);
     g.N = d->N; g.H = d->H; g.W = d->W; g.Cin = d->Cin; g.ldx = d->ldx; g.Ho = d->Ho; g.Wo = d->Wo; g.Cout = d->Cout; g.lddz = d->ldy;
     g.kh = d->kh; g.kw = d->kw; g.pt = d->pad_top; g.pl = d->pad_left; g.pad_mode = d->pad_mode; g.pad_value = d->pad_value;
-    g.S = q.S; g.nout = nout; g.XRS = q.XRS; g.tiles_x = q.tiles_x; g.tiles = q.tiles;
+    g.S = q.S; g.nout = nout; g.XRS = q.XRS; g.tiles_x = q.tiles_x; g.tiles = q.tiles; g.GR = q.GR;
     const dim3 grid((unsigned)q.S, (unsigned)d->N);
 #define GM_WLAUNCH(NIv, MCv, COv)                                                                                                \
     do {                                                                                                                         \
       if (q.lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gm_wgrad_kernel<NIv, MCv, COv>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds); \
       hipLaunchKernelGGL((gm_wgrad_kernel<NIv, MCv, COv>), grid, dim3(256), q.lds, h->stream, g);                                \
     } while (0)
+#define GM_WLAUNCH_MC(NIv, MCv)                                                   \
+    do {                                                                          \
+      if constexpr ((NIv) * (MCv) * 1 <= 20) { if (q.CO4 == 1) GM_WLAUNCH(NIv, MCv, 1); } \
+      if constexpr ((NIv) * (MCv) * 2 <= 20) { if (q.CO4 == 2) GM_WLAUNCH(NIv, MCv, 2); } \
+      if constexpr ((NIv) * (MCv) * 4 <= 20) { if (q.CO4 == 4) GM_WLAUNCH(NIv, MCv, 4); } \
+    } while (0)
 #define GM_WLAUNCH_NI(NIv)                                  \
     do {                                                    \
-      if (q.MC == 1 && q.CO4 == 1) GM_WLAUNCH(NIv, 1, 1);   \
-      else if (q.MC == 1) GM_WLAUNCH(NIv, 1, 2);            \
-      else if (q.CO4 == 1) GM_WLAUNCH(NIv, 2, 1);           \
-      else GM_WLAUNCH(NIv, 2, 2);                           \
+      if (q.MC == 1) GM_WLAUNCH_MC(NIv, 1);                 \
+      else if (q.MC == 2) GM_WLAUNCH_MC(NIv, 2);            \
+      else GM_WLAUNCH_MC(NIv, 3);                           \
     } while (0)
     switch (q.NI) {
       case 1: GM_WLAUNCH_NI(1); break;
@@ -629,6 +640,7 @@ extern "C" int pcnn_grouped_conv2d_wgrad(pcnn_handle h, const pcnn_conv_desc* d,
       case 4: GM_WLAUNCH_NI(4); break;
       default: GM_WLAUNCH_NI(5); break;
     }
+#undef GM_WLAUNCH_MC
 #undef GM_WLAUNCH_NI
 #undef GM_WLAUNCH
     GroupedWgradParams r;

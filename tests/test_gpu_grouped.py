@@ -29,7 +29,8 @@ def route(request):
 # more than 64 K steps per filter row (two B registers in the weight gradient), even filter sizes, a 1-row image
 MFMA_SHAPES = [(19, 3, 4, 70, 93, 'CONSTANT'), (17, 4, 6, 50, 66, 'SYMMETRIC'), (15, 6, 8, 33, 130, 'REFLECT'), (13, 8, 8, 64, 64, 'CONSTANT'),
                (7, 8, 6, 41, 29, 'SYMMETRIC'), (5, 1, 3, 23, 71, 'CONSTANT'), (4, 2, 5, 37, 65, 'REFLECT'), (3, 16, 7, 9, 200, 'CONSTANT'),
-               (11, 5, 1, 30, 30, 'SYMMETRIC'), (2, 7, 8, 1, 77, 'CONSTANT')]
+               (11, 5, 1, 30, 30, 'SYMMETRIC'), (2, 7, 8, 1, 77, 'CONSTANT'), (11, 16, 8, 40, 70, 'CONSTANT'), (11, 8, 16, 33, 47, 'SYMMETRIC'),
+               (3, 8, 16, 20, 90, 'REFLECT'), (5, 4, 12, 31, 64, 'CONSTANT')]
 
 
 @pytest.mark.parametrize('k,Cin,Cout,H,W,mode', MFMA_SHAPES)
@@ -43,7 +44,8 @@ def test_grouped_conv_mfma_route_matches_the_oracle(k, Cin, Cout, H, W, mode):
     nk = k * k * Cin * Cout
     wshape = (k, k, Cin, Cout)
     pt, pb = k // 2, k // 2 - (1 - k % 2)
-    assert ops.grouped_uses_mfma((N, H, W, Cin), wshape, (H, W), 'fwd') and ops.grouped_uses_mfma((N, H, W, Cin), wshape, (H, W), 'wgrad')
+    assert ops.grouped_uses_mfma((N, H, W, Cin), wshape, (H, W), 'fwd')
+    assert ops.grouped_uses_mfma((N, H, W, Cin), wshape, (H, W), 'wgrad') or (k, Cin, Cout) == (11, 8, 16)      # 3 x 2 x 4 accumulator quads: vector-ALU filter gradient
     x = torch.randn(N, H, W, Cin, device='cuda', generator=g)
     kb = torch.randn(N, nk + Cout, device='cuda', generator=g) / np.sqrt(k * k * Cin)
     dz = torch.randn(N, H, W, Cout, device='cuda', generator=g)
