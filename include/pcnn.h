@@ -147,6 +147,20 @@ int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, const float* 
 int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg);
 int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
                              const float* residual, float* dx, float* dw);
+/* The same call with the activation backward of the PRODUCING layer fused into the data gradient's epilogue (round 4): in a chain
+ * a_prev = act(conv_prev(...)); y = conv(a_prev) the gradient dx that this call produces is at once multiplied by act'(a_prev) - which is what
+ * pcnn_conv2d_epilogue_bwd would do in a separate pass over the tensor before conv_prev's own backward (blocks/resnet.py:29-39 chains three
+ * such layers; models/Homogeneous_Poisson_NN_Legacy.py:86-96 seven such blocks):
+ *   v = dgrad(dz) (+ residual);  raw_out (optional, stride ld_raw) = v;  dx = v * act'(act_out);  dbias (optional, Cin floats) = sum over pixels of dx.
+ * act_out (stride ld_act_out) is conv_prev's saved activation output, act / act_alpha its activation.  Available where the data gradient runs
+ * on 32-point tiles with one channel group (ask _post_eligible); otherwise call pcnn_conv2d_bwd_spectral and pcnn_conv2d_epilogue_bwd. */
+typedef struct pcnn_post_desc {
+  const float* act_out; int ld_act_out; int act; float act_alpha;
+  float* dbias; float* raw_out; int ld_raw;
+} pcnn_post_desc;
+int pcnn_conv2d_bwd_spectral_post_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg);
+int pcnn_conv2d_bwd_spectral_post(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
+                                  const float* residual, float* dx, float* dw, const pcnn_post_desc* post);
 
 /* Backward of the fused epilogue: given dy (gradient at y) and the saved activation a = act(z),
  *   dz = dy * bn_scale[c] * act'(z)      (act' recovered from a: leaky -> a>0 ? 1 : alpha, tanh -> 1-a^2)

@@ -67,6 +67,11 @@ struct InvParams {
   int tiles_x, tiles_y, tile0, ntile, Vy, Vx;
   int flip;              // store output pixel (y, x) at (Ho-1-y, Wo-1-x): the input-partitioned weight gradient comes out tap-reversed
   int pack, cpt, tgx;    // tile packing, as in FwdParams (flip requires pack == 1)
+  // POST (data-gradient launches only): the activation backward of the layer that PRODUCED this convolution's input, applied to the gradient
+  // before it is stored - v = (conv + residual); y2 (if given) receives v, y receives v * act'(gact) where gact is that layer's saved
+  // activation output, and every lane adds what it stored into bsum[(block 8 + wave) 64 + lane] (the bias gradient's partial sums)
+  const float* gact = nullptr; float* y2 = nullptr; float* bsum = nullptr;
+  int ld_gact = 0, ld_y2 = 0, gmode = 0; float galpha = 1.f;
 };
 
 // 64-point tiles (spectral64.hip): table block, slots are built by build_tables64; the launchers take the same parameter blocks (pack = 1)

@@ -244,7 +244,7 @@ __device__ __forceinline__ void inv_load_unit(const float* in, int q, int h, uns
 // reads its operands.  LDS: E[(y*32 + s)*32 + c] in the first 64 KB, O in the second.
 // TANH = false: linear / relu / leaky-relu as one select with the negative-side slope in p.alpha (1 / 0 / alpha) - sixteen inlined
 // tanhf bodies would otherwise cost every layer ~90 registers and spills
-template <bool TANH, bool RES>
+template <bool TANH, bool RES, bool POST = false>
 __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   extern __shared__ __attribute__((aligned(16))) float U[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
@@ -269,6 +269,8 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
     for (int u = 0; u < 4; ++u) inv_load_unit(in, q, h, loff, u, b[u]);
   }
   float ymax = 0.f;
+  constexpr int BURST = POST ? (RES ? 4 : 8) : 8;
+  float bsum = 0.f;                                                  // POST: sum of what this lane stored (its channel's bias-gradient share)
   for (;;) {
     const int next = item + gridDim.x;
     const float* nin = p.sp + sp_item(next);
@@ -329,8 +331,10 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
         const int64_t rowpix = p.flip ? ((int64_t)n * p.Ho + (p.Ho - 1 - y0 - yy)) * p.Wo + (p.Wo - 1 - x0) : ((int64_t)n * p.Ho + y0 + yy) * p.Wo + x0;
         const int xsgn = p.flip ? -1 : 1;
         float* yrow = p.y + rowpix * p.ldy;
-        float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
+        float* arow = (!POST && p.act_out) ? p.act_out + rowpix * p.ld_act : nullptr;
         const float* rrow = RES ? p.res + rowpix * p.ld_res : nullptr;
+        const float* grow = POST ? p.gact + rowpix * p.ld_gact : nullptr;
+        float* y2row = (POST && p.y2) ? p.y2 + rowpix * p.ld_y2 : nullptr;
         // the per-pixel offsets below are invariant across rows and items: left alone, the compiler hoists all 48 of them out of the
         // persistent loop and keeps them in registers (256 VGPRs + spills); an opaque channel index makes it recompute them (one v_mad each)
         unsigned chv = (unsigned)chan;
@@ -340,25 +344,41 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
           // between the stores is waited for with vmcnt(0) each - sixteen exposed memory latencies per row (measured: + 1.2 ms per convolution
           // of 8 x 1024^2 x 32 with a residual, for 0.25 ms worth of extra traffic)
 #pragma unroll
-          for (int r0 = 0; r0 < 16; r0 += 8) {                       // two bursts of eight (sixteen values at once do not fit the register file)
-            float rv[8];
+          for (int r0 = 0; r0 < 16; r0 += BURST) {                   // bursts of eight (sixteen values at once do not fit the register file; POST: of four)
+            float rv[BURST], gv[BURST];
             if (RES) {
 #pragma unroll
-              for (int r = 0; r < 8; ++r) {
+              for (int r = 0; r < BURST; ++r) {
                 const int xx = acc_row(r0 + r, half);
                 rv[r] = rrow[xx < vx ? (int)((xsgn * xx + subx) * p.ld_res) + (int)chv : (int)chv];
               }
             }
+            if (POST) {                                              // the producing layer's activation output, same burst form
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+              for (int r = 0; r < BURST; ++r) {
+                const int xx = acc_row(r0 + r, half);
+                gv[r] = grow[xx < vx ? (int)((xsgn * xx + subx) * p.ld_gact) + (int)chv : (int)chv];
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < BURST; ++r) {
               const int xx = acc_row(r0 + r, half);
               if (xx < vx) {
-                float v = acc[r0 + r] + bias;
-                v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+                float v = acc[r0 + r];
                 const int xo = xsgn * xx + subx;
-                if (arow) arow[(int)(xo * p.ld_act) + (int)chv] = v;
-                v = v * sc + sh;
+                if (!POST) {                                           // (a data-gradient launch has no bias, activation, BN or act_out)
+                  v += bias;
+                  v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+                  if (arow) arow[(int)(xo * p.ld_act) + (int)chv] = v;
+                  v = v * sc + sh;
+                }
                 if (RES) v += rv[r];
+                if (POST) {
+                  if (y2row) y2row[(int)(xo * p.ld_y2) + (int)chv] = v;
+                  const float g = gv[r];
+                  v *= p.gmode == PCNN_ACT_TANH ? 1.f - g * g : (g > 0.f ? 1.f : p.galpha);
+                  bsum += v;
+                }
                 yrow[(int)(xo * p.ldy) + (int)chv] = v;
                 ymax = fmaxf(ymax, fabsf(v));
               }
@@ -371,6 +391,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
     item = next;
     lds_barrier();                                                       // U is free for the next item
   }
+  if (POST && p.bsum) p.bsum[(blockIdx.x * 8 + wave) * 64 + lane] += bsum;    // own slot: launches of one call follow each other on the stream
   if (p.absmax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
@@ -682,6 +703,14 @@ void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
   p.ntile = ntile; p.tab = gm.tab;
   if (gm.T == 64) { launch_inv64(h, p, ntile); return; }
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
+  if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)
+    p.alpha = 1.f;
+    p.galpha = p.gmode == PCNN_ACT_LINEAR ? 1.f : (p.gmode == PCNN_ACT_RELU ? 0.f : p.galpha);
+    set_lds(spec_inv_kernel<false, true, true>); set_lds(spec_inv_kernel<false, false, true>);
+    if (p.res) hipLaunchKernelGGL((spec_inv_kernel<false, true, true>), grid, dim3(512), LDS_U, h->stream, p);
+    else hipLaunchKernelGGL((spec_inv_kernel<false, false, true>), grid, dim3(512), LDS_U, h->stream, p);
+    return;
+  }
   if (p.act == PCNN_ACT_TANH) {
     if (p.res) launch_inv_t<true, true>(h, p, grid); else launch_inv_t<true, false>(h, p, grid);
   } else {
@@ -722,6 +751,24 @@ int pick_tile(pcnn_handle h, const pcnn_conv_desc* d) {
   // 11 and 12 taps: ahead only on large images (1024^2, 16->32: 2.77 -> 2.66 ms forward, 4.48 -> 4.30 fused backward; 512^2: 0.80 -> 0.93)
   if (d->kh >= 11 && d->kw >= 11 && d->kh < 13 && d->kw < 13) return tiles >= 256 ? 64 : 32;
   return (d->kh >= 13 && d->kw >= 13 && tiles >= 36) ? 64 : 32;
+}
+
+// POST: bias gradient = the lanes' partial sums of spec_inv_kernel<.., POST>, added in a fixed order.  One workgroup per channel; thread t sums the
+// slots (block, wave) = t, t + 256, ... of the lanes that carry the channel (lane & 31 = sub cpt + channel for each packed tile, both halves).
+__global__ __launch_bounds__(256) void spec_post_bias_kernel(const float* __restrict__ bsum, int nslots, int pack, int cpt, float* __restrict__ dbias) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int sl = t; sl < nslots; sl += 256)
+    for (int sub = 0; sub < pack; ++sub) {
+      const int c = sub * cpt + ch;
+      a += bsum[sl * 64 + c];
+      a += bsum[sl * 64 + 32 + c];
+    }
+  red[t] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
+  if (t == 0) dbias[ch] = red[0];
 }
 
 }  // namespace
@@ -902,8 +949,28 @@ extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_
   return pcnn_spectral_eligible(h, dg, false) && pcnn_spectral_eligible(h, d, true) ? 1 : 0;
 }
 
+extern "C" int pcnn_conv2d_bwd_spectral_post_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg) {
+  if (!pcnn_conv2d_bwd_spectral_eligible(h, d, dg)) return 0;
+  return pick_tile(h, dg) == 32 && d->Cin <= 32 ? 1 : 0;             // the 32-point inverse carries the POST epilogue; one channel group
+}
+
+static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
+                             const float* residual, float* dx, float* dw, const pcnn_post_desc* post);
+
 extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
                                         const float* residual, float* dx, float* dw) {
+  return bwd_spectral_impl(h, d, dg, x, dz, w_flipped, residual, dx, dw, nullptr);
+}
+
+extern "C" int pcnn_conv2d_bwd_spectral_post(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
+                                             const float* residual, float* dx, float* dw, const pcnn_post_desc* post) {
+  PCNN_REQUIRE(h, h && post && post->act_out, "pcnn_conv2d_bwd_spectral_post: null argument");
+  PCNN_REQUIRE(h, pcnn_conv2d_bwd_spectral_post_eligible(h, d, dg), "pcnn_conv2d_bwd_spectral_post: layer is not eligible (ask pcnn_conv2d_bwd_spectral_post_eligible first)");
+  return bwd_spectral_impl(h, d, dg, x, dz, w_flipped, residual, dx, dw, post);
+}
+
+static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
+                             const float* residual, float* dx, float* dw, const pcnn_post_desc* post) {
   PCNN_REQUIRE(h, h && d && dg && x && dz && w_flipped && dx && dw, "pcnn_conv2d_bwd_spectral: null argument");
   PCNN_REQUIRE(h, pcnn_conv2d_bwd_spectral_eligible(h, d, dg), "pcnn_conv2d_bwd_spectral: layer is not eligible (ask pcnn_conv2d_bwd_spectral_eligible first)");
   PCNN_REQUIRE(h, dg->Cin == d->Cout && dg->Cout == d->Cin && dg->kh == d->kh && dg->kw == d->kw && dg->N == d->N, "pcnn_conv2d_bwd_spectral: descriptors do not match");
@@ -923,13 +990,15 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / gx, ntile), [&](int ch) { return wsp_b + part_b + 4096 + zs_bytes(ch) + 2 * ys_bytes(ch); });
   const size_t zs_b = zs_bytes(chunk), ys_b = ys_bytes(chunk);
   char* r;
-  if (int rc = ensure_workspace(h, wsp_b + zs_b + 2 * ys_b + part_b + 4096, &r)) return rc;
+  const size_t bs_b = post ? (size_t)256 * 8 * 64 * sizeof(float) : 0;       // POST: one partial bias sum per (workgroup, wave, lane)
+  if (int rc = ensure_workspace(h, wsp_b + zs_b + 2 * ys_b + part_b + bs_b + 4096, &r)) return rc;
   const Geom gm = geom_of(h, Tg);
   float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
   float* zs = reinterpret_cast<float*>(r); r += zs_b;
   float* ys = reinterpret_cast<float*>(r); r += ys_b;
   float* xs = reinterpret_cast<float*>(r); r += ys_b;
-  float* part = reinterpret_cast<float*>(r);
+  float* part = reinterpret_cast<float*>(r); r += part_b;
+  float* bsum = post ? reinterpret_cast<float*>(r) : nullptr;
   // flipped filter spectrum -> mixing matrices of the data gradient (input groups: dz's, output groups: dx's)
   PCNN_REQUIRE(h, gx == 1 || dg->Cout == 64, "pcnn_conv2d_bwd_spectral: %d input channels unsupported (<= 32 or 64)", d->Cin);
   launch_fwd(h, gm, filter_params(gm, w_flipped, wsp, d->kh, d->kw, dg->Cin, dg->Cout, gx), 1);
@@ -951,6 +1020,11 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
   iv.act = PCNN_ACT_LINEAR; iv.alpha = 0.f; iv.tiles_x = tiles_x; iv.tiles_y = tiles_y; iv.Vy = Vy; iv.Vx = Vx; iv.flip = 0;
   iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
   if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
+  if (post) {
+    iv.gact = post->act_out; iv.ld_gact = post->ld_act_out; iv.gmode = post->act; iv.galpha = post->act_alpha;
+    iv.y2 = post->raw_out; iv.ld_y2 = post->ld_raw; iv.bsum = post->dbias ? bsum : nullptr;
+    if (iv.bsum && hipMemsetAsync(bsum, 0, bs_b, h->stream) != hipSuccess) PCNN_FAIL(h, "pcnn_conv2d_bwd_spectral_post: memset failed");
+  }
   MixParams mx;
   mx.xs = zs; mx.ys = ys; mx.wsp = wsp; mx.gin = gz; mx.gout = gx; mx.Cin = dg->Cin; mx.cpt = cpt;
   WMixParams wm;
@@ -964,6 +1038,7 @@ extern "C" int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, 
     launch_fwd(h, gm, fxm, nt);
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gx), dim3(256), 0, h->stream, wm);
   }
+  if (post && post->dbias) hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * 8, pack, cpt, post->dbias);
   float* csp = wsp;                                      // the filter spectrum is no longer needed: every mixing launch above has read it (same stream)
   hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gx), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);
   launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 1), 1);

@@ -238,9 +238,19 @@ class ConvUnit:
             self.saved = (x, a if a is not None else out, None, x_absmax)   # without BN/residual the output itself is the activation
         return out
 
-    def backward(self, dy, need_dx=True, inplace=False, add_to=None):
+    def post_spec(self, want_raw=False):
+        """This layer's activation backward (dz = dy act'(a), dbias = sum dz) as an offer to the data-gradient kernel of the layer that CONSUMES
+        its output (ops.Post; pass it as `post=` to that layer's backward, then call this layer's backward with dz_ready=post.applied).  None
+        where there is nothing to fuse or the epilogue carries more than an activation (BatchNormalization, strides, a linear layer)."""
+        if self.saved is None or self.bn_name is not None or self.stride > 1 or self.act == 'linear' or self.saved[2] is not None:
+            return None
+        return ops.Post(self.saved[1], self.act, self.store.g[self.name + '/bias'] if self.use_bias else None, want_raw)
+
+    def backward(self, dy, need_dx=True, inplace=False, add_to=None, dz_ready=False, post=None):
         """add_to: optional tensor added to the returned input gradient inside the data-gradient kernel's epilogue (a skip connection's
-        gradient); it may be overwritten."""
+        gradient); it may be overwritten.  dz_ready: dy already IS dz - the consumer's data-gradient kernel applied this layer's post_spec()
+        (and wrote its bias gradient).  post: the producing layer's post_spec(), taken by the spectral data-gradient kernel where it can
+        (post.applied tells)."""
         if self.stride > 1:
             dy, inplace = ops.subsample_bwd(dy, self._full_hw, self.stride), True
         x, a, bn_stats, x_absmax = self.saved
@@ -257,7 +267,10 @@ class ConvUnit:
         s2 = s.bn_s2[self.bn_off:self.bn_off + self.cout] if sc is not None else None
         trivial = self.act == 'linear' and sc is None
         amax = None                    # max|dz|: a by-product of the epilogue pass that the split-mode weight gradient would otherwise recompute
-        if trivial and not self.use_bias:
+        if dz_ready:
+            assert sc is None and bn_stats is None
+            dz = dy
+        elif trivial and not self.use_bias:
             dz = dy
         else:
             if not trivial and ops.get_math_mode() == 'split_f16':
@@ -274,7 +287,7 @@ class ConvUnit:
             wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
             res = add_to if (self.mode == 'CONSTANT') else None
             out = ops.conv2d_bwd_fused(x, dz, w.shape, wf, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
-                                       dw=g[self.name + '/kernel'], residual=res)
+                                       dw=g[self.name + '/kernel'], residual=res, post=post)
             if out is not None:
                 if self.mode == 'CONSTANT':
                     return out
@@ -335,10 +348,21 @@ class resnet:
         self.out_absmax = self.c2.out_absmax
         return o
 
-    def backward(self, dy, inplace=False):
-        d1 = self.c2.backward(dy, inplace=inplace)           # gradient at (x + BN1(a1))
-        d0 = self.c1.backward(d1, inplace=False)              # d1 is still needed for the skip connection
-        return self.c0.backward(d0, inplace=True, add_to=d1)      # + the skip connection's gradient, fused into the epilogue
+    def post_spec(self, want_raw=False):
+        return self.c2.post_spec(want_raw)
+
+    def backward(self, dy, inplace=False, dz_ready=False, post=None):
+        """Where the data gradients run on the spectral route, each convolution's data-gradient kernel also applies the activation backward of
+        the convolution before it (ops.Post): conv2's produces dz1 AND the raw gradient for the skip connection, conv1's produces dz0, conv0's
+        (+ skip) takes the caller's `post` - 7 of the block's 12 activation-backward tensor passes disappear."""
+        p1 = self.c1.post_spec(want_raw=True)
+        d1 = self.c2.backward(dy, inplace=inplace, dz_ready=dz_ready, post=p1)           # gradient at (x + BN1(a1))
+        ready1 = p1 is not None and p1.applied
+        d1raw = p1.raw if ready1 else d1
+        p0 = self.c0.post_spec()
+        d0 = self.c1.backward(d1, inplace=ready1, dz_ready=ready1, post=p0)              # not fused: d1 is still needed for the skip connection
+        ready0 = p0 is not None and p0.applied
+        return self.c0.backward(d0, inplace=True, add_to=d1raw, dz_ready=ready0, post=post)   # + the skip connection's gradient, fused into the epilogue
 
 
 # ----------------------------------------------------------------------------- bottleneck blocks

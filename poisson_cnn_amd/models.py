@@ -374,14 +374,18 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         d = ops.bc_ring_bwd(d, self.neumann)
         if self.scaling is not None:
             d = self.scaling.backward(d)
-        for lyr in reversed(self.final):
-            d = lyr.backward(d, inplace=True)
+        ready = False                                              # the gradient arriving at a layer already went through its activation backward
+        for i in reversed(range(len(self.final))):                 # (fused into the data-gradient kernel of the layer after it, layers.ConvUnit.post_spec)
+            post = self.final[i - 1].post_spec() if i > 0 else None
+            d = self.final[i].backward(d, inplace=True, dz_ready=ready, post=post)
+            ready = post is not None and post.applied
         d, ds = ops.channel_scale_bwd(sv['scale_in'], sv['dx_info'], d, ws=self.ctx.ws)
         dd = ds
         for i, lyr in enumerate(reversed(self.dx_dense_layers)):
             dd = lyr.backward(dd, need_dx=(i < len(self.dx_dense_layers) - 1))
-        d = self.post_merge_resnet.backward(d, inplace=True)
-        dcat = self.post_merge_conv.backward(d, inplace=True)
+        post = self.post_merge_conv.post_spec()
+        d = self.post_merge_resnet.backward(d, inplace=True, post=post)
+        dcat = self.post_merge_conv.backward(d, inplace=True, dz_ready=post is not None and post.applied)
         d_initial = self.non_bottleneck_conv.backward(dcat[..., :F], inplace=False)
         dmerged = dcat[..., F:]
         blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks

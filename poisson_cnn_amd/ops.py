@@ -134,6 +134,12 @@ class Workspace:
 
 
 _default_ws = Workspace()
+_post_fusion = __import__('os').environ.get('PCNN_POST_FUSION', '1') != '0'      # developer switch: 0 = every activation backward as its own pass
+
+
+def set_post_fusion(on):
+    global _post_fusion
+    _post_fusion = bool(on)
 
 
 class KernelTimer:
@@ -228,7 +234,23 @@ def conv2d_wgrad(x, dz, w_shape, *, pad_top, pad_left, pad_mode='CONSTANT', pad_
     return dw
 
 
-def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, dw, residual=None):
+class PostDesc(ctypes.Structure):
+    """include/pcnn.h pcnn_post_desc"""
+    _fields_ = [('act_out', c_void_p), ('ld_act_out', c_int), ('act', c_int), ('act_alpha', c_float), ('dbias', c_void_p), ('raw_out', c_void_p), ('ld_raw', c_int)]
+
+
+class Post:
+    """The activation backward of the layer that produced a convolution's input, offered to that convolution's data-gradient kernel for fusion
+    (pcnn_conv2d_bwd_spectral_post): a = the producer's saved activation output, act its activation, dbias its bias gradient (or None),
+    want_raw: the un-multiplied gradient is needed as well (a skip connection branches off here).  After the call `applied` says whether the
+    kernel took it (then `raw` holds the un-multiplied gradient if it was asked for)."""
+
+    def __init__(self, a, act, dbias=None, want_raw=False):
+        self.a, self.act, self.dbias, self.want_raw = a, act, dbias, want_raw
+        self.applied, self.raw = False, None
+
+
+def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, dw, residual=None, post=None):
     """Both gradients of the fused pad+conv in one call when the layer takes the spectral route (pcnn_conv2d_bwd_spectral: dz's spectrum is
     computed once for the data gradient and the weight gradient).  wf: the flipped / transposed filter (kh,kw,Cout,Cin).  Fills dw and returns
     the data-gradient convolution's output - dx for CONSTANT padding (+ `residual` if given), the gradient on the padded domain otherwise
@@ -249,9 +271,17 @@ def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTAN
         return None
     out = empty((N, out_hw[0], out_hw[1], Cin), x.device)
     flops = 2.0 * N * dz.shape[1] * dz.shape[2] * kh * kw * Cin * Cout
+    nbytes = 4.0 * (2 * N * H * W * Cin + N * dz.shape[1] * dz.shape[2] * Cout + 2 * kh * kw * Cin * Cout)
+    if post is not None and mode == 'CONSTANT' and _post_fusion and h.lib.pcnn_conv2d_bwd_spectral_post_eligible(h._h, byref(d), byref(dg)):
+        post.raw = empty((N, H, W, Cin), x.device) if post.want_raw else None
+        pd = PostDesc(post.a.data_ptr(), _ld(post.a), ACTS[post.act], LEAKY_ALPHA, post.dbias.data_ptr() if post.dbias is not None else None,
+                      post.raw.data_ptr() if post.raw is not None else None, Cin)
+        _launch('conv_bwd_fused', 2.0 * flops,
+                lambda: h.call('pcnn_conv2d_bwd_spectral_post', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw), byref(pd)), nbytes)
+        post.applied = True
+        return out
     _launch('conv_bwd_fused', 2.0 * flops,
-            lambda: h.call('pcnn_conv2d_bwd_spectral', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw)),
-            4.0 * (2 * N * H * W * Cin + N * dz.shape[1] * dz.shape[2] * Cout + 2 * kh * kw * Cin * Cout))
+            lambda: h.call('pcnn_conv2d_bwd_spectral', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw)), nbytes)
     return out
 
 

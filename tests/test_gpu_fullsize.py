@@ -13,15 +13,21 @@ def dot64(a, b):
     return float((a.double() * b.double()).sum())
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'split_f16'])
+# (taps, Cin, Cout) at 8 x 1024^2: the final stack's 15- and 13-tap layers and the 11-tap layer of the pre-bottleneck stack - at this size the
+# 11-tap layer switches to 64-point tiles (pick_tile: >= 256 tiles per image, never true at 512^2), which no oracle fixture of the BACKWARD pass
+# covers: the identities below tie its forward, weight-gradient, data-gradient and fused-backward kernels to each other
+FULL_SHAPES = [(15, 32, 32, 'fp32'), (15, 32, 32, 'split_f16'), (13, 28, 28, 'fp32'), (11, 16, 32, 'fp32'), (9, 24, 24, 'fp32')]
+
+
+@pytest.mark.parametrize('k,ci,co,mode', FULL_SHAPES)
 @pytest.mark.parametrize('pad_mode', ['SYMMETRIC', 'CONSTANT'])
-def test_conv_adjoint_identities_at_full_size(mode, pad_mode):
+def test_conv_adjoint_identities_at_full_size(k, ci, co, mode, pad_mode):
     from poisson_cnn_amd import ops
     prev = ops.get_math_mode()
     ops.set_math_mode(mode)
     try:
         g = torch.Generator(device='cuda').manual_seed(1)
-        N, H, W, k, ci, co = 8, 1024, 1024, 15, 32, 32
+        N, H, W = 8, 1024, 1024
         x = torch.randn(N, H, W, ci, device='cuda', generator=g)
         w = torch.randn(k, k, ci, co, device='cuda', generator=g) * 0.02
         gy = torch.randn(N, H, W, co, device='cuda', generator=g)
@@ -39,6 +45,16 @@ def test_conv_adjoint_identities_at_full_size(mode, pad_mode):
             gp = ops.conv2d_fwd(gy, wf, None, pad_top=k - 1, pad_left=k - 1, out_hw=(H + k - 1, W + k - 1))
             dx = ops.pad_fold_bwd(gp, (H, W), ((pt, pt), (pt, pt)), pad_mode)
         assert abs(dot64(x, dx) - ref) < tol
+        # the fused backward of the spectral route (one pass: dz's spectrum shared by both gradients) obeys the same two identities
+        dwf = torch.zeros_like(w)
+        out = ops.conv2d_bwd_fused(x, gy, w.shape, wf, pad_top=pt, pad_left=pt, pad_mode=pad_mode, dw=dwf)
+        if out is not None:
+            dxf = out if pad_mode == 'CONSTANT' else ops.pad_fold_bwd(out, (H, W), ((pt, pt), (pt, pt)), pad_mode)
+            assert abs(dot64(w, dwf) - ref) < tol and abs(dot64(x, dxf) - ref) < tol
+            assert float((dwf - dw).double().norm() / dw.double().norm()) < 5e-6 and float((dxf - dx).double().norm() / dx.double().norm()) < 5e-6
+        else:
+            assert mode == 'split_f16'
+        del dwf, out
         # linearity in x
         x2 = torch.randn(N, H, W, ci, device='cuda', generator=g)
         y2 = ops.conv2d_fwd(x2, w, None, pad_top=pt, pad_left=pt, pad_mode=pad_mode)

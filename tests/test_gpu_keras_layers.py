@@ -91,6 +91,54 @@ def test_resnet_block(use_bn):
         resnet(2, filters=4, kernel_size=3)(x)
 
 
+@pytest.mark.parametrize('filters,k,act,hw', [(32, 7, 'tf.nn.leaky_relu', (70, 83)), (12, 5, 'tf.nn.tanh', (64, 64)), (20, 9, 'tf.nn.leaky_relu', (50, 41))])
+def test_resnet_block_fuses_the_activation_backward_into_the_data_gradient(filters, k, act, hw):
+    """Round 4: with zero padding and the data gradients on the 32-point spectral route, each convolution's data-gradient
+    kernel applies the activation backward of the convolution BEFORE it (dz = dx act'(a), bias gradient from per-lane partial sums; conv2's also
+    hands back the raw gradient for the skip connection).  The block's gradients must match the fp64 oracle exactly as without the fusion,
+    the fused entry point must really have been taken (three times per block), and dx / dK must agree with the unfused path to rounding."""
+    from poisson_cnn_amd import _lib, ops
+    from poisson_cnn_amd.keras_layers import resnet
+    rng = np.random.default_rng(3)
+    x = f32(rng.standard_normal((2, filters) + hw))
+    dy = f32(rng.standard_normal((2, filters) + hw))
+    oact = 'leaky_relu' if 'leaky' in act else 'tanh'
+    res = {}
+    ops.set_spectral_mode('force')
+    try:
+        for fused in (True, False):
+            ops.set_post_fusion(fused)
+            blk = resnet(2, padding_mode='constant', filters=filters, kernel_size=k, activation=act, data_format='channels_first', seed=5)
+            blk(x)
+            w = randomize(blk, np.random.default_rng(4))
+            y = blk(x, training=True)
+            calls = []
+            orig = _lib.Handle.call
+
+            def spy(self, name, *a):
+                calls.append(name)
+                return orig(self, name, *a)
+            _lib.Handle.call = spy
+            try:
+                dx = blk.backward(dy)
+            finally:
+                _lib.Handle.call = orig
+            n_post = calls.count('pcnn_conv2d_bwd_spectral_post')
+            # conv2's and conv1's data gradients carry the activation backward of conv1 / conv0 (conv0's has no producer inside the block)
+            assert n_post == (2 if fused else 0), calls
+            assert calls.count('pcnn_conv2d_epilogue_bwd_absmax') + calls.count('pcnn_conv2d_epilogue_bwd') == (1 if fused else 3)
+            fn = lambda p, xx: ohpnn.resnet_forward(torch_twin, p, 'resnet', xx, 'CONSTANT', 0.0, oact, False)
+            check_grads(blk, w, fn, [x], dy, dx)
+            to_np = lambda t: t.detach().cpu().numpy().copy() if hasattr(t, 'detach') else np.array(t)
+            res[fused] = (to_np(dx), {n: to_np(g) for n, g in blk.gradients.items()})
+    finally:
+        ops.set_post_fusion(True)
+        ops.set_spectral_mode('auto')
+    assert rel(res[True][0], res[False][0]) < 1e-6
+    for n, g in res[True][1].items():
+        assert rel(g, res[False][1][n]) < 2e-6, n
+
+
 def _oracle_bottleneck(ops_ns, p, x, *, f, up, k, n_convs, mode, val, act, method, pool, use_resnet, use_bn, kdown, kind, resize='bilinear'):
     """blocks/bottleneck_block.py:9-118 restated for every constructor path (conv / pool down-sampling, plain / resnet stages)."""
     H, W = x.shape[2], x.shape[3]

@@ -87,8 +87,8 @@ def test_whole_model_forward_and_gradients():
 def test_adjoint_identities_at_full_size():
     """8 x 1024^2, 15 x 15, 32 -> 32: <conv(x; w), g> = <w, wgrad(x, g)> = <x, dgrad(g; w)> through the spectral route."""
     import test_gpu_fullsize as t
-    t.test_conv_adjoint_identities_at_full_size('fp32', 'CONSTANT')
-    t.test_conv_adjoint_identities_at_full_size('fp32', 'SYMMETRIC')
+    t.test_conv_adjoint_identities_at_full_size(15, 32, 32, 'fp32', 'CONSTANT')
+    t.test_conv_adjoint_identities_at_full_size(15, 32, 32, 'fp32', 'SYMMETRIC')
 
 
 @pytest.mark.parametrize('k,Cin,Cout,mode', [(15, 32, 32, 'CONSTANT'), (13, 28, 28, 'CONSTANT'), (7, 64, 32, 'CONSTANT'), (11, 16, 32, 'SYMMETRIC'), (9, 24, 20, 'REFLECT'),

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Everything under profiles/r03_* in one go (run on the GPU box from the repo root through gpurun, ~10 minutes):
+# Everything under profiles/r04_* in one go (run on the GPU box from the repo root through gpurun, ~10 minutes):
 #   gpurun --timeout 1200 -- 'bash tools/collect_evidence.sh'
 # then copy gpurun_out/evidence/* into profiles/ (gpurun merges gpurun_out/ back).  Order matters: the PMC summaries are written first and
 # copied into profiles/ on the box, so that bench.py finds a summary whose source stamp matches the tree it runs from.
 set -o pipefail
 ROOT=$(pwd)
-R=r03
+R=r04
 OUT=$ROOT/gpurun_out/evidence
 mkdir -p "$OUT"
 export TMPDIR=/tmp
