@@ -93,6 +93,36 @@ class _CheckpointedTwin:
         return wrapped
 
 
+def c4_target():
+    """Target of the C4 training step: the smooth low-order sine series of c3_inputs at 1024^2."""
+    rng = np.random.default_rng(44)
+    t = np.linspace(0, np.pi, 1024)
+    coef = rng.standard_normal((8, 4, 4)) * 0.1
+    S = np.stack([np.sin((a + 1) * t) for a in range(4)])
+    return np.einsum('nab,ah,bw->nhw', coef, S, S)[:, None].astype(np.float32)
+
+
+class _CheckpointedTwin:
+    """oracle.torch_twin with its convolution-like ops run under torch.utils.checkpoint (identical arithmetic; an op's internal intermediates
+    - padded copy, pre-activation - are recomputed in the backward pass instead of being kept)."""
+    _WRAP = ('padded_conv2d', 'same_conv2d', 'conv2d_transpose_same', 'resize2d', 'pool2d_same')
+
+    def __getattr__(self, name):
+        fn = getattr(torch_twin, name)
+        if name not in self._WRAP:
+            return fn
+        from torch.utils.checkpoint import checkpoint
+
+        def wrapped(x, *a, **k):
+            return checkpoint(lambda x_: fn(x_, *a, **k), x, use_reentrant=False)
+        return wrapped
+
+
+C4_GRADS = ('pre/conv0/kernel', 'pre/conv2/kernel', 'final/out0/kernel', 'final/out0/bias', 'final/out1/kernel', 'final/out1/bias', 'final/stage0/conv/bias',
+            'final/stage0/conv/kernel', 'final/stage0/res/conv1/kernel', 'final/stage1/conv/kernel', 'final/stage2/conv/kernel', 'final/stage2/res/conv0/bias',
+            'deconv_f2/res0/conv1/kernel', 'post_merge_conv/kernel')
+
+
 def main():
     which = set(sys.argv[1:]) or {'c2', 'c3', 'c4'}
     out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
@@ -151,6 +181,37 @@ def main():
             # rounding (6e-8) is far below the test tolerance and the fixture stays a few MB
             out['c4_grad:%s' % n.replace('/', '.')] = g.astype(np.float32 if g.size > 4096 else np.float64)
         print('c4grad: %.1f s, loss %.6g, pred vs c4_out %.3g' % (time.time() - t0, float(loss.detach()), float(out['c4_pred_check'])), flush=True)
+        np.savez_compressed(PATH, **out)
+        del pt, pred, loss
+    if 'c4grad' in which:
+        cfg = configs.hpnn()['model']
+        p = ohpnn.init_params(cfg, seed=WEIGHT_SEED, gain=WEIGHT_GAIN, randomize_all=True)
+        rhs, dx = c4_inputs()
+        tgt = c4_target()
+        k = 3
+        pt = {n: torch.tensor(v, dtype=torch.float64, requires_grad=not n.endswith(('moving_mean', 'moving_variance'))) for n, v in p.items()}
+        t0 = time.time()
+        r64, d64 = rhs[k:k + 1].astype(np.float64), dx[k:k + 1].astype(np.float64)
+        torch_twin.set_fft_conv(min_pixels=200 * 200, tile=256)
+        try:
+            pred = ohpnn.forward(_CheckpointedTwin(), cfg, pt, torch.tensor(r64), torch.tensor(d64))
+            print('c4grad: forward %.1f s' % (time.time() - t0), flush=True)
+            L = oloss.loss_wrapper(global_batch_size=8, **full['training']['loss_parameters'])
+            loss = L(tgt[k:k + 1].astype(np.float64), pred, torch.tensor(r64), np.concatenate([d64, d64], 1))
+            loss.backward()
+        finally:
+            torch_twin.set_fft_conv(None)
+        names = [n for n, v in pt.items() if v.requires_grad]
+        out['c4_loss'] = np.float64(loss.detach())
+        # the FFT-evaluated forward against the F.conv2d-evaluated fixture of the same sample (c4_out): the two evaluations agree to fp32 storage
+        out['c4_pred_vs_c4_out'] = np.float64(np.linalg.norm(pred.detach().numpy().astype(np.float32) - out['c4_out']) / np.linalg.norm(out['c4_out'])) if 'c4_out' in out else np.float64(-1)
+        out['c4_grad_names'] = np.array(names)
+        out['c4_grad_norms'] = np.array([float(pt[n].grad.norm()) for n in names])
+        for n in C4_GRADS:
+            g = pt[n].grad.numpy()
+            # the wide-filter gradients are kept in float32: the rounding (6e-8) is far below the test tolerance and the fixture stays a few MB
+            out['c4_grad:%s' % n.replace('/', '.')] = g.astype(np.float32 if g.size > 4096 else np.float64)
+        print('c4grad: %.1f s, loss %.6g, pred vs c4_out %.3g' % (time.time() - t0, float(loss.detach()), float(out['c4_pred_vs_c4_out'])), flush=True)
         np.savez_compressed(PATH, **out)
         del pt, pred, loss
     if 'c3' in which:

@@ -126,7 +126,11 @@ def test_bench_two_ranks_bare_invocation_on_gpu():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['value'] > 0
     assert 'gloo' in out['config']['collective'] and out['dtype'] == 'f32'
-    assert out['split_f16']['value'] > 0 and out['split_f16']['accuracy_vs_fp32']['forward_output']['rel_l2'] < 1e-5
+    assert len(lines[0]) < 3072 and out['config']['ranks_seen'] == 2                     # the compact line; both ranks joined the group
+    assert out['split_f16']['value'] > 0 and out['split_f16']['fwd_rel_l2'] < 1e-5
+    with open(os.path.join(root, out['detail'])) as f:                                  # everything else lives in the detail file
+        detail = json.load(f)
+    assert detail['split_f16']['accuracy_vs_fp32']['forward_output']['rel_l2'] < 1e-5 and detail['roofline']['bound'] == 'hbm'
 
 
 def test_c_abi_collective_single_rank():

@@ -204,3 +204,30 @@ def test_loss_numpy_vs_twin_and_gradcheck():
         e = np.zeros_like(yp); e[idx] = 1e-6
         fd = (L(yt, yp + e, rhs, dx) - L(yt, yp - e, rhs, dx)) / 2e-6
         assert abs(fd - g[idx]) < 1e-6 * max(1.0, abs(g[idx]))
+
+
+@pytest.mark.parametrize('k,C,O,H,W,tile', [(7, 3, 4, 61, 45, 32), (15, 2, 3, 70, 90, 64), (4, 5, 2, 33, 100, 24), (3, 1, 1, 20, 20, 256)])
+def test_fft_convolution_of_the_autograd_twin_equals_the_direct_one(k, C, O, H, W, tile):
+    """oracle.torch_twin.conv2d_valid_fft (overlap-save, torch.fft, fp64) - the evaluation the 1024^2 training-step fixture is generated with,
+    because PyTorch's fp64 CPU convolution needs 60 GB for one 15 x 15 x 32 layer at that size - against F.conv2d: values and the gradients
+    with respect to input, filter and bias, ragged tile edges and even filter sizes included."""
+    rng = np.random.default_rng(k)
+    x = torch.tensor(rng.standard_normal((2, C, H, W)), requires_grad=True)
+    w = torch.tensor(rng.standard_normal((k, k, C, O)), requires_grad=True)
+    b = torch.tensor(rng.standard_normal(O), requires_grad=True)
+    g = torch.tensor(rng.standard_normal((2, O, H - k + 1, W - k + 1)))
+    ref = F.conv2d(x, w.permute(3, 2, 0, 1), b)
+    gr = torch.autograd.grad((ref * g).sum(), [x, w, b])
+    got = torch_twin.conv2d_valid_fft(x, w, b, tile)
+    gg = torch.autograd.grad((got * g).sum(), [x, w, b])
+    assert rel(got.detach(), ref.detach()) < 1e-13
+    for a, r in zip(gg, gr):
+        assert rel(a, r) < 1e-12
+    # the switch: the twin's padded convolution takes the FFT evaluation above the pixel threshold and F.conv2d below it
+    torch_twin.set_fft_conv(min_pixels=H * W, tile=tile)
+    try:
+        y1 = torch_twin.padded_conv2d(x.detach(), w.detach(), b.detach(), 'SYMMETRIC', 0.0, 'leaky_relu')
+    finally:
+        torch_twin.set_fft_conv(None)
+    y0 = torch_twin.padded_conv2d(x.detach(), w.detach(), b.detach(), 'SYMMETRIC', 0.0, 'leaky_relu')
+    assert rel(y1, y0) < 1e-13 and not torch.equal(y1, y0)
