@@ -356,6 +356,16 @@ int pcnn_dst_setup(int n, double* S /* (n-2)^2, host */, double* lam /* n-2, hos
 int pcnn_fd_poisson_dst(pcnn_handle h, int N, int H, int W, const float* rhs, const float* left, const float* right,
                         const float* bottom, const float* top, const float* dx, const double* S_h, const double* lam_h,
                         const double* S_w, const double* lam_w, double* tmp, float* soln);
+/* The same solve with the two DST-I passes done by rocFFT (BASELINE.json north star: "HIP stencil + rocFFT kernel"): odd extension of the
+ * right-hand side to 2 (H-1) x 2 (W-1), batched real 2-D FFT, division by the eigenvalues, the same FFT again - O(n^2 log n) against the
+ * 8 n^3 FLOP of the GEMM form above, fp64 throughout.  rocFFT is bound at run time (dlopen; PCNN_ROCFFT_LIBRARY overrides the name); plans are
+ * kept per (device, shape, batch).  lam_h / lam_w: the eigenvalues pcnn_dst_setup returns; workspace: pcnn_fd_poisson_fft_workspace bytes.
+ * Measured per sample (tools/bench_fd_solver.py): 512^2 0.035 (GEMM) vs 0.076 ms, 1024^2 0.25 vs 0.35, 2048^2 1.86 vs 1.66 - the odd extension
+ * quadruples the data and its lengths are awkward (2046 = 2 3 11 31), so poisson_cnn_amd.dataset takes this route from 2048 points per axis
+ * (solver='auto'); below that the fp64 matrix cores win and the GEMM form is this route's checker in the tests. */
+size_t pcnn_fd_poisson_fft_workspace(int N, int H, int W);
+int pcnn_fd_poisson_fft(pcnn_handle h, int N, int H, int W, const float* rhs, const float* left, const float* right, const float* bottom,
+                        const float* top, const float* dx, const double* lam_h, const double* lam_w, void* workspace, float* soln);
 /* Mixed Dirichlet / Neumann 5-point solve on the same vertex-centred grid (the consumer in the reference is the
  * pressure projection of Navier_Stokes_2D/solvers.py:225-335, whose pure-Neumann system carries a zero-integral constraint, :258-259).
  * neumann_mask bit 0/1/2/3: left / right / bottom / top edge is Neumann - its array then holds du/dn (outward normal), its nodes are

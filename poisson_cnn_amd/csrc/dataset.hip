@@ -292,6 +292,160 @@ extern "C" int pcnn_fd_poisson_dst(pcnn_handle h, int N, int H, int W, const flo
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ rocFFT route
+// The same Dirichlet solve with the two DST-I passes done by rocFFT instead of the 8 n^3 GEMMs (BASELINE.json north star: "HIP stencil +
+// rocFFT kernel"): the odd extension of an n-vector to length L = 2 (n + 1) turns the DST-I into a real FFT, Y[k] = -2i (D x)[k-1] with the
+// unnormalised D[k][j] = sin(pi (j+1)(k+1)/(n+1)); in two dimensions FFT2(odd-odd extension)[a+1][b+1] = -4 (D_h B D_w)[a][b], real.  So
+//   u = c_h c_w D_h ((D_h B D_w) ./ (lam_h + lam_w)) D_w,  c = 2 / (n + 1),
+// is: build B -> odd-extend -> rocFFT real 2-D forward -> (take -Re/4, divide, odd-extend again: one kernel) -> the same FFT -> -Re/4 c_h c_w.
+// O(n^2 log n) instead of O(n^3) - but the extension quadruples the data and 2 (n + 1) is an awkward length for the configs' grids (2046 =
+// 2 3 11 31), so the fp64 matrix cores win up to ~1536^2 (tools/bench_fd_solver.py: 0.25 vs 0.35 ms per 1024^2 sample, 1.86 vs 1.66 ms at 2048^2):
+// the Python side takes this route from 2048 points per axis; below that the GEMM route is the default and the CHECKER of this one in the tests.
+// rocFFT is bound at run time (dlopen of librocfft.so on the first call), like RCCL in collective.hip: libpcnn.so keeps no link-time dependency.
+#include <dlfcn.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+namespace {
+
+typedef int (*RfSetupFn)();
+typedef int (*RfPlanCreateFn)(void** plan, int placement, int transform_type, int precision, size_t dims, const size_t* lengths, size_t batch, void* desc);
+typedef int (*RfPlanWorkSizeFn)(void* plan, size_t* bytes);
+typedef int (*RfInfoCreateFn)(void** info);
+typedef int (*RfInfoSetStreamFn)(void* info, void* stream);
+typedef int (*RfInfoSetWorkFn)(void* info, void* buf, size_t bytes);
+typedef int (*RfExecuteFn)(void* plan, void** in, void** out, void* info);
+
+struct RocFFT {
+  void* lib = nullptr;
+  RfSetupFn setup = nullptr; RfPlanCreateFn plan_create = nullptr; RfPlanWorkSizeFn work_size = nullptr; RfInfoCreateFn info_create = nullptr;
+  RfInfoSetStreamFn set_stream = nullptr; RfInfoSetWorkFn set_work = nullptr; RfExecuteFn execute = nullptr;
+  std::string why;
+};
+struct FftPlan { void* plan = nullptr; void* info = nullptr; void* work = nullptr; size_t work_bytes = 0; };
+
+RocFFT& rocfft() {
+  static RocFFT r;
+  if (r.lib || !r.why.empty()) return r;
+  const char* forced = getenv("PCNN_ROCFFT_LIBRARY");
+  for (const char* name : {forced ? forced : "librocfft.so.0", "librocfft.so", "/opt/rocm/lib/librocfft.so"}) {
+    r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (r.lib || forced) break;
+  }
+  if (!r.lib) { const char* e = dlerror(); r.why = std::string("cannot load librocfft.so: ") + (e ? e : "unknown dlopen error"); return r; }
+  r.setup = reinterpret_cast<RfSetupFn>(dlsym(r.lib, "rocfft_setup"));
+  r.plan_create = reinterpret_cast<RfPlanCreateFn>(dlsym(r.lib, "rocfft_plan_create"));
+  r.work_size = reinterpret_cast<RfPlanWorkSizeFn>(dlsym(r.lib, "rocfft_plan_get_work_buffer_size"));
+  r.info_create = reinterpret_cast<RfInfoCreateFn>(dlsym(r.lib, "rocfft_execution_info_create"));
+  r.set_stream = reinterpret_cast<RfInfoSetStreamFn>(dlsym(r.lib, "rocfft_execution_info_set_stream"));
+  r.set_work = reinterpret_cast<RfInfoSetWorkFn>(dlsym(r.lib, "rocfft_execution_info_set_work_buffer"));
+  r.execute = reinterpret_cast<RfExecuteFn>(dlsym(r.lib, "rocfft_execute"));
+  if (!r.setup || !r.plan_create || !r.work_size || !r.info_create || !r.set_stream || !r.set_work || !r.execute) {
+    r.why = "librocfft.so lacks an expected rocfft_* symbol"; dlclose(r.lib); r.lib = nullptr; return r;
+  }
+  if (r.setup() != 0) { r.why = "rocfft_setup failed"; dlclose(r.lib); r.lib = nullptr; }
+  return r;
+}
+
+// batched real 2-D forward transform of (N, Lh, Lw) doubles -> (N, Lh, Lw/2+1) complex, one plan per (device, Lh, Lw, N), kept for the process
+int fft_plan(pcnn_handle h, int Lh, int Lw, int N, FftPlan** out) {
+  static std::map<std::tuple<int, int, int, int>, FftPlan> plans;
+  static std::mutex mu;
+  RocFFT& r = rocfft();
+  if (!r.lib) PCNN_FAIL(h, "pcnn_fd_poisson_fft: %s", r.why.c_str());
+  std::lock_guard<std::mutex> lock(mu);
+  FftPlan& p = plans[std::make_tuple(h->device, Lh, Lw, N)];
+  if (!p.plan) {
+    const size_t lengths[2] = {(size_t)Lw, (size_t)Lh};            // rocFFT: fastest dimension first
+    // placement 1 = not in place, transform type 2 = real forward, precision 1 = double (rocfft.h enums)
+    if (r.plan_create(&p.plan, 1, 2, 1, 2, lengths, (size_t)N, nullptr) != 0) { p.plan = nullptr; PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_plan_create(%d x %d x %d) failed", N, Lh, Lw); }
+    if (r.info_create(&p.info) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_create failed");
+    if (r.work_size(p.plan, &p.work_bytes) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_plan_get_work_buffer_size failed");
+    if (p.work_bytes) {
+      if (hipMalloc(&p.work, p.work_bytes) != hipSuccess) PCNN_FAIL(h, "pcnn_fd_poisson_fft: cannot allocate %zu B of rocFFT work buffer", p.work_bytes);
+      if (r.set_work(p.info, p.work, p.work_bytes) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_set_work_buffer failed");
+    }
+  }
+  *out = &p;
+  return 0;
+}
+
+// E[n][i][j] = odd-odd extension of src(n, ii, jj) to (2 (nh + 1)) x (2 (nw + 1)): zero on rows / columns 0 and n + 1, mirrored with a sign change beyond
+template <typename Src>
+__device__ __forceinline__ void odd_extend(int64_t total, int nh, int nw, double* __restrict__ E, Src src) {
+  const int Lh = 2 * (nh + 1), Lw = 2 * (nw + 1);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx % Lw; const int i = (idx / Lw) % Lh; const int n = idx / ((int64_t)Lh * Lw);
+    double v = 0.0;
+    if (i != 0 && i != nh + 1 && j != 0 && j != nw + 1) {
+      const int ii = i <= nh ? i - 1 : 2 * nh + 1 - i, jj = j <= nw ? j - 1 : 2 * nw + 1 - j;
+      v = src(n, ii, jj);
+      if ((i > nh) != (j > nw)) v = -v;
+    }
+    E[idx] = v;
+  }
+}
+__global__ void dst_extend_rhs_kernel(int N, int nh, int nw, const double* __restrict__ B, double* __restrict__ E) {
+  odd_extend((int64_t)N * 4 * (nh + 1) * (nw + 1), nh, nw, E, [&](int n, int ii, int jj) { return B[((int64_t)n * nh + ii) * nw + jj]; });
+}
+// coefficients (D B D)[a][b] = -Re Ehat[a+1][b+1] / 4, divided by the eigenvalues, extended again
+__global__ void dst_extend_coeff_kernel(int N, int nh, int nw, const double2* __restrict__ Eh, const double* __restrict__ lam_h, const double* __restrict__ lam_w,
+                                        double* __restrict__ E) {
+  const int Lh = 2 * (nh + 1), Cw = nw + 2;                         // Lw / 2 + 1 complex columns
+  odd_extend((int64_t)N * 4 * (nh + 1) * (nw + 1), nh, nw, E, [&](int n, int a, int b) {
+    return -0.25 * Eh[((int64_t)n * Lh + a + 1) * Cw + b + 1].x / (lam_h[a] + lam_w[b]);
+  });
+}
+__global__ void dst_fft_write_soln_kernel(int N, int H, int W, const double2* __restrict__ Eh, const float* __restrict__ left, const float* __restrict__ right,
+                                          const float* __restrict__ bottom, const float* __restrict__ top, float* __restrict__ soln) {
+  const int nh = H - 2, nw = W - 2, Lh = 2 * (nh + 1), Cw = nw + 2;
+  const double scale = -0.25 * (2.0 / (nh + 1)) * (2.0 / (nw + 1));
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx % W; const int i = (idx / W) % H; const int n = idx / ((int64_t)H * W);
+    float v;
+    if (i == 0) v = left[(int64_t)n * W + j];
+    else if (i == H - 1) v = right[(int64_t)n * W + j];
+    else if (j == 0) v = bottom[(int64_t)n * H + i];
+    else if (j == W - 1) v = top[(int64_t)n * H + i];
+    else v = (float)(scale * Eh[((int64_t)n * Lh + i) * Cw + j].x);     // u[i-1][j-1] sits at Ehat[i][j]
+    soln[idx] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t pcnn_fd_poisson_fft_workspace(int N, int H, int W) {
+  if (N < 1 || H < 3 || W < 3) return 0;
+  const size_t nh = H - 2, nw = W - 2;
+  return ((size_t)N * nh * nw + (size_t)N * 4 * (nh + 1) * (nw + 1) + 2 * (size_t)N * 2 * (nh + 1) * (nw + 2)) * sizeof(double);
+}
+
+extern "C" int pcnn_fd_poisson_fft(pcnn_handle h, int N, int H, int W, const float* rhs, const float* left, const float* right, const float* bottom,
+                                   const float* top, const float* dx, const double* lam_h, const double* lam_w, void* workspace, float* soln) {
+  PCNN_REQUIRE(h, h && rhs && left && right && bottom && top && dx && lam_h && lam_w && workspace && soln, "pcnn_fd_poisson_fft: null argument");
+  PCNN_REQUIRE(h, H >= 3 && W >= 3 && N >= 1, "pcnn_fd_poisson_fft: grid %dx%d too small", H, W);
+  const int nh = H - 2, nw = W - 2, Lh = 2 * (nh + 1), Lw = 2 * (nw + 1);
+  FftPlan* pl;
+  if (int rc = fft_plan(h, Lh, Lw, N, &pl)) return rc;
+  RocFFT& r = rocfft();
+  double* Bm = static_cast<double*>(workspace);
+  double* E = Bm + (int64_t)N * nh * nw;
+  double2* Eh = reinterpret_cast<double2*>(E + (int64_t)N * Lh * Lw);
+  if (r.set_stream(pl->info, h->stream) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_set_stream failed");
+  hipLaunchKernelGGL(dst_build_rhs_kernel, grid1d((int64_t)N * nh * nw), dim3(256), 0, h->stream, N, H, W, rhs, left, right, bottom, top, dx, Bm);
+  hipLaunchKernelGGL(dst_extend_rhs_kernel, grid1d((int64_t)N * Lh * Lw), dim3(256), 0, h->stream, N, nh, nw, Bm, E);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_fft(extend)");
+  void* in[1] = {E}; void* out[1] = {Eh};
+  if (r.execute(pl->plan, in, out, pl->info) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execute failed");
+  hipLaunchKernelGGL(dst_extend_coeff_kernel, grid1d((int64_t)N * Lh * Lw), dim3(256), 0, h->stream, N, nh, nw, Eh, lam_h, lam_w, E);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_fft(coefficients)");
+  if (r.execute(pl->plan, in, out, pl->info) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execute failed");
+  hipLaunchKernelGGL(dst_fft_write_soln_kernel, grid1d((int64_t)N * H * W), dim3(256), 0, h->stream, N, H, W, Eh, left, right, bottom, top, soln);
+  PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_fft(write)");
+  return 0;
+}
+
 extern "C" int pcnn_series_synthesis(pcnn_handle h, int N, int H, int W, int ka, int kb, const float* coef, int trig, int accumulate, float* out) {
   PCNN_REQUIRE(h, h && coef && out && N >= 1 && H >= 1 && W >= 1, "pcnn_series_synthesis: bad argument");
   PCNN_REQUIRE(h, ka >= 1 && kb >= 1 && ka <= SYN_MAXK && kb <= SYN_MAXK, "pcnn_series_synthesis: %dx%d coefficients unsupported (<=%d)", ka, kb, SYN_MAXK);

@@ -24,11 +24,29 @@ def dst_matrices(n, device):
     return _dst_cache[key]
 
 
-def fd_poisson_dst(rhs, left, right, bottom, top, dx):
-    """rhs (N,H,W); left/right (N,W); bottom/top (N,H); dx (N,) -> soln (N,H,W), all fp32 CUDA tensors."""
+FFT_FROM = 2048          # solver='auto': rocFFT route from this many points per axis - measured crossover (profiles/r04_fd_solver_routes.txt: per sample
+                         # 0.25 vs 0.35 ms at 1024^2, 0.80 vs 1.11 at 1536^2, 1.86 vs 1.66 at 2048^2; the odd extension has awkward lengths, 2046 = 2 3 11 31)
+
+
+def fd_poisson_dst(rhs, left, right, bottom, top, dx, solver='auto'):
+    """rhs (N,H,W); left/right (N,W); bottom/top (N,H); dx (N,) -> soln (N,H,W), all fp32 CUDA tensors.
+    solver: 'gemm' (DST-I as fp64 matrix-core GEMMs, pcnn_fd_poisson_dst), 'fft' (rocFFT, pcnn_fd_poisson_fft) or 'auto' (fft from FFT_FROM
+    points per axis; environment PCNN_FD_SOLVER overrides)."""
+    import os
+    from ctypes import c_size_t
     N, H, W = rhs.shape
     Sh, lh = dst_matrices(H, rhs.device)
     Sw, lw = dst_matrices(W, rhs.device)
+    solver = os.environ.get('PCNN_FD_SOLVER', solver)
+    if solver not in ('auto', 'gemm', 'fft'):
+        raise ValueError("solver must be 'auto', 'gemm' or 'fft'")
+    if solver == 'fft' or (solver == 'auto' and min(H, W) >= FFT_FROM):
+        lib = _lib.load()
+        lib.pcnn_fd_poisson_fft_workspace.restype = c_size_t
+        ws = torch.empty((lib.pcnn_fd_poisson_fft_workspace(c_int(N), c_int(H), c_int(W)) + 7) // 8, dtype=torch.float64, device=rhs.device)
+        soln = torch.empty_like(rhs)
+        handle().call('pcnn_fd_poisson_fft', c_int(N), c_int(H), c_int(W), _p(rhs), _p(left), _p(right), _p(bottom), _p(top), _p(dx), _p(lh), _p(lw), _p(ws), _p(soln))
+        return soln
     tmp = torch.empty(2 * N * (H - 2) * (W - 2), dtype=torch.float64, device=rhs.device)
     soln = torch.empty_like(rhs)
     handle().call('pcnn_fd_poisson_dst', c_int(N), c_int(H), c_int(W), _p(rhs), _p(left), _p(right), _p(bottom), _p(top), _p(dx),

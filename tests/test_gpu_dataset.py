@@ -17,8 +17,11 @@ def dev(a):
     return torch.tensor(np.asarray(a), dtype=torch.float32, device='cuda')
 
 
+@pytest.mark.parametrize('solver', ['gemm', 'fft'])
 @pytest.mark.parametrize('H,W', [(9, 7), (33, 47), (64, 64), (130, 101)])
-def test_dst_solve_matches_sparse_direct_solve(H, W):
+def test_dst_solve_matches_sparse_direct_solve(H, W, solver):
+    """Both routes of the Dirichlet solve - the DST-I as fp64 matrix-core GEMMs and as rocFFT transforms of the odd extension (BASELINE.json
+    north star) - against the sparse direct solve of the reference's linear system."""
     from poisson_cnn_amd.dataset import _kernels as K
     rng = np.random.default_rng(H)
     N = 3
@@ -28,11 +31,34 @@ def test_dst_solve_matches_sparse_direct_solve(H, W):
           'bottom': f32(rng.standard_normal((N, H))), 'top': f32(rng.standard_normal((N, H)))}
     dx = f32(rng.uniform(5e-3, 5e-2, N))
     ref = ods.multigrid_poisson_solve(rhs, bc, dx)
-    got = K.fd_poisson_dst(dev(rhs), dev(bc['left']), dev(bc['right']), dev(bc['bottom']), dev(bc['top']), dev(dx)).cpu().numpy()
+    got = K.fd_poisson_dst(dev(rhs), dev(bc['left']), dev(bc['right']), dev(bc['bottom']), dev(bc['top']), dev(dx), solver=solver).cpu().numpy()
     assert rel(got, ref) < 2e-7            # fp64 solve, result rounded to fp32 once
     # discrete residual of the fp64 reference is ~0; ours is limited by the fp32 output rounding only
     assert np.array_equal(got[:, 0, :], bc['left'].astype(np.float32)) and np.array_equal(got[:, -1, :], bc['right'].astype(np.float32))
     assert np.array_equal(got[:, 1:-1, 0], bc['bottom'].astype(np.float32)[:, 1:-1]) and np.array_equal(got[:, 1:-1, -1], bc['top'].astype(np.float32)[:, 1:-1])
+
+
+@pytest.mark.parametrize('H,W,N', [(512, 512, 4), (1024, 1024, 2), (1025, 700, 1)])
+def test_rocfft_route_agrees_with_the_gemm_route_at_full_size(H, W, N):
+    """At BASELINE.json's grid sizes the GEMM-DST is the checker of the rocFFT route (the sparse direct solve takes minutes there): the two
+    fp64 pipelines must agree to the fp32 rounding of the stored solution, and the 5-point residual of the rocFFT solution must be at the
+    level that rounding allows.  solver='auto' picks rocFFT from K.FFT_FROM (2048, the measured crossover) points per axis."""
+    from poisson_cnn_amd.dataset import _kernels as K
+    g = torch.Generator(device='cuda').manual_seed(H + W)
+    rhs = torch.randn(N, H, W, device='cuda', generator=g)
+    left, right = torch.randn(N, W, device='cuda', generator=g), torch.randn(N, W, device='cuda', generator=g)
+    bottom, top = torch.randn(N, H, device='cuda', generator=g), torch.randn(N, H, device='cuda', generator=g)
+    dx = torch.rand(N, device='cuda', generator=g) * 4.5e-2 + 5e-3
+    a = K.fd_poisson_dst(rhs, left, right, bottom, top, dx, solver='gemm')
+    b = K.fd_poisson_dst(rhs, left, right, bottom, top, dx, solver='fft')
+    assert float((a.double() - b.double()).norm() / a.double().norm()) < 1e-7 and float((a - b).abs().max() / a.abs().max()) < 3e-7
+    c = K.fd_poisson_dst(rhs, left, right, bottom, top, dx, solver='auto')
+    assert torch.equal(c, b if min(H, W) >= K.FFT_FROM else a)
+    u, f, h = b.double(), rhs.double(), dx.double().reshape(-1, 1, 1)
+    lap = (u[:, 2:, 1:-1] + u[:, :-2, 1:-1] + u[:, 1:-1, 2:] + u[:, 1:-1, :-2] - 4 * u[:, 1:-1, 1:-1]) / h ** 2
+    res = (lap - f[:, 1:-1, 1:-1]).abs().amax(dim=(1, 2))
+    bound = 8 * 2.0 ** -24 * u.abs().amax(dim=(1, 2)) / h.reshape(-1) ** 2 + 1e-4 * f.abs().amax(dim=(1, 2))
+    assert bool((res <= bound).all()), (res, bound)
 
 
 def test_gemm_f64_and_dst_orthonormality():
