@@ -94,7 +94,10 @@ def conv2d_valid_fft(x, w, bias=None, tile=256):
         for x0 in range(0, Wo, Vx):
             xt = x[:, :, y0:y0 + T, x0:x0 + T]
             xh = torch.fft.rfft2(xt, s=(T, T))                                     # zero-padded at the image's far edges
-            yt = torch.fft.irfft2(torch.einsum('ncyx,ocyx->noyx', xh, wh), s=(T, T))
+            # channel contraction per frequency, eight output channels at a time (an einsum of the same contraction is 8x slower on complex128;
+            # the whole (O, C, T, T/2+1) product at once is a 0.5 GB temporary per tile)
+            yh = torch.cat([(xh.unsqueeze(1) * wh[o:o + 8].unsqueeze(0)).sum(2) for o in range(0, O, 8)], 1)
+            yt = torch.fft.irfft2(yh, s=(T, T))
             cols.append(yt[:, :, :min(Vy, Ho - y0), :min(Vx, Wo - x0)])
         rows.append(torch.cat(cols, 3))
     y = torch.cat(rows, 2)

@@ -12,10 +12,12 @@ The oracle is oracle/hpnn.py on oracle/torch_twin.py (fp64 torch-CPU; its forwar
 in tests/test_oracle_ops.py - at these sizes the pure-numpy convolution would take hours).  The TensorFlow reference cannot run
 in the build container.  Run time on 8 cores: about 15 minutes, ~30 GB of memory.
 
-  C4 backward (round 4, `c4grad`): full training-step quantities of that SAME 1024^2 sample (global_batch_size = 8: its share of the
-      bench batch's loss) - loss, first / last-layer gradients, every parameter's gradient norm.  At 1024^2 the fp64 autograd graph
-      would keep ~120 GB of intermediates, so every convolution-like op of the twin is wrapped in torch.utils.checkpoint (only its
-      input stays, the padded copy / pre-activation are recomputed in the backward pass): same arithmetic, ~45 GB, ~45 minutes.
+  C4 backward (round 4, `c4grad`): full training-step quantities of that SAME 1024^2 sample (global_batch_size = 8: its share of the bench
+      batch's loss) - loss, first / last-layer gradients, gradients of wide-filter layers that switch to 64-point tiles only at this size
+      (15 / 13 / 11 taps), every parameter's gradient norm.  PyTorch's fp64 CPU convolution cannot do this (it unfolds the image: 60 GB and
+      5.5 minutes of backward for ONE 15 x 15 x 32 layer), so the twin evaluates its large convolutions by overlap-save FFT
+      (oracle/torch_twin.set_fft_conv; pinned to F.conv2d in tests/test_oracle_ops.py), and every convolution-like op runs under
+      torch.utils.checkpoint (only its input stays alive; identical arithmetic).  About 15 minutes, ~25 GB.
 
     python tests/golden/make_atsize_golden.py [c2] [c3] [c4] [c4grad]        (c4 alone: about 10 minutes)
 """
@@ -69,31 +71,6 @@ def c3_inputs(n=32):
 
 
 def c4_target():
-    """Target of the C4 training step: the smooth low-order sine series of c3_inputs at 1024^2 (seed 4 stream continued)."""
-    rng = np.random.default_rng(44)
-    t = np.linspace(0, np.pi, 1024)
-    coef = rng.standard_normal((8, 4, 4)) * 0.1
-    S = np.stack([np.sin((a + 1) * t) for a in range(4)])
-    return np.einsum('nab,ah,bw->nhw', coef, S, S)[:, None].astype(np.float32)
-
-
-class _CheckpointedTwin:
-    """oracle.torch_twin with its convolution-like ops run under torch.utils.checkpoint (identical arithmetic; the op's internal
-    intermediates are recomputed in the backward pass instead of being kept)."""
-    _WRAP = ('padded_conv2d', 'same_conv2d', 'conv2d_transpose_same', 'resize2d', 'pool2d_same')
-
-    def __getattr__(self, name):
-        fn = getattr(torch_twin, name)
-        if name not in self._WRAP:
-            return fn
-        from torch.utils.checkpoint import checkpoint
-
-        def wrapped(x, *a, **k):
-            return checkpoint(lambda x_: fn(x_, *a, **k), x, use_reentrant=False)
-        return wrapped
-
-
-def c4_target():
     """Target of the C4 training step: the smooth low-order sine series of c3_inputs at 1024^2."""
     rng = np.random.default_rng(44)
     t = np.linspace(0, np.pi, 1024)
@@ -114,7 +91,11 @@ class _CheckpointedTwin:
         from torch.utils.checkpoint import checkpoint
 
         def wrapped(x, *a, **k):
-            return checkpoint(lambda x_: fn(x_, *a, **k), x, use_reentrant=False)
+            r = checkpoint(lambda x_: fn(x_, *a, **k), x, use_reentrant=False)
+            if os.environ.get('PCNN_GOLDEN_VERBOSE'):
+                import psutil
+                print('   %s %s -> %s, rss %.1f GB' % (name, tuple(x.shape), tuple(r.shape), psutil.Process().memory_info().rss / 1e9), flush=True)
+            return r
         return wrapped
 
 
@@ -155,35 +136,19 @@ def main():
         print('c4: %.1f s, max|y| %.4g' % (time.time() - t0, np.abs(out['c4_out']).max()), flush=True)
         np.savez_compressed(PATH, **out)
     if 'c4grad' in which:
-        cfg = configs.hpnn()['model']
-        p = ohpnn.init_params(cfg, seed=WEIGHT_SEED, gain=WEIGHT_GAIN, randomize_all=True)
-        rhs, dx = c4_inputs()
-        tgt = c4_target()
-        k = 3
-        pt = {n: torch.tensor(v, dtype=torch.float64, requires_grad=not n.endswith(('moving_mean', 'moving_variance'))) for n, v in p.items()}
-        t0 = time.time()
-        r64, d64 = rhs[k:k + 1].astype(np.float64), dx[k:k + 1].astype(np.float64)
-        pred = ohpnn.forward(_CheckpointedTwin(), cfg, pt, torch.tensor(r64), torch.tensor(d64))
-        print('c4grad: forward %.1f s' % (time.time() - t0), flush=True)
-        L = oloss.loss_wrapper(global_batch_size=8, **full['training']['loss_parameters'])
-        loss = L(tgt[k:k + 1].astype(np.float64), pred, torch.tensor(r64), np.concatenate([d64, d64], 1))
-        loss.backward()
-        names = [n for n, v in pt.items() if v.requires_grad]
-        out['c4_loss'] = np.float64(loss.detach())
-        out['c4_pred_check'] = np.float64(np.linalg.norm(pred.detach().numpy().astype(np.float32) - out['c4_out']) / np.linalg.norm(out['c4_out'])) if 'c4_out' in out else np.float64(-1)
-        out['c4_grad_names'] = np.array(names)
-        out['c4_grad_norms'] = np.array([float(pt[n].grad.norm()) for n in names])
-        for n in ('pre/conv0/kernel', 'final/out0/kernel', 'final/out0/bias', 'final/out1/kernel', 'final/out1/bias', 'final/stage0/conv/bias',
-                  'pre/conv2/kernel', 'final/stage0/conv/kernel', 'final/stage0/res/conv1/kernel', 'final/stage1/conv/kernel',
-                  'final/stage2/conv/kernel', 'deconv_f2/res0/conv1/kernel', 'post_merge_conv/kernel'):
-            g = pt[n].grad.numpy()
-            # the wide-filter gradients (k = 15 / 13 / 11 / 9: the 64- and 32-point spectral tiles at 1024^2) are kept in float32: the
-            # rounding (6e-8) is far below the test tolerance and the fixture stays a few MB
-            out['c4_grad:%s' % n.replace('/', '.')] = g.astype(np.float32 if g.size > 4096 else np.float64)
-        print('c4grad: %.1f s, loss %.6g, pred vs c4_out %.3g' % (time.time() - t0, float(loss.detach()), float(out['c4_pred_check'])), flush=True)
-        np.savez_compressed(PATH, **out)
-        del pt, pred, loss
-    if 'c4grad' in which:
+        import threading
+        import psutil
+        proc = psutil.Process()
+
+        def _guard():                         # the build container has 64 GB and no swap: report the resident set, stop before the kernel does
+            while True:
+                r = proc.memory_info().rss / 1e9
+                print('   [rss %.1f GB]' % r, flush=True)
+                if r > 45:
+                    print('resident set above 45 GB - aborting', flush=True)
+                    os._exit(3)
+                time.sleep(15)
+        threading.Thread(target=_guard, daemon=True).start()
         cfg = configs.hpnn()['model']
         p = ohpnn.init_params(cfg, seed=WEIGHT_SEED, gain=WEIGHT_GAIN, randomize_all=True)
         rhs, dx = c4_inputs()
