@@ -39,7 +39,7 @@ namespace {
 constexpr int T = 64, ROWS = 4096;
 // table block (floats): GX [px][ks 16][lane]; Y [h][ks 16][C S R][lane]; IY [hh][C S][yb 2][ks 8][lane]; IR [hh][yb][ks 8][lane];
 // IX [ex][tau 4][kk 2][xb 2][lane]
-constexpr int TB_GX = 0, TB_Y = 2048, TB_IY = 8192, TB_IR = 12288, TB_IX = 14336, TB_END = 16384;
+constexpr int TB_GX = 0, TB_Y = 2048, TB_IY = 8192, TB_IR = 12288, TB_IX = 14336, TB_Y4 = 16384, TB_END = 16384 + 3 * 4096;
 static_assert(TB_END <= TAB64_FLOATS, "table block");
 constexpr int SB_FLOATS = 8 * 32 * 32;             // one stage buffer of the forward transform: 8 rows x 32 columns x 32 channels
 
@@ -253,6 +253,153 @@ __global__ __launch_bounds__(512, 2) void spec64_fwd_kernel(FwdParams p) {
         __builtin_nontemporal_store(Z[jj][1][r], &out[(unsigned)(r1 * RS + cv)]);
       }
       Z[jj][0] = zero16(); Z[jj][1] = zero16();
+    }
+    if (!more_x) break;
+    item = item_l;                                          // == the item of cx
+    cy = cx;
+    st = 0;
+  }
+}
+
+// The same transform with a SECOND radix-2 step on the y axis (round 4): class h2 = fy mod 4 per wave, sixteen-point transforms of
+// W[y] = sum_q D[y + 16 q] (-i)^(q h2) formed on the vector ALU from the four stage rows y + 16 q; real and imaginary outputs stacked in the 32 rows of ONE
+// accumulator tile ([Zr; Zi] = [C S; -S C] [Wr; Wi], K step = (Wr[y], Wi[y])), so the y axis costs 16 instead of 32 MFMAs per wave and stage.
+template <bool MASKED>
+__global__ __launch_bounds__(512, 2) void spec64_fwd4_kernel(FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const SB = lds;                                   // [2][8 rows][32 columns][32 channels]
+  float* const TY = lds + 2 * SB_FLOATS;                   // Y4 | Y4A | Y4B, each [h2][y 16][lane]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h2 = wave & 3, pg = wave >> 2;                 // this wave's y-frequency class fy = 4 m + h2 and its group of eight column pairs
+  for (int i = tid; i < 3 * 4096; i += 512) TY[i] = p.tab[TB_Y4 + i];
+  const int ntg = p.ntile * p.groups;
+  const int nitem = 2 * ((ntg + 7) & ~7);                  // item -> (tile group, px): px = (item >> 3) & 1, group = ((item >> 4) << 3) | (item & 7):
+                                                           // with a grid that is a multiple of 16 a workgroup keeps ONE parity (its table stays in
+                                                           // registers) and the two parities of a tile run on workgroups b and b + 8 (one XCD's L2)
+  auto group_of = [&](int it) { return ((it >> 4) << 3) | (it & 7); };
+  auto next_item = [&](int it) { it += gridDim.x; while (it < nitem && group_of(it) >= ntg) it += gridDim.x; return it; };
+  int item = blockIdx.x;
+  if (group_of(item) >= ntg) item = next_item(item);
+  if (item >= nitem) return;
+  const int px = (item >> 3) & 1;
+  const bool special = px == 0 && pg == 0;                 // this wave's first pair is the two real columns (fx = 0 | 32)
+  const float sgx = px ? -1.f : 1.f;
+  // second radix-2 step: W[y] = sum_q D[y + 16 q] (-i)^(q h2), y < 16.  This lane's B row is the component `half` (0: Re, 1: Im) of W: from row
+  // q it takes component coff[q] (float offset 0 | 16 columns) with sign sg[q].  The real pair: B = W_re (pass a) / W_im (pass b) of the REAL
+  // column `half` (fx = 0 | 32), coefficients ca / cb.
+  int coff[4]; float sg[4], ca[4], cb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = (q * h2) & 3;
+    const bool src_im = (e & 1) ? !half : (bool)half;
+    coff[q] = src_im ? 16 * 32 : 0;
+    sg[q] = half == 0 ? (e < 2 ? 1.f : -1.f) : ((e == 0 || e == 3) ? 1.f : -1.f);
+    ca[q] = (h2 & 1) ? ((q & 1) ? 0.f : (q == 0 ? 1.f : -1.f)) : ((h2 == 2 && (q & 1)) ? -1.f : 1.f);
+    cb[q] = (h2 & 1) ? ((q & 1) ? ((q == 1) == (h2 == 1) ? -1.f : 1.f) : 0.f) : 0.f;
+  }
+  const bool passb = (h2 & 1) != 0;                        // the real pair's W has an imaginary part only in the odd classes
+  float gx[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) gx[ks] = p.tab[TB_GX + (px * 16 + ks) * 64 + lane];
+  const float* const ty = TY + h2 * (16 * 64) + lane;
+  const int srow = (wave & 1) + 16 * (wave >> 1);          // this wave's window row in stage 0 (stage s: + 2 s): stage rows y = 2 s + ky, + 16 q -> buffer row ky + 2 q
+  // LDS addresses of this lane: its x-axis results (row = wave) and the first column of its eight pairs
+  const int wr_off = (wave * 32 + 4 * half) * 32 + c;
+  const int rd_off = (8 * pg) * 32 + c;
+  // Software pipeline over the stages q = 0, 1, ... of this workgroup's items (8 per item): while the y axis consumes stage q from one LDS
+  // buffer, the x axis of stage q + 1 runs on the matrix pipe from registers and lands in the other buffer, and the window row of stage q + 2
+  // is in flight from global.  cy / cx / cl: the items those three stages belong to.  One LDS barrier per stage.
+  Ctx64 cy, cx, cl;
+  make_ctx(p, group_of(item), half, c, cy);
+  cx = cy; cl = cy;
+  float lo[16], hi[16];
+  f32x16 Z[8];                                             // pair jj: rows 0..15 Re, 16..31 Im of the sixteen frequencies of this class
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) Z[jj] = zero16();
+  int item_l = item;                                        // item of the load stage
+  load_row64<MASKED>(p, cl, srow, half, lo, hi);
+  {
+    const f32x16 acc = x_row64<MASKED>(p, cx, srow, half, sgx, gx, lo, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) SB[wr_off + (8 * (r >> 2) + (r & 3)) * 32] = acc[r];
+  }
+  load_row64<MASKED>(p, cl, srow + 2, half, lo, hi);      // stage 1
+  lds_barrier();
+  int st = 0;                                               // stage of the y axis
+  bool more_x = true;                                       // a stage q + 1 exists
+#pragma unroll 1
+  for (;;) {
+    const float* const sb = SB + (st & 1) * SB_FLOATS;
+    float* const sbn = SB + ((st + 1) & 1) * SB_FLOATS;
+    const int stx = (st + 1) & 7;                           // stage of the x axis (stage q + 1), of item cx
+    // ---- x axis of stage q + 1: its sixteen MFMAs run while the LDS reads of the y axis below are in flight
+    f32x16 accx = zero16();
+    if (more_x) accx = x_row64<MASKED>(p, cx, srow + 2 * stx, half, sgx, gx, lo, hi);
+    // ---- the window row of stage q + 2 (item cl): its latency sits under this stage's y axis and the next stage's
+    {
+      const int stl = (st + 2) & 7;
+      if (stl == 0 && more_x) { item_l = next_item(item_l); if (item_l < nitem) make_ctx(p, group_of(item_l), half, c, cl); }
+      if (item_l < nitem) load_row64<MASKED>(p, cl, srow + 2 * stl, half, lo, hi);
+    }
+    // ---- y axis of stage q: the two rows y = 2 st + ky of the sixteen-point transforms.  K step = (Re W[y], Im W[y]) in the lane halves;
+    // accumulator rows 0..15 = Re, 16..31 = Im of this class' frequencies: ONE MFMA per pair and row (the parity form took four)
+#pragma unroll
+    for (int ky = 0; ky < 2; ++ky) {
+      const float* t = ty + (2 * st + ky) * 64;
+      const float ay = t[0];
+      const float* s0 = sb + rd_off + ky * 1024;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        if (jj == 0 && special) {
+          const float* sq = s0 + half * (16 * 32);
+          const float d0 = sq[0], d1 = sq[2048], d2 = sq[4096], d3 = sq[6144];
+          Z[0] = mfma(t[4096], ca[0] * d0 + ca[1] * d1 + ca[2] * d2 + ca[3] * d3, Z[0]);
+          if (passb) Z[0] = mfma(t[8192], cb[1] * d1 + cb[3] * d3, Z[0]);
+        } else {
+          const float* sq = s0 + jj * 32;
+          const float w = sq[coff[0]] + sg[1] * sq[2048 + coff[1]] + sg[2] * sq[4096 + coff[2]] + sg[3] * sq[6144 + coff[3]];
+          Z[jj] = mfma(ay, w, Z[jj]);
+        }
+      }
+    }
+    if (more_x) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sbn[wr_off + (8 * (r >> 2) + (r & 3)) * 32] = accx[r];
+    }
+    lds_barrier();
+    if (++st < 8) {
+      if (st == 7) {                                        // the x stage moves on to the next item (its first row is what lo / hi receive now)
+        cx = cl;
+        more_x = item_l < nitem && (item_l != item);
+      }
+      continue;
+    }
+    // ---- the item's spectrum rows, straight from the accumulators (accumulator row m <-> fy = 2 m + h).  (Measured and rejected: the
+    // transposed product - data as the A operand - whose accumulators hold four consecutive channels per lane: 32 16-byte stores instead of
+    // 128 dword stores, but each store instruction then writes 32-byte pieces of 32 different rows: 1.24 -> 1.39 ms per 8 x 1024^2 layer.)
+    float* const out = p.sp + sp_item(cy.tg, ROWS);
+    // the 128 store offsets are invariant across items: left alone, the compiler hoists all of them out of the persistent loop (256 registers
+    // of 64-bit offsets, spilled); opaque lane coordinates make it form them here, one v_add each
+    int hv = half, cv = c;
+    asm volatile("" : "+v"(hv), "+v"(cv));
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int fx = 2 * (8 * pg + jj) + px;
+      const int base = 128 + 128 * (fx - 1) + h2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (DBG64(p.cpt, 1) && r > 0) continue;                  // removal study: one store instead of sixteen
+        const int m = 8 * (r >> 2) + 4 * hv + (r & 3);           // accumulator row: m < 16 Re, m >= 16 Im of fy = 4 (m & 15) + h2
+        int row = base + 4 * (m & 15) + 64 * (m >> 4);
+        if (jj == 0 && special) {                                // rows m < 16: the real column fx = 0, m >= 16: fx = 32; half-complex row order
+          const int mm = m & 15, im = h2 == 0 ? (mm > 8) : (mm > 7);
+          const int fy = 4 * (im ? mm - 8 : mm) + h2;
+          row = 64 * (m >> 4) + (im ? 32 + fy : fy);
+        }
+        __builtin_nontemporal_store(Z[jj][r], &out[(unsigned)(row * RS + cv)]);      // streamed once, read by the next kernel: see spectral_conv.hip
+      }
+      Z[jj] = zero16();
     }
     if (!more_x) break;
     item = item_l;                                          // == the item of cx
@@ -543,6 +690,22 @@ void build_tables64(float* tab, int* slots) {
         t[128] = (float)ry_val(h, m, x, 1.0);
       }
     }
+    // radix-4 y axis of spec64_fwd4_kernel: A[m][k = half] for K step y < 16 of class h2.  Complex pairs (Y4): rows m < 16 Re, m >= 16 Im of
+    // fy = 4 (m & 15) + h2; k = 0 multiplies Re W[y], k = 1 Im W[y]: [C S; -S C].  The real pair: rows m < 16 belong to the real column fx = 0
+    // and take k = 0 only, rows m >= 16 to fx = 32 and take k = 1 only; pass a (Y4A) multiplies Re W, pass b (Y4B) Im W; row order = the
+    // half-complex order of the class (class 0: Re fy = 0, 4 .. 32 then Im fy = 4 .. 28; else Re of its 8 frequencies <= 31, then their Im).
+    for (int h2 = 0; h2 < 4; ++h2)
+      for (int y = 0; y < 16; ++y) {
+        const int mm = m & 15;
+        const double th = tp * (((4 * mm + h2) * y) & 63);
+        tab[TB_Y4 + (h2 * 16 + y) * 64 + lane] = (float)(m < 16 ? (half ? sin(th) : cos(th)) : (half ? cos(th) : -sin(th)));
+        const bool im = h2 == 0 ? mm > 8 : mm > 7;
+        const int fy = 4 * (im ? mm - 8 : mm) + h2;
+        const double ts = tp * ((fy * y) & 63);
+        const bool mine = (m >= 16) == (half == 1);
+        tab[TB_Y4 + 4096 + (h2 * 16 + y) * 64 + lane] = mine ? (float)(im ? -sin(ts) : cos(ts)) : 0.f;
+        tab[TB_Y4 + 8192 + (h2 * 16 + y) * 64 + lane] = (mine && (h2 & 1)) ? (float)(im ? cos(ts) : sin(ts)) : 0.f;
+      }
     // 16x16x4 forms of the inverse: A[m = lane & 15][k = lane >> 4]
     const int mr = lane & 15, kq = lane >> 4;
     for (int hh = 0; hh < 2; ++hh)
@@ -589,8 +752,20 @@ void launch_fwd64(pcnn_handle h, FwdParams p, int ntile) {
   const int ntg = ntile * p.groups;
   const int nitem = 2 * ((ntg + 7) & ~7);
   const unsigned grid = (unsigned)std::min((nitem + 15) & ~15, 256);
-  const size_t lds = (2 * SB_FLOATS + 6144) * sizeof(float);
   const bool masked = p.ylim < T || p.xlim < T || p.ext_y < (1 << 29) || p.ext_x < (1 << 29);
+  const int radix = getenv("PCNN_FWD64_RADIX") ? atoi(getenv("PCNN_FWD64_RADIX")) : 4;      // 2: the one-step (parity) form of round 3
+  if (radix == 4) {
+    const size_t lds4 = (2 * SB_FLOATS + 3 * 4096) * sizeof(float);
+    if (masked) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spec64_fwd4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      hipLaunchKernelGGL(spec64_fwd4_kernel<true>, dim3(grid), dim3(512), lds4, h->stream, p);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spec64_fwd4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      hipLaunchKernelGGL(spec64_fwd4_kernel<false>, dim3(grid), dim3(512), lds4, h->stream, p);
+    }
+    return;
+  }
+  const size_t lds = (2 * SB_FLOATS + 6144) * sizeof(float);
   if (masked) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spec64_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(spec64_fwd_kernel<true>, dim3(grid), dim3(512), lds, h->stream, p);

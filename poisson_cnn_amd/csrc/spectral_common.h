@@ -75,7 +75,7 @@ struct InvParams {
 };
 
 // 64-point tiles (spectral64.hip): table block, slots are built by build_tables64; the launchers take the same parameter blocks (pack = 1)
-constexpr int TAB64_FLOATS = 20480;
+constexpr int TAB64_FLOATS = 32768;
 void build_tables64(float* tab, int* slots);                 // TAB64_FLOATS floats, 2048 x int4 slots
 void launch_fwd64(pcnn_handle h, FwdParams p, int ntile);     // p.tab: the 64-point table block
 void launch_inv64(pcnn_handle h, InvParams p, int ntile);

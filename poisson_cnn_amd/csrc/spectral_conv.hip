@@ -941,6 +941,27 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
 // corr(x tile, dz window)[k-1-t] - so that neither x's windows nor a second, masked copy of dz have to be transformed.
 // d: the forward convolution; dg: its data-gradient convolution (input dz, filter w_flipped (kh,kw,Cout,Cin), output dx or, for
 // SYMMETRIC / REFLECT layers, the gradient on the padded domain).
+// Diagnostic (tests, tools): the spectrum rows of ONE 64 x 64 window at the image origin, item layout of spectral_common.h (4096 rows x 32 floats per
+// channel group), as the forward transform writes them - tests/test_gpu_spectral64.py compares the kernel forms (PCNN_FWD64_RADIX = 2 | 4) row by row.
+extern "C" int pcnn_debug_tile_spectrum64(pcnn_handle h, int H, int W, int C, const float* x, int ylim, int xlim, float* out) {
+  PCNN_REQUIRE(h, h && x && out && H >= 1 && W >= 1 && C >= 1 && C <= 64, "pcnn_debug_tile_spectrum64: bad argument");
+  const int groups = pcnn_cdiv(C, 32);
+  const size_t sp_b = align256(sp_bytes((size_t)groups, 4096));
+  char* r;
+  if (int rc = ensure_workspace(h, sp_b, &r)) return rc;
+  const Geom gm = geom_of(h, 64);
+  FwdParams f;
+  f.x = x; f.sp = reinterpret_cast<float*>(r); f.tab = gm.tab; f.H = H; f.W = W; f.C = C; f.ld = C; f.groups = groups; f.cstride = 32; f.cvalid = 32;
+  f.tiles_x = 1; f.tiles_y = 1; f.tile0 = 0; f.Vy = 64; f.Vx = 64; f.oy = 0; f.ox = 0; f.pad_mode = PCNN_PAD_CONSTANT; f.pad_value = 0.f;
+  f.ylim = ylim; f.xlim = xlim; f.ext_y = 1 << 30; f.ext_x = 1 << 30; f.pack = 1; f.cpt = 32; f.tgx = 1;
+  launch_fwd(h, gm, f, 1);
+  PCNN_CHECK_LAUNCH(h, "pcnn_debug_tile_spectrum64");
+  for (int g = 0; g < groups; ++g)
+    if (hipMemcpyAsync(out + (size_t)g * 4096 * 32, f.sp + pcnn_spec::sp_item(g, 4096), 4096 * 32 * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+      PCNN_FAIL(h, "pcnn_debug_tile_spectrum64: copy failed");
+  return 0;
+}
+
 extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg) {
   if (!h || !d || !dg) return 0;
   if (d->Cout > 32 || d->Cin > 64) return 0;
