@@ -753,7 +753,11 @@ void launch_fwd64(pcnn_handle h, FwdParams p, int ntile) {
   const int nitem = 2 * ((ntg + 7) & ~7);
   const unsigned grid = (unsigned)std::min((nitem + 15) & ~15, 256);
   const bool masked = p.ylim < T || p.xlim < T || p.ext_y < (1 << 29) || p.ext_x < (1 << 29);
-  const int radix = getenv("PCNN_FWD64_RADIX") ? atoi(getenv("PCNN_FWD64_RADIX")) : 4;      // 2: the one-step (parity) form of round 3
+  // Unmasked windows take the form with the second radix-2 step on the y axis (spec64_fwd4_kernel: a third less matrix-core work, measured 1.154 ->
+  // 1.080 ms per 8 x 1024^2 x 32-channel launch); the masked form stays on the parity kernel (its radix-4 build needs 20 bytes of scratch per lane and
+  // runs 0.393 -> 0.415 ms).  PCNN_FWD64_RADIX = 2 | 4 forces one form for both (tests, A/B timing).
+  const int forced = getenv("PCNN_FWD64_RADIX") ? atoi(getenv("PCNN_FWD64_RADIX")) : 0;
+  const int radix = forced ? forced : (masked ? 2 : 4);
   if (radix == 4) {
     const size_t lds4 = (2 * SB_FLOATS + 3 * 4096) * sizeof(float);
     if (masked) {

@@ -154,3 +154,42 @@ def test_workspace_limit_shrinks_the_launches_not_the_result():
     finally:
         h.call('pcnn_set_workspace_limit', ctypes.c_size_t(0))
     assert torch.equal(ops.conv2d_fwd(x, w, None, pad_top=6, pad_left=6), y0)
+
+
+@pytest.mark.parametrize('ylim,xlim,C', [(64, 64, 32), (64, 64, 20), (50, 50, 32), (37, 64, 7), (15, 15, 64)])
+def test_the_two_forms_of_the_forward_transform_write_the_same_spectrum(ylim, xlim, C):
+    """Round 4: the 64-point forward transform with a second radix-2 step on the y axis (spec64_fwd4_kernel: classes fy mod 4, sixteen-point
+    transforms, Re / Im stacked in one accumulator tile) against round 3's parity form, row by row on one window (pcnn_debug_tile_spectrum64) -
+    full and masked windows, ragged channel groups - and against numpy's FFT for the rows whose meaning spectral_common.h states."""
+    import ctypes
+    import os
+    from poisson_cnn_amd import ops
+    from poisson_cnn_amd.ops import _p
+    g = torch.Generator(device='cuda').manual_seed(ylim + C)
+    x = torch.randn(64, 64, C, device='cuda', generator=g)
+    groups = (C + 31) // 32
+
+    def spectrum(radix):
+        os.environ['PCNN_FWD64_RADIX'] = str(radix)
+        try:
+            out = torch.zeros(groups * 4096, 32, device='cuda')
+            ops.handle().call('pcnn_debug_tile_spectrum64', ctypes.c_int(64), ctypes.c_int(64), ctypes.c_int(C), _p(x), ctypes.c_int(ylim), ctypes.c_int(xlim), _p(out))
+            torch.cuda.synchronize()
+            return out.cpu().numpy().astype(np.float64)
+        finally:
+            os.environ.pop('PCNN_FWD64_RADIX', None)
+    a, b = spectrum(2), spectrum(4)
+    scale = np.abs(a).max()
+    assert np.abs(a - b).max() < 2e-6 * scale
+    xm = x.cpu().numpy().astype(np.float64).copy()
+    xm[ylim:, :, :] = 0
+    xm[:, xlim:, :] = 0
+    X = np.fft.fft2(xm, axes=(0, 1))                                        # X[fy][fx][c]
+    for fx, fy in ((5, 9), (31, 63), (1, 0), (17, 32)):
+        row = 128 + 128 * (fx - 1) + fy
+        assert abs(b[row, 0] - X[fy, fx, 0].real) < 1e-5 * scale and abs(b[row + 64, 0] - X[fy, fx, 0].imag) < 1e-5 * scale
+    for fx, base in ((0, 0), (32, 64)):                                     # the two real columns: half-complex rows
+        for fy in (0, 1, 2, 3, 13, 30, 31, 32):
+            assert abs(b[base + fy, 0] - X[fy, fx, 0].real) < 1e-5 * scale
+            if 0 < fy < 32:
+                assert abs(b[base + 32 + fy, 0] - X[fy, fx, 0].imag) < 1e-5 * scale
