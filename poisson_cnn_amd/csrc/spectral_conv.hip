@@ -786,28 +786,38 @@ extern "C" int pcnn_set_workspace_limit(pcnn_handle h, size_t bytes) {
 // Route choice.  Both estimates are calibrated on MI355X measurements at 8 x 1024^2 (tools/probe_spectral.py, profiles/r02_probe_spectral.txt):
 // the spectral route costs a fixed time per 32 x 32 tile whatever the filter size (0.21 us per tile with <= 32 channels, 0.33 us with
 // 64; its three kernels are HBM-bound on the tile spectra), the direct route the layer's padded MAC count over the rate its kernel sustains.
-bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad) {
+// Cost-model estimates of one convolution on ONE image (seconds): the spectral route and its alternative.  Returns 0 when the shape cannot
+// take the spectral route at all, 1 when the policy is "whenever the shape allows" (no estimates), 2 with both estimates filled in.
+static int spectral_costs(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad, double* t_spec, double* t_alt) {
   const int mode = h->spectral_mode;                       // 0: never, 1: whenever the shape allows, -1: cost model
-  if (mode == 0) return false;
-  if (d->kh > 15 || d->kw > 15 || d->kh < 2 || d->kw < 2 || d->Cin > 64) return false;
-  if (d->Cout > 32 && (wgrad || d->Cout != 64)) return false;      // 64 output channels: two exact lane groups (forward / data gradient only)
-  if (mode == 1) return true;
+  if (mode == 0) return 0;
+  if (d->kh > 15 || d->kw > 15 || d->kh < 2 || d->kw < 2 || d->Cin > 64) return 0;
+  if (d->Cout > 32 && (wgrad || d->Cout != 64)) return 0;          // 64 output channels: two exact lane groups (forward / data gradient only)
+  if (mode == 1) return 1;
   // decided on ONE image, so that a sample's arithmetic never depends on its batch neighbours (the model's per-sample results are
   // bit-identical for any batch size); images of fewer than 4 tiles stay on the direct route (launch overheads dominate there)
   const int Vy = T - d->kh + 1, Vx = T - d->kw + 1;
   const int pack = pack_for(d->Cin, d->Cout);
   const double tiles = (double)((d->Ho + Vy - 1) / Vy) * (((d->Wo + Vx - 1) / Vx + pack - 1) / pack);        // tile groups
-  if (tiles < 4) return false;
-  const double t_spec = tiles * ((d->Cin > 32 || d->Cout > 32) ? 0.33e-6 : 0.19e-6);
+  if (tiles < 4) return 0;
+  *t_spec = tiles * ((d->Cin > 32 || d->Cout > 32) ? 0.33e-6 : 0.19e-6);
   if (!wgrad && pcnn_conv_small_fwd_eligible(d)) {         // the alternative is the vector-ALU narrow kernel: ~17 T multiply-adds/s on its padded channels
     const double fma = (double)d->Ho * d->Wo * d->kh * d->kw * ((d->Cin + 3) & ~3) * ((d->Cout + 3) & ~3);
-    return t_spec < 0.8 * fma / 17e12;
+    *t_alt = 0.8 / 0.9 * fma / 17e12;                      // (compared below with the common factor 0.9)
+    return 2;
   }
   const int cin8 = (d->Cin + 7) & ~7, co32 = (d->Cout + 31) & ~31;
   const double flop = 2.0 * d->Ho * d->Wo * d->kh * d->kw * cin8 * co32;
   const bool split = h->math_mode == PCNN_MATH_SPLIT_F16;
   const double rate = split ? (wgrad ? 210e12 : 330e12) : (wgrad ? 95e12 : 118e12);
-  return t_spec < 0.9 * flop / rate;
+  *t_alt = flop / rate;
+  return 2;
+}
+
+bool pcnn_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, bool wgrad) {
+  double t_spec = 0.0, t_alt = 0.0;
+  const int r = spectral_costs(h, d, wgrad, &t_spec, &t_alt);
+  return r == 1 || (r == 2 && t_spec < 0.9 * t_alt);
 }
 
 // forward / data-gradient route of a layer the narrow kernels could also take: they keep every 3x3 layer; a 5x5 layer goes spectral when
@@ -967,7 +977,13 @@ extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_
   if (d->Cout > 32 || d->Cin > 64) return 0;
   if (d->pad_mode == PCNN_PAD_CONSTANT && d->pad_value != 0.f) return 0;
   if (pcnn_conv_fwd_takes_narrow_route(h, dg)) return 0;
-  return pcnn_spectral_eligible(h, dg, false) && pcnn_spectral_eligible(h, d, true) ? 1 : 0;
+  if (pcnn_spectral_eligible(h, dg, false) && pcnn_spectral_eligible(h, d, true)) return 1;
+  // Neither gradient alone may beat its direct kernel while the FUSED pass does: it transforms dz once for both (measured: 1.6-1.75 x one
+  // spectral convolution for data + weight gradient together).  5 x 5, 20 -> 16 at 8 x 1024^2 (final/stage4/conv of hpnn.json): direct data
+  // gradient 1.99 ms + direct weight gradient 1.73 ms against 2.97 ms fused (tools/probe_k5.py).
+  double ts_g = 0.0, ta_g = 0.0, ts_w = 0.0, ta_w = 0.0;
+  if (spectral_costs(h, dg, false, &ts_g, &ta_g) != 2 || spectral_costs(h, d, true, &ts_w, &ta_w) != 2) return 0;
+  return 1.75 * std::max(ts_g, ts_w) < 0.9 * (ta_g + ta_w) ? 1 : 0;
 }
 
 extern "C" int pcnn_conv2d_bwd_spectral_post_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg) {
