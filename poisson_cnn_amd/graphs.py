@@ -77,7 +77,7 @@ class _Captured:
                 c.side_allowed, c.use_side = allowed, use
         # the recorded launches address these buffers; their owners drop them when a larger shape comes along - the graph must not
         for c in ctxs:
-            self._keep += [c.ws.buf, c.ws_side.buf, c._wflip]
+            self._keep += c.all_scratch()
         self._keep.append(ops._default_ws.buf)
         self._keep = [b for b in self._keep if b is not None]
         return out

@@ -117,11 +117,12 @@ class ParamStore:
 
 
 class Context:
-    """Per-model scratch: workspace + the scratch filter used by data-gradient convolutions."""
+    """Per-model scratch: workspace + the scratch filter used by data-gradient convolutions - one set PER STREAM (the coarse bottleneck branches
+    of the homogeneous model run on streams of their own, models.Homogeneous_Poisson_NN_Legacy.call), so two streams never share a scratch buffer."""
 
     def __init__(self):
-        self.ws = ops.Workspace()
-        self._wflip = None
+        self._ws = {}
+        self._wflips = {}
         # Weight gradients run on a second HIP stream: their HBM-bound pre-pass (abs-max, fp16 plane conversion) and the kernel itself
         # overlap with the clock-bound data-gradient convolution of the same layer on the main stream (PCNN_WGRAD_STREAM=0 disables).
         import os
@@ -130,6 +131,20 @@ class Context:
         self.side = None
         self.ws_side = ops.Workspace()
         self.side_reads = {}                                   # data_ptr -> event: tensors a side-stream weight gradient is still reading
+        self.branch_streams = []                               # streams of the coarse bottleneck branches (created on demand)
+
+    @staticmethod
+    def _stream_key():
+        return torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0
+
+    @property
+    def ws(self):
+        """The scratch workspace of the CURRENT stream."""
+        return self._ws.setdefault(self._stream_key(), ops.Workspace())
+
+    def all_scratch(self):
+        """Every scratch buffer this context holds right now (a captured hipGraph keeps them alive, graphs._Captured)."""
+        return [w.buf for w in list(self._ws.values()) + [self.ws_side] if w.buf is not None] + list(self._wflips.values())
 
     def enable_side_stream(self):
         self.use_side = self.side_allowed
@@ -140,6 +155,11 @@ class Context:
         if self.side is None:
             self.side = torch.cuda.Stream()
         return self.side
+
+    def branch_stream(self, k):
+        while len(self.branch_streams) <= k:
+            self.branch_streams.append(torch.cuda.Stream())
+        return self.branch_streams[k]
 
     def join(self):
         """Main stream waits for the weight gradients enqueued on the side stream (call before the gradients are consumed)."""
@@ -156,9 +176,11 @@ class Context:
 
     def wflip(self, shape, device):
         n = int(np.prod(shape))
-        if self._wflip is None or self._wflip.numel() < n:
-            self._wflip = torch.empty(n, dtype=torch.float32, device=device)
-        return self._wflip[:n].view(shape)
+        key = self._stream_key()
+        buf = self._wflips.get(key)
+        if buf is None or buf.numel() < n:
+            buf = self._wflips[key] = torch.empty(n, dtype=torch.float32, device=device)
+        return buf[:n].view(shape)
 
 
 # ----------------------------------------------------------------------------- conv unit
@@ -461,23 +483,34 @@ class bottleneck_block_deconvupsample(_bottleneck_base):
         if deconv_use_bias:
             store.add(name + '/deconv/bias', (self.filters,), 'glorot')
 
-    def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
-        N, H, W, _ = x.shape
-        o = self._down_and_convs(x, training, pooled)
-        assert self.out_hw(H, W) == (H, W), 'deconv branch must restore the input resolution'
+    # The branch in two halves - its down-sampled convolution stages and the up-sampling that accumulates into the merge buffer - so that the model
+    # can run the first half of a coarse branch on a stream of its own (models.Homogeneous_Poisson_NN_Legacy.call / backward).
+    def forward_convs(self, x, training=True, pooled=None):
+        return self._down_and_convs(x, training, pooled)
+
+    def forward_up(self, o, hw, merged, alpha, beta, training=True):
+        assert self.out_hw(*hw) == tuple(hw), 'deconv branch must restore the input resolution'
         self.coarse = o if training else None
         ops.deconv_fwd(o, self.store.w[self.name + '/deconv/kernel'], self.store.w[self.name + '/deconv/bias'] if self.deconv_use_bias else None,
-                       (H, W), self.up, alpha=alpha, beta=beta, out=merged)
+                       tuple(hw), self.up, alpha=alpha, beta=beta, out=merged)
 
-    def backward_from(self, dmerged, alpha, d_in):
+    def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
+        self.forward_up(self.forward_convs(x, training, pooled), (x.shape[1], x.shape[2]), merged, alpha, beta, training)
+
+    def backward_up(self, dmerged, alpha):
         g = self.store.g
         k = self.store.w[self.name + '/deconv/kernel']
         o = self.coarse
         self.coarse = None
         ops.deconv_bwd_filter(o, dmerged, self.up, alpha=alpha, dk=g[self.name + '/deconv/kernel'],
                               dbias=g[self.name + '/deconv/bias'] if self.deconv_use_bias else None, ws=self.ctx.ws, kernel_size=(self.dk, self.dk))
-        dcoarse = ops.deconv_bwd_data(dmerged, k, (o.shape[1], o.shape[2]), self.up, alpha=alpha)
+        return ops.deconv_bwd_data(dmerged, k, (o.shape[1], o.shape[2]), self.up, alpha=alpha)
+
+    def backward_convs(self, dcoarse, d_in):
         return self._backward_convs_and_down(dcoarse, d_in)
+
+    def backward_from(self, dmerged, alpha, d_in):
+        return self.backward_convs(self.backward_up(dmerged, alpha), d_in)
 
 
 class bottleneck_block_multilinearupsample(_bottleneck_base):
@@ -489,16 +522,25 @@ class bottleneck_block_multilinearupsample(_bottleneck_base):
         if self.method not in ops.RESIZE:
             raise ValueError('unsupported resize method ' + resize_method)
 
-    def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
-        N, H, W, _ = x.shape
-        o = self._down_and_convs(x, training, pooled)
+    def forward_convs(self, x, training=True, pooled=None):
+        return self._down_and_convs(x, training, pooled)
+
+    def forward_up(self, o, hw, merged, alpha, beta, training=True):
         self.coarse_hw = (o.shape[1], o.shape[2])
-        assert self.out_hw(H, W) == (H, W)
-        ops.resize_fwd(o, (H, W), self.method, alpha=alpha, beta=beta, out=merged)
+        assert self.out_hw(*hw) == tuple(hw)
+        ops.resize_fwd(o, tuple(hw), self.method, alpha=alpha, beta=beta, out=merged)
+
+    def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
+        self.forward_up(self.forward_convs(x, training, pooled), (x.shape[1], x.shape[2]), merged, alpha, beta, training)
+
+    def backward_up(self, dmerged, alpha):
+        return ops.resize_bwd(dmerged, self.coarse_hw, self.method, alpha=alpha)
+
+    def backward_convs(self, dcoarse, d_in):
+        return self._backward_convs_and_down(dcoarse, d_in)
 
     def backward_from(self, dmerged, alpha, d_in):
-        dcoarse = ops.resize_bwd(dmerged, self.coarse_hw, self.method, alpha=alpha)
-        return self._backward_convs_and_down(dcoarse, d_in)
+        return self.backward_convs(self.backward_up(dmerged, alpha), d_in)
 
 
 # ----------------------------------------------------------------------------- dense / scaling / jacobi

@@ -191,6 +191,9 @@ class _ModelBase:
         return history
 
 
+_BRANCH_STREAMS = os.environ.get('PCNN_BRANCH_STREAMS', '1') != '0'      # 0: the coarse bottleneck branches stay on the main stream
+
+
 class Homogeneous_Poisson_NN_Legacy(_ModelBase):
     model_name = 'Homogeneous_Poisson_NN_Legacy'
 
@@ -295,6 +298,8 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         self.grad_sync = None    # set by parallel.DataParallel: called with the flat gradient bucket before the optimizer step
         self._acc = None
 
+    COARSE_FACTOR = 8          # bottleneck branches from this down-sampling factor on run their convolution stages on streams of their own
+
     # ------------------------------------------------------------------ forward
     def _pool_pyramid(self, x, blocks):
         """The eight branches average-pool the SAME tensor by 2, 3, 4, 8, ..., 128 (blocks/bottleneck_block.py:36-41): eight full-resolution
@@ -336,8 +341,38 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks
         alpha = 1.0 / float(len(blocks) * F)                     # :222
         pyr = self._pool_pyramid(initial, blocks)
-        for i, b in enumerate(blocks):
-            b.forward_into(initial, merged, alpha, 0.0 if i == 0 else 1.0, training=training, pooled=pyr[b.f][0] if b.f in pyr else None)
+        # The coarse branches (factor >= 8: images of 128^2 and below at 1024^2) are chains of launches that fill a fraction of the chip - 7.9 ms per
+        # training step when run back to back (tools/probe_branches.py).  Their convolution stages run on streams of their own beside the large
+        # branches (each stream has its libpcnn handle and its scratch, layers.Context); only the up-sampling, which accumulates into the shared
+        # merge buffer, stays on the main stream.  The accumulation order - large branches first, then the coarse ones - is the same with and
+        # without the streams, so the result does not depend on the mode.  Only pyramid-fed branches qualify (their backward returns the
+        # pooled gradient instead of accumulating into d_initial).
+        coarse = [b for b in blocks if b.f >= self.COARSE_FACTOR and b.f in pyr]
+        order = [b for b in blocks if b not in coarse] + coarse
+        pending = {}
+        self._branch_streams = {}
+        if coarse and self.ctx.use_side and _BRANCH_STREAMS:
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for k, b in enumerate(coarse):
+                st = self.ctx.branch_stream(k)
+                with torch.cuda.stream(st):
+                    st.wait_event(ready)
+                    o = b.forward_convs(initial, training, pyr[b.f][0])
+                    done = torch.cuda.Event()
+                    done.record(st)
+                pending[b] = (o, done)
+                if training:
+                    self._branch_streams[b] = st
+        for i, b in enumerate(order):
+            if b in pending:
+                o, done = pending[b]
+                torch.cuda.current_stream().wait_event(done)
+                o.record_stream(torch.cuda.current_stream())
+            else:
+                o = b.forward_convs(initial, training, pyr[b.f][0] if b.f in pyr else None)
+            b.forward_up(o, (H, W), merged, alpha, 0.0 if i == 0 else 1.0, training)
         self._pyr = pyr if training else None
         self.non_bottleneck_conv.forward(initial, out=cat[..., :F], training=training)
         x = self.post_merge_conv.forward(cat, training=training)
@@ -391,10 +426,31 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks
         alpha = 1.0 / float(len(blocks) * F)
         grads = {}
+        late = []
+        main = torch.cuda.current_stream()
         for b in blocks:
-            g = b.backward_from(dmerged, alpha, d_initial)
+            st = self._branch_streams.get(b)
+            if st is None:
+                g = b.backward_from(dmerged, alpha, d_initial)
+                if g is not None:
+                    grads[b.f] = g if b.f not in grads else ops.axpby(1.0, g, 1.0, grads[b.f])
+                continue
+            dco = b.backward_up(dmerged, alpha)                       # reads the shared gradient: main stream
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(st):                               # the branch's convolution stages: the stream its saved activations live on
+                st.wait_event(ev)
+                dco.record_stream(st)
+                g = b.backward_convs(dco, d_initial)                 # pyramid-fed: returns the pooled gradient, does not touch d_initial
+                done = torch.cuda.Event()
+                done.record(st)
+            late.append((b, g, done))
+        for b, g, done in late:
+            main.wait_event(done)
             if g is not None:
+                g.record_stream(main)
                 grads[b.f] = g if b.f not in grads else ops.axpby(1.0, g, 1.0, grads[b.f])
+        self._branch_streams = {}
         for f in sorted(grads, reverse=True):                      # the pyramid's adjoint: coarsest level first, each into its parent
             parent = self._pyr[f][1]
             if parent is None:
