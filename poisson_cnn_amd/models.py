@@ -298,7 +298,8 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         self.grad_sync = None    # set by parallel.DataParallel: called with the flat gradient bucket before the optimizer step
         self._acc = None
 
-    COARSE_FACTOR = 8          # bottleneck branches from this down-sampling factor on run their convolution stages on streams of their own
+    COARSE_FACTOR = int(os.environ.get('PCNN_COARSE_FACTOR', '2'))     # bottleneck branches from this down-sampling factor on (default: all of them) run their
+                                                                        # convolution stages on streams of their own; measured at 8 x 1024^2: none 243, >= 8: 238.9, all: 236 ms per step
 
     # ------------------------------------------------------------------ forward
     def _pool_pyramid(self, x, blocks):
@@ -341,13 +342,12 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         blocks = self.bottleneck_deconv_blocks + self.bottleneck_multilinear_blocks
         alpha = 1.0 / float(len(blocks) * F)                     # :222
         pyr = self._pool_pyramid(initial, blocks)
-        # The coarse branches (factor >= 8: images of 128^2 and below at 1024^2) are chains of launches that fill a fraction of the chip - 7.9 ms per
-        # training step when run back to back (tools/probe_branches.py).  Their convolution stages run on streams of their own beside the large
-        # branches (each stream has its libpcnn handle and its scratch, layers.Context); only the up-sampling, which accumulates into the shared
-        # merge buffer, stays on the main stream.  The accumulation order - large branches first, then the coarse ones - is the same with and
-        # without the streams, so the result does not depend on the mode.  Only pyramid-fed branches qualify (their backward returns the
-        # pooled gradient instead of accumulating into d_initial).
-        coarse = [b for b in blocks if b.f >= self.COARSE_FACTOR and b.f in pyr]
+        # The eight branches are independent between the pooling pyramid and the merge buffer, and the coarse ones (factor >= 8: images of 128^2 and
+        # below at 1024^2) are chains of launches that fill a fraction of the chip - 7.9 ms per training step back to back (tools/probe_branches.py).
+        # Their convolution stages run on streams of their own (each stream has its libpcnn handle and its scratch, layers.Context), so that one
+        # branch's small or tailing launches fill the gaps of another's; only the up-sampling, which accumulates into the shared merge buffer, stays on
+        # the main stream.  The accumulation order is the same with and without the streams, so the result does not depend on the mode.
+        coarse = [b for b in blocks if b.f >= self.COARSE_FACTOR]
         order = [b for b in blocks if b not in coarse] + coarse
         pending = {}
         self._branch_streams = {}
@@ -356,10 +356,12 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
             ready = torch.cuda.Event()
             ready.record(main)
             for k, b in enumerate(coarse):
-                st = self.ctx.branch_stream(k)
+                # a branch that pools the full-resolution tensor itself (its factor does not divide the image) accumulates its input gradient
+                # into d_initial in the backward pass: all such branches share stream 0, so that they do so one after the other
+                st = self.ctx.branch_stream(k + 1 if b.f in pyr else 0)
                 with torch.cuda.stream(st):
                     st.wait_event(ready)
-                    o = b.forward_convs(initial, training, pyr[b.f][0])
+                    o = b.forward_convs(initial, training, pyr[b.f][0] if b.f in pyr else None)
                     done = torch.cuda.Event()
                     done.record(st)
                 pending[b] = (o, done)
@@ -441,7 +443,7 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
             with torch.cuda.stream(st):                               # the branch's convolution stages: the stream its saved activations live on
                 st.wait_event(ev)
                 dco.record_stream(st)
-                g = b.backward_convs(dco, d_initial)                 # pyramid-fed: returns the pooled gradient, does not touch d_initial
+                g = b.backward_convs(dco, d_initial)                 # pyramid-fed: returns the pooled gradient; else adds into d_initial (stream 0 only)
                 done = torch.cuda.Event()
                 done.record(st)
             late.append((b, g, done))
