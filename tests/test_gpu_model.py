@@ -272,6 +272,34 @@ def test_two_stream_backward_is_bitwise_identical_to_one_stream():
     assert np.array_equal(grads[0], grads[1]) and np.array_equal(grads[0], grads[2])
 
 
+def test_branch_streams_are_bitwise_identical_to_one_stream_on_the_shipped_model():
+    """Round 4: every bottleneck branch of hpnn.json runs its convolution stages on a stream of its own (models.Homogeneous_Poisson_NN_Legacy.call /
+    backward: eight branches, pyramid-fed ones and the factor-3 branch that pools the full-resolution tensor itself and accumulates its input gradient).
+    Same kernels, same accumulation order per buffer: predictions and the whole gradient bucket must be bit-identical to the single-stream run, step
+    after step - any difference would be a missing event or a shared scratch buffer."""
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import SGD
+    full = configs.hpnn()
+    cfg = full['model']
+    rhs, dx = make_inputs(2, 256, 256, 23)
+    target = np.random.default_rng(5).standard_normal(rhs.shape) * 0.1
+    runs = []
+    for side in (True, False, True):
+        model, _ = build(cfg, 43)
+        model.ctx.use_side = side
+        model.compile(loss=loss_wrapper(global_batch_size=2, **full['training']['loss_parameters']), optimizer=SGD(learning_rate=0.0))
+        preds = []
+        for _ in range(3):
+            model.train_step(((rhs, dx), target))
+            preds.append(model([rhs, dx]).cpu().numpy().copy())
+        assert (len(model.ctx.branch_streams) > 0) == side
+        runs.append((preds, model.store.flat_g.cpu().numpy().copy()))
+    for other in runs[1:]:
+        assert np.array_equal(runs[0][1], other[1])
+        for a, b in zip(runs[0][0], other[0]):
+            assert np.array_equal(a, b)
+
+
 def test_channels_last_model_api():
     """Homogeneous_Poisson_NN_Legacy(data_format='channels_last'): (N,H,W,1) in, (N,H,W,1) out, identical numbers and an identical training
     step (the boundary tensors have one channel, so the two formats are the same memory)."""
