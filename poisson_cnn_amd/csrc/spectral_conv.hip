@@ -544,6 +544,150 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ fused backward mixing
+// Backward pass of one layer: the gradient spectrum D^ (dz's windows) feeds BOTH the data gradient (Y^ = D^ M_f, spec_mix_kernel) and the
+// weight gradient (P_f = sum_tiles X^^T D^, spec_wmix_kernel).  As two kernels D^ crosses HBM twice (7 spectrum passes per layer); here one
+// wave does both for its M-tiles of 32 tiles - D^ comes from HBM once (the second operand layout, lane = channel instead of lane = tile, is
+// re-read from L2 within the same M-tile), 6 passes per layer.  One x / dx channel group per blockIdx.z, dz has one group (Cout <= 32).
+// The partial sums P are laid out exactly as spec_wmix_kernel's (spec_wcombine_kernel reads them): part = blockIdx.y * 4 + wave.
+struct MixWParams { const float* zs; const float* xs; float* ys; float* part; const float* wsp; const int4* slots; int ntile, gx, rows, nslot, Cz, cpt, accumulate; };
+
+__global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = blockIdx.x, g = blockIdx.z;
+  const int part = blockIdx.y * 4 + wave;
+  const int4 sl = p.slots[slot];
+  const int rr = sl.x, ri = sl.y;
+  // M_f = [[Hr, -Hi], [Hi, Hr]] as in spec_mix_kernel<1> (input group: dz's single one; output group g), but held as its 32 DISTINCT values per
+  // lane - the sign and, for the two slots that pack two real frequencies (block diagonal: [[Hr, 0], [0, Hi]]), the zero blocks go onto the A
+  // operand (x -1, x 0: exact) - 32 registers instead of 64, which is what lets the weight-gradient accumulators live beside them.
+  float hr[16], hi[16];
+  const bool real2 = sl.z == 1;
+  const float s_neg = real2 ? 0.f : -1.f, s_pos = real2 ? 0.f : 1.f;
+  {
+    const int co = c % p.cpt;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int kc = j + 16 * half, ci = kc % p.cpt;
+      float wr = 0.f, wi = 0.f;
+      if (ci < p.Cz && kc / p.cpt == c / p.cpt) {
+        const float* wg = p.wsp + pcnn_spec::sp_item(ci * p.gx + g, p.rows) + co;
+        wr = wg[rr * RS]; wi = wg[ri * RS];
+      }
+      hr[j] = wr; hi[j] = wi;
+    }
+  }
+  const int nMt = (p.ntile + 31) >> 5;
+  const int mstride = gridDim.y * 4;
+  // Weight-gradient operands of K steps 4 b .. 4 b + 3 (tile pair 2 j + half per step): ONE 16-byte load per spectrum row and batch - lane
+  // (quad cq, i) fetches channels 4 cq .. 4 cq + 3 of tile 8 b + 2 i + half, the in-quad transpose turns that into channel 4 cq + i of the four
+  // tiles 8 b + 2 j + half (register j): the MFMA operand layout (lane = channel) from a quarter of the memory instructions.
+  const float* xr = p.xs + rr * RS, *xi = p.xs + ri * RS;
+  const float* dr = p.zs + rr * RS, *di = p.zs + ri * RS;
+  const int qi = lane & 3, c4 = c & ~3;
+  const bool odd = lane & 1, upper = lane & 2;
+  auto load_w = [&](int mt, int b, f32x4 (&w)[4]) {
+    const int tt = mt * 32 + 8 * b + 2 * qi + half;
+    const unsigned tc = (unsigned)(tt < p.ntile ? tt : 0);
+    const unsigned ix = (unsigned)pcnn_spec::sp_item((int64_t)tc * p.gx + g, p.rows) + c4, id = (unsigned)pcnn_spec::sp_item(tc, p.rows) + c4;
+    w[0] = NT_LOAD(16, reinterpret_cast<const f32x4*>(&xr[ix])); w[1] = NT_LOAD(16, reinterpret_cast<const f32x4*>(&xi[ix]));
+    w[2] = *reinterpret_cast<const f32x4*>(&dr[id]); w[3] = *reinterpret_cast<const f32x4*>(&di[id]);
+  };
+  f32x16 accp[4] = {zero16(), zero16(), zero16(), zero16()};
+  auto mfma_w = [&](int mt, int b, f32x4 (&w)[4]) {
+    float t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[q][j] = w[q][j];
+      quad_transpose(t[q][0], t[q][1], t[q][2], t[q][3], odd, upper);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = mt * 32 + 8 * b + 2 * j + half < p.ntile;
+      const float a0 = ok ? t[0][j] : 0.f, a1 = ok ? t[1][j] : 0.f;
+      accp[0] = mfma(a0, t[2][j], accp[0]);
+      accp[1] = mfma(a1, t[2][j], accp[1]);
+      accp[2] = mfma(a0, t[3][j], accp[2]);
+      accp[3] = mfma(a1, t[3][j], accp[3]);
+    }
+  };
+  // One M-tile = 8 phases of 16 MFMAs, weight-gradient batches and mixing quarters interleaved (W0 M0 W1 M1 W2 M2 W3 M3) so that every operand
+  // is requested >= 3 phases (two register sets ws[0], ws[1]) resp. 4 phases (the mixing operand) before its use: a load issued one phase
+  // ahead is still in flight when its MFMAs come up (first version of this kernel: 30 % slower than the two kernels it replaces).
+  // The mixing operand (lane = tile: 16 consecutive channels of its tile's real and imaginary row) lives in two slots of 8 channels that
+  // alternate between the real and the imaginary row: a quarter's registers are refilled, right after it has consumed them, with the piece that
+  // is needed 4 phases later - 16 registers instead of 32.
+  f32x4 aq[2][2], ws[2][4];
+  auto load_a_part = [&](int mt, int pp, int sl2) {                  // channels 8 sl2 .. 8 sl2 + 7 (of this lane's 16) of row pp (0 real, 1 imaginary)
+    const int tile = min(mt * 32 + c, p.ntile - 1);
+    const float* base = p.zs + pcnn_spec::sp_item(tile, p.rows) + 16 * half + (pp ? ri : rr) * RS + 8 * sl2;
+    aq[sl2][0] = *reinterpret_cast<const f32x4*>(base);
+    aq[sl2][1] = *reinterpret_cast<const f32x4*>(base + 4);
+  };
+  int mt = part;
+  if (mt < nMt) {
+    load_w(mt, 0, ws[0]); load_w(mt, 1, ws[1]);
+    load_a_part(mt, 0, 0); load_a_part(mt, 0, 1);
+  }
+  auto m_tile = [&](int mt) {
+    const int mn = mt + mstride < nMt ? mt + mstride : mt;
+    f32x16 acc[2] = {zero16(), zero16()};
+    auto mix_quarter = [&](int qu) {                                 // K steps 8 qu .. 8 qu + 7 of the mixing product (qu < 2: real rows, else imaginary)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 8 * (qu & 1) + e;
+        const float av = aq[qu & 1][e >> 2][e & 3];
+        if (qu < 2) {
+          acc[0] = mfma(av, hr[j], acc[0]);
+          acc[1] = mfma(av * s_neg, hi[j], acc[1]);
+        } else {
+          acc[0] = mfma(av * s_pos, hi[j], acc[0]);
+          acc[1] = mfma(av, real2 ? hi[j] : hr[j], acc[1]);
+        }
+      }
+    };
+    // (the last M-tile re-requests its own operands instead of branching around the loads: with a static number of memory operations per
+    // pass the compiler's s_waitcnt values name exactly the load a phase needs; behind a branch they become vmcnt(0), i.e. a wait for the
+    // previous M-tile's 32 stores.  The scheduling barriers keep the phases in the order written.)
+    mfma_w(mt, 0, ws[0]); load_w(mt, 2, ws[0]);     __builtin_amdgcn_sched_barrier(0);
+    mix_quarter(0);       load_a_part(mt, 1, 0);    __builtin_amdgcn_sched_barrier(0);
+    mfma_w(mt, 1, ws[1]); load_w(mt, 3, ws[1]);     __builtin_amdgcn_sched_barrier(0);
+    mix_quarter(1);       load_a_part(mt, 1, 1);    __builtin_amdgcn_sched_barrier(0);
+    mfma_w(mt, 2, ws[0]); load_w(mn, 0, ws[0]);     __builtin_amdgcn_sched_barrier(0);
+    mix_quarter(2);       load_a_part(mn, 0, 0);    __builtin_amdgcn_sched_barrier(0);
+    mfma_w(mt, 3, ws[1]); load_w(mn, 1, ws[1]);     __builtin_amdgcn_sched_barrier(0);
+    mix_quarter(3);       load_a_part(mn, 0, 1);    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int row = nt ? ri : rr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int trow = mt * 32 + acc_row(r, half);
+        NT_STORE(4, acc[nt][r], &p.ys[pcnn_spec::sp_item((int64_t)trow * p.gx + g, p.rows) + row * RS + c]);            // rows >= ntile: padding of the buffer (pad32)
+      }
+    }
+  };
+  // first M-tile outside the loop, as in spec_mix_kernel: a pass inside the loop then always starts with the previous pass's stores behind its
+  // operand loads in the memory counter, and its waits need not also cover an entry with no stores pending (which makes them wait for the stores)
+  if (mt < nMt) {
+    m_tile(mt);
+    for (mt += mstride; mt < nMt; mt += mstride) m_tile(mt);
+  }
+  float* o = p.part + (((int64_t)part * p.nslot + slot) * p.gx + g) * 4 * 1024 + c;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    float old[16];
+    if (p.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = o[qd * 1024 + acc_row(r, half) * 32];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[qd * 1024 + acc_row(r, half) * 32] = p.accumulate ? old[r] + accp[qd][r] : accp[qd][r];
+  }
+}
+
 // C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
 // Output: spectrum of a one-tile image with Cin*Cout channels, group = ci, lane = co.
 // cpt < 32 (tile packing): the wanted products are the 32 / cpt diagonal blocks (tile with itself); they are summed here.
@@ -1066,10 +1210,21 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
   mx.xs = zs; mx.ys = ys; mx.wsp = wsp; mx.gin = gz; mx.gout = gx; mx.Cin = dg->Cin; mx.cpt = cpt;
   WMixParams wm;
   wm.xs = xs; wm.ds = zs; wm.part = part; wm.slots = gm.slots; wm.gin = gx; wm.S = S / 4; wm.rows = rows; wm.nslot = nslot;
+  static const int fused_mix = getenv("PCNN_SPEC_MIXW") ? atoi(getenv("PCNN_SPEC_MIXW")) : 1;   // developer switch (A/B timing): 0 = two kernels
+  MixWParams mw;
+  mw.zs = zs; mw.xs = xs; mw.ys = ys; mw.part = part; mw.wsp = wsp; mw.slots = gm.slots; mw.gx = gx; mw.rows = rows; mw.nslot = nslot;
+  mw.Cz = dg->Cin; mw.cpt = cpt;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
     fz.tile0 = (int)t0; fxm.tile0 = (int)t0; iv.tile0 = (int)t0; wm.ntile = nt; wm.accumulate = t0 > 0;
     launch_fwd(h, gm, fz, nt);
+    if (fused_mix) {                                     // one pass over D^ for both gradients (spec_mixw_kernel)
+      launch_fwd(h, gm, fxm, nt);
+      mw.ntile = nt; mw.accumulate = t0 > 0;
+      hipLaunchKernelGGL(spec_mixw_kernel, dim3(nslot, S / 4, gx), dim3(256), 0, h->stream, mw);
+      launch_inv(h, gm, iv, nt);
+      continue;
+    }
     launch_mix(h, gm, mx, gz, gx, nt);
     launch_inv(h, gm, iv, nt);
     launch_fwd(h, gm, fxm, nt);
