@@ -467,9 +467,10 @@ def run(args):
         flops, secs, calls = prof.totals('conv_fwd')
         wf, ws_, wc = prof.totals('conv_wgrad')
         bf, bs, bc = prof.totals('conv_bwd_fused')
-        af, as_, ac = flops + wf + bf, secs + ws_ + bs, calls + wc + bc
+        gf, gs, gc = prof.totals('conv_stage')                                # narrow resnet stages as one launch (three convolutions each)
+        af, as_, ac = flops + wf + bf + gf, secs + ws_ + bs + gs, calls + wc + bc + gc
         conv_s = as_ / max(steps, 1)
-        alg_bytes = (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad')) / max(steps, 1)
+        alg_bytes = (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad') + prof.total_bytes('conv_stage')) / max(steps, 1)
         summ, src = pmc_summary(mode, workload)
         traffic = busy = table = None
         if summ is not None:
@@ -482,7 +483,8 @@ def run(args):
                      for k, v in sorted(summ['kernels'].items(), key=lambda kv: -(kv[1].get('ms_per_step') or 0.0)) if not k.startswith('conv (')]
         achieved = (traffic if traffic else alg_bytes) / conv_s / 1e9 if conv_s else None
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
-        hf, hb, hs, hc = prof.select(lambda k, f, b: k == 'conv_fwd' and b > 0 and f / b < ridge)
+        hf, hb, hs, hc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage') and b > 0 and f / b < ridge)
+        sf, sb, ss, sc = prof.select(lambda k, f, b: k == 'conv_stage')   # narrow resnet stages as one launch: algorithmic bytes of the UNFUSED layers / time
         df, db, ds, dc = prof.select(lambda k, f, b: k == 'deconv_fwd')
         rf, rb, rs, rc = prof.select(lambda k, f, b: k == 'resize_fwd')
         direct_tflops = af / as_ / 1e12 if as_ else None
@@ -501,6 +503,10 @@ def run(args):
                                                    'fraction: the spectral route does not execute these FLOP',
                                            'tflops': direct_tflops, 'speedup_vs_direct_fp32_peak': direct_tflops / PEAK_FP32_MFMA_TFLOPS if direct_tflops else None},
                 'kernels': table,
+                'fused_stage': {'what': 'narrow resnet stages (3x3, 4 / 8 channels) as ONE launch (pcnn_resnet3_fwd): the algorithmic bytes of the three unfused '
+                                        'layers (8 tensor passes in training) over the launch time; the launch itself moves 5 passes',
+                                'achieved': sb / ss / 1e9 if ss else None, 'frac': sb / ss / 1e9 / PEAK_HBM_GBS if ss else None, 'launches': sc,
+                                'avg_launch_ms': 1e3 * ss / sc if sc else None},
                 'hbm_bound': {'what': 'conv forward / data-gradient launches below the fp32 ridge (%.1f FLOP/B: the 3x3 tail with <= 8 channels and the Scaling convs)' % ridge,
                               'bound': 'hbm', 'achieved': hb / hs / 1e9 if hs else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s (algorithmic bytes)',
                               'frac': hb / hs / 1e9 / PEAK_HBM_GBS if hs else None, 'launches': hc, 'avg_launch_ms': 1e3 * hs / hc if hc else None,

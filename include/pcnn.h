@@ -144,6 +144,16 @@ int pcnn_conv2d_wgrad_hint(pcnn_handle h, const pcnn_conv_desc* d, const float* 
  * pcnn_conv2d_flip_transpose_weights, output dx (N,dg->Ho,dg->Wo,Cin) with stride dg->ldy - for SYMMETRIC / REFLECT layers the gradient on
  * the padded domain, Ho = H + kh - 1; residual (stride dg->ld_res) is added to dx if given).  Eligibility (cost model, Cout <= 32, zero
  * constant padding) must be asked first; an ineligible layer uses pcnn_conv2d_wgrad + pcnn_conv2d_fwd as before. */
+/* One narrow resnet stage as ONE launch (csrc/conv_small.hip, round 4): blocks/resnet.py:29-39 with 3 x 3 filters, C = 4 / 8 channels on both
+ * sides of all three convolutions, zero CONSTANT padding, no BatchNormalization, activation linear / relu / leaky relu:
+ *   o0 = act(conv0(x) + b0);  a1 = act(conv1(o0) + b1);  o1 = x + a1;  y = act(conv2(o1) + b2)
+ * x, y and the optional outputs are dense NHWC (N, H, W, C), 16-byte aligned; filters (3, 3, C, C); biases may be NULL.  o0 / a1 / o1 (each may be
+ * NULL) receive what the three pcnn_conv2d_fwd calls of the unfused chain leave behind for the backward pass (conv1's input, conv1's act_out,
+ * conv2's input): with them the existing backward calls run unchanged.  Same fp32 FMA chain per output value as the narrow forward kernel. */
+int pcnn_resnet3_fwd_eligible(pcnn_handle h, int C, int act);
+int pcnn_resnet3_fwd(pcnn_handle h, int N, int H, int W, int C, int act, float act_alpha, const float* x, const float* w0, const float* b0,
+                     const float* w1, const float* b1, const float* w2, const float* b2, float* o0, float* a1, float* o1, float* y);
+
 int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg);
 int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
                              const float* residual, float* dx, float* dw);

@@ -419,6 +419,156 @@ bool wgrad_dispatch_ci(pcnn_handle h, const SmallWgradParams& p, int CI, int CO)
   return false;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- fused resnet stage (forward)
+// blocks/resnet.py:29-39 on a narrow stage (3 x 3, C = 4 / 8 channels, zero CONSTANT padding, no BatchNormalization):
+//   o0 = act(conv0(x) + b0);  a1 = act(conv1(o0) + b1);  o1 = x + a1;  y = act(conv2(o1) + b2)
+// as ONE kernel: the workgroup stages x for its TH x 32 output tile with a 3-pixel halo, computes o0 on the tile + 2 pixels into LDS, o1 on the
+// tile + 1 pixel in place over the staged x (only the thread that owns a pixel reads its x and writes its o1) and y from there.  The three
+// separate launches move 8 tensor passes through HBM (conv1 reads o0 and the skip input and writes a1 and o1); this one reads x once and
+// writes y - plus, when the backward pass will need them (training), o0, a1 and o1: 2 passes for inference, 5 for training.  The price is the
+// halo recomputed per tile ((TH + 4)(36) + (TH + 2)(34) + 32 TH pixel convolutions instead of 3 x 32 TH) on the vector ALUs that already bound
+// the single layers.  An intermediate OUTSIDE the image is the zero padding of the next convolution, not a
+// convolution of padded input: it is stored as 0.  Arithmetic per output value: the same fp32 FMA chain, tap by tap, as conv_small_fwd_kernel
+// (bit-identical results).  Measured at 8 x 1024^2 against the three launches (tools/probe_stage.py, training / inference): 4 channels 0.267 ->
+// 0.167 ms / 0.263 -> 0.149 (0.80 of the HBM peak on the unfused layers' bytes), 8 channels 0.577 -> 0.540 / 0.537 -> 0.491 (0.50), 12 channels
+// 1.267 -> 1.262 / 1.017 -> 1.221: at 12 channels the recomputed halo costs what the saved passes bring, so 12-channel stages keep three launches.
+struct StageParams {
+  const float* x; const float* w0; const float* w1; const float* w2; const float* b0; const float* b1; const float* b2;
+  float* o0; float* a1; float* o1; float* y;
+  int N, H, W, tiles_x, tiles_y; float slope;            // act(v) = v > 0 ? v : slope v (linear 1, relu 0, leaky relu alpha)
+};
+
+// The filters are read through the CONSTANT address space: between the three stages the kernel stores to global memory (o0, a1, o1), and a load
+// that a preceding store might alias is not "invariant" for the compiler - it would fetch every weight with a vector load per lane (measured:
+// the whole kernel 3.5 x slower) instead of the s_load + SGPR-operand form the single-layer kernel gets for free (its stores all come last).
+typedef const float __attribute__((address_space(4))) * const_weights;
+
+template <int C>
+__device__ __forceinline__ void stage_conv3(const float* __restrict__ src, int pitch, const float* wg, float (&acc)[C]) {
+  const const_weights w = (const_weights)wg;
+#pragma unroll 1
+  for (int i = 0; i < 3; ++i)                              // filter rows stay a loop (registers; see conv_small_fwd_kernel)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* px = src + (i * pitch + j) * C;
+      float xv[C];
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(px + 4 * q);
+        xv[4 * q] = v[0]; xv[4 * q + 1] = v[1]; xv[4 * q + 2] = v[2]; xv[4 * q + 3] = v[3];
+      }
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+        for (int o = 0; o < C; ++o) acc[o] = fmaf(xv[ci], w[((i * 3 + j) * C + ci) * C + o], acc[o]);
+    }
+}
+
+template <int C, int TH>
+__global__ __launch_bounds__(256) void resnet3_stage_kernel(StageParams p) {
+  constexpr int XR = TH + 6, XC = STW + 6, R0 = TH + 4, C0 = STW + 4, R1 = TH + 2, C1 = STW + 2, Q = C / 4;
+  constexpr int TOTAL = XR * XC * Q, NX = (TOTAL + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const X = lds;                                    // [XR][XC][C]: x, later o1 (tile + 1 pixel) in place
+  float* const O0 = lds + XR * XC * C;                     // [R0][C0][C]
+  int tile = blockIdx.x;
+  const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+  const int ty = tile % p.tiles_y;
+  const int n = tile / p.tiles_y;
+  const int y0 = ty * TH, x0 = tx * STW;
+  const int64_t img = (int64_t)n * p.H * p.W * C;
+  {                                                        // x with a 3-pixel halo, zero outside the image; all loads of a thread in flight together
+    const float* xin = p.x + img;
+    f32x4 v[NX];
+    unsigned okm = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int u = threadIdx.x + i * 256, q = u % Q, pix = u / Q, r = pix / XC, c = pix - r * XC;
+      const int sy = y0 + r - 3, sx = x0 + c - 3;
+      const bool ok = u < TOTAL && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+      v[i] = *reinterpret_cast<const f32x4*>(xin + (ok ? ((int64_t)sy * p.W + sx) * C + 4 * q : 0));
+      okm |= ok ? (1u << i) : 0u;
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int u = threadIdx.x + i * 256;
+      if (u < TOTAL) *reinterpret_cast<f32x4*>(X + (u / Q) * C + 4 * (u % Q)) = ((okm >> i) & 1u) ? v[i] : z4;
+    }
+  }
+  __syncthreads();
+  auto bias_act = [&](float (&acc)[C], const float* bg) {
+    const const_weights b = (const_weights)bg;             // (constant address space: scalar loads, see stage_conv3)
+#pragma unroll
+    for (int o = 0; o < C; ++o) { const float t = acc[o] + (bg ? b[o] : 0.f); acc[o] = t > 0.f ? t : p.slope * t; }
+  };
+  auto store_px = [&](float* dst, int gy, int gx, const float (&val)[C]) {
+    float* d = dst + img + ((int64_t)gy * p.W + gx) * C;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) *reinterpret_cast<f32x4*>(d + 4 * q) = (f32x4){val[4 * q], val[4 * q + 1], val[4 * q + 2], val[4 * q + 3]};
+  };
+  // ---- o0 on the tile + 2 pixels
+#pragma unroll 1
+  for (int idx = threadIdx.x; idx < R0 * C0; idx += 256) {
+    const int r = idx / C0, c = idx - r * C0, gy = y0 - 2 + r, gx = x0 - 2 + c;
+    float acc[C];
+#pragma unroll
+    for (int o = 0; o < C; ++o) acc[o] = 0.f;
+    stage_conv3<C>(X + (r * XC + c) * C, XC, p.w0, acc);
+    bias_act(acc, p.b0);
+    const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      *reinterpret_cast<f32x4*>(O0 + idx * C + 4 * q) = inside ? (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]} : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.o0 && inside && r >= 2 && r < TH + 2 && c >= 2 && c < STW + 2) store_px(p.o0, gy, gx, acc);
+  }
+  __syncthreads();
+  // ---- a1 = act(conv1(o0)), o1 = x + a1 on the tile + 1 pixel, in place over x
+#pragma unroll 1
+  for (int idx = threadIdx.x; idx < R1 * C1; idx += 256) {
+    const int r = idx / C1, c = idx - r * C1, gy = y0 - 1 + r, gx = x0 - 1 + c;
+    float acc[C];
+#pragma unroll
+    for (int o = 0; o < C; ++o) acc[o] = 0.f;
+    stage_conv3<C>(O0 + (r * C0 + c) * C, C0, p.w1, acc);
+    bias_act(acc, p.b1);
+    const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const bool own = inside && r >= 1 && r < TH + 1 && c >= 1 && c < STW + 1;
+    if (p.a1 && own) store_px(p.a1, gy, gx, acc);
+    float* xs = X + ((r + 2) * XC + (c + 2)) * C;
+    float s[C];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[4 * q + j] = inside ? xv[j] + acc[4 * q + j] : 0.f;
+      *reinterpret_cast<f32x4*>(xs + 4 * q) = (f32x4){s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]};
+    }
+    if (p.o1 && own) store_px(p.o1, gy, gx, s);
+  }
+  __syncthreads();
+  // ---- y = act(conv2(o1)) on the tile
+#pragma unroll 1
+  for (int idx = threadIdx.x; idx < TH * STW; idx += 256) {
+    const int r = idx >> 5, c = idx & 31, gy = y0 + r, gx = x0 + c;
+    float acc[C];
+#pragma unroll
+    for (int o = 0; o < C; ++o) acc[o] = 0.f;
+    stage_conv3<C>(X + ((r + 2) * XC + (c + 2)) * C, XC, p.w2, acc);
+    bias_act(acc, p.b2);
+    if (gy < p.H && gx < p.W) store_px(p.y, gy, gx, acc);
+  }
+}
+
+template <int C, int TH>
+void launch_stage(pcnn_handle h, StageParams p) {
+  constexpr size_t lds = ((size_t)(TH + 6) * (STW + 6) + (size_t)(TH + 4) * (STW + 4)) * C * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resnet3_stage_kernel<C, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  p.tiles_x = pcnn_cdiv(p.W, STW); p.tiles_y = pcnn_cdiv(p.H, TH);
+  hipLaunchKernelGGL((resnet3_stage_kernel<C, TH>), dim3((unsigned)(p.N * p.tiles_x * p.tiles_y)), dim3(256), lds, h->stream, p);
+}
+
 }  // namespace
 
 static int pad4(int c) { return (c + 3) & ~3; }
@@ -484,5 +634,30 @@ int pcnn_conv_small_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x
   const int nel = d->kh * d->kw * d->Cin * d->Cout;
   hipLaunchKernelGGL(small_wgrad_reduce_kernel, dim3(pcnn_cdiv(nel, 16)), dim3(256), 0, h->stream, p.part, dw, nel, p.S);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_wgrad(small reduce)");
+  return 0;
+}
+
+extern "C" int pcnn_resnet3_fwd_eligible(pcnn_handle h, int C, int act) {
+  static const int on = getenv("PCNN_FUSED_STAGE") ? atoi(getenv("PCNN_FUSED_STAGE")) : 1;
+  return (h && on && (C == 4 || C == 8) && (act == PCNN_ACT_LINEAR || act == PCNN_ACT_RELU || act == PCNN_ACT_LEAKY_RELU)) ? 1 : 0;
+}
+
+extern "C" int pcnn_resnet3_fwd(pcnn_handle h, int N, int H, int W, int C, int act, float act_alpha, const float* x, const float* w0, const float* b0,
+                                const float* w1, const float* b1, const float* w2, const float* b2, float* o0, float* a1, float* o1, float* y) {
+  PCNN_REQUIRE(h, h && x && w0 && w1 && w2 && y, "pcnn_resnet3_fwd: null argument");
+  PCNN_REQUIRE(h, pcnn_resnet3_fwd_eligible(h, C, act), "pcnn_resnet3_fwd: %d channels / activation %d are not eligible (ask pcnn_resnet3_fwd_eligible first)", C, act);
+  PCNN_REQUIRE(h, N >= 1 && H >= 1 && W >= 1, "pcnn_resnet3_fwd: bad shape");
+  for (const void* q : {(const void*)x, (const void*)o0, (const void*)a1, (const void*)o1, (const void*)y})
+    PCNN_REQUIRE(h, (reinterpret_cast<uintptr_t>(q) & 15) == 0, "pcnn_resnet3_fwd: tensors must be 16-byte aligned");
+  PCNN_REQUIRE(h, (int64_t)N * pcnn_cdiv(W, STW) * pcnn_cdiv(H, 8) < (1ll << 31), "pcnn_resnet3_fwd: grid too large");
+  StageParams p;
+  p.x = x; p.w0 = w0; p.w1 = w1; p.w2 = w2; p.b0 = b0; p.b1 = b1; p.b2 = b2; p.o0 = o0; p.a1 = a1; p.o1 = o1; p.y = y;
+  p.N = N; p.H = H; p.W = W; p.tiles_x = 0; p.tiles_y = 0;
+  p.slope = act == PCNN_ACT_LINEAR ? 1.f : (act == PCNN_ACT_RELU ? 0.f : act_alpha);
+  static const int th = getenv("PCNN_STAGE_TH") ? atoi(getenv("PCNN_STAGE_TH")) : 16;
+  const bool tall = th == 16 && H > 8;
+  if (C == 4) { if (tall) launch_stage<4, 16>(h, p); else launch_stage<4, 8>(h, p); }
+  else { if (tall) launch_stage<8, 16>(h, p); else launch_stage<8, 8>(h, p); }
+  PCNN_CHECK_LAUNCH(h, "pcnn_resnet3_fwd");
   return 0;
 }

@@ -363,7 +363,25 @@ class resnet:
                 c.bn_name = '%s/bn%d' % (name, i)
                 c.bn_off = store.add_bn(c.bn_name, filters)
 
+    def _fusable(self, x, out):
+        """The narrow stages (3 x 3, 4 / 8 channels, zero padding, no BatchNormalization) run as ONE launch (ops.resnet3_fwd, fp32 math mode; at 12
+        channels the recomputed halo costs what the saved tensor passes bring: tools/probe_stage.py)."""
+        cs = (self.c0, self.c1, self.c2)
+        c = self.c0
+        return (all(u.kh == 3 and u.kw == 3 and u.cin == c.cin and u.cout == c.cin and u.mode == 'CONSTANT' and u.pad_value == 0.0 and u.stride == 1
+                    and u.bn_name is None and u.act == c.act and u.pads_y == (1, 1) and u.pads_x == (1, 1) for u in cs)
+                and x.is_contiguous() and x.shape[3] == c.cin and (out is None or out.is_contiguous())
+                and ops.get_math_mode() == 'fp32' and ops.resnet3_eligible(c.cin, c.act))
+
     def forward(self, x, out=None, training=True, x_absmax=None):
+        if self._fusable(x, out):
+            w = self.c0.store.w
+            wb = [(w[u.name + '/kernel'], w[u.name + '/bias'] if u.use_bias else None) for u in (self.c0, self.c1, self.c2)]
+            y, o0, a1, o1 = ops.resnet3_fwd(x, wb[0][0], wb[0][1], wb[1][0], wb[1][1], wb[2][0], wb[2][1], act=self.c0.act, training=training, out=out)
+            if training:                                     # what the three launches would have saved: the backward pass runs unchanged
+                self.c0.saved, self.c1.saved, self.c2.saved = (x, o0, None, None), (o0, a1, None, None), (o1, y, None, None)
+            self.c0.out_absmax = self.c1.out_absmax = self.c2.out_absmax = self.out_absmax = None
+            return y
         o = self.c0.forward(x, training=training, x_absmax=x_absmax)
         o = self.c1.forward(o, residual=x, training=training, x_absmax=self.c0.out_absmax)
         o = self.c2.forward(o, out=out, training=training, x_absmax=self.c1.out_absmax)

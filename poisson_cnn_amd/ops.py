@@ -142,6 +142,14 @@ def set_post_fusion(on):
     _post_fusion = bool(on)
 
 
+_stage_fusion = __import__('os').environ.get('PCNN_STAGE_FUSION', '1') != '0'    # developer switch: 0 = a narrow resnet stage as three launches
+
+
+def set_stage_fusion(on):
+    global _stage_fusion
+    _stage_fusion = bool(on)
+
+
 class KernelTimer:
     """Live per-kernel timing for bench.py: HIP events (torch.cuda.Event on the launch stream) around every launch of the
     MFMA kernels, with the algorithmic FLOP count of each launch."""
@@ -283,6 +291,30 @@ def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTAN
     _launch('conv_bwd_fused', 2.0 * flops,
             lambda: h.call('pcnn_conv2d_bwd_spectral', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw)), nbytes)
     return out
+
+
+def resnet3_eligible(C, act):
+    """A narrow resnet stage (3 x 3, C -> C three times, zero padding) that pcnn_resnet3_fwd runs as one launch."""
+    h = handle()
+    return _stage_fusion and bool(h.lib.pcnn_resnet3_fwd_eligible(h._h, c_int(C), c_int(ACTS[act])))
+
+
+def resnet3_fwd(x, w0, b0, w1, b1, w2, b2, *, act, training, out=None):
+    """blocks/resnet.py:29-39 as ONE launch (pcnn_resnet3_fwd).  Returns (y, o0, a1, o1): the three intermediates the unfused chain leaves for
+    the backward pass (None when training is False - they then never reach HBM)."""
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and w0.shape == (3, 3, C, C) and w1.shape == (3, 3, C, C) and w2.shape == (3, 3, C, C)
+    if out is None:
+        out = empty((N, H, W, C), x.device)
+    assert out.is_contiguous() and out.shape == x.shape
+    o0, a1, o1 = (empty((N, H, W, C), x.device) for _ in range(3)) if training else (None, None, None)
+    T = 4.0 * N * H * W * C
+    # algorithmic bytes of the UNFUSED layers (what the three conv2d_fwd launches count: conv1 reads the skip input and, in training, writes a1 too)
+    nbytes = (8.0 if training else 7.0) * T + 3 * 4.0 * 9 * C * C
+    _launch('conv_stage', 3 * 2.0 * N * H * W * 9 * C * C,
+            lambda: handle().call('pcnn_resnet3_fwd', c_int(N), c_int(H), c_int(W), c_int(C), c_int(ACTS[act]), c_float(LEAKY_ALPHA), _p(x), _p(w0), _p(b0),
+                                  _p(w1), _p(b1), _p(w2), _p(b2), _p(o0), _p(a1), _p(o1), _p(out)), nbytes)
+    return out, o0, a1, o1
 
 
 def epilogue_bwd(dy, a, *, act='linear', bn_scale=None, dz=None, dbias=None, s_dy_a=None, s_dy=None, ws=None, dz_absmax=None):

@@ -139,6 +139,59 @@ def test_resnet_block_fuses_the_activation_backward_into_the_data_gradient(filte
         assert rel(g, res[False][1][n]) < 2e-6, n
 
 
+@pytest.mark.parametrize('filters,act,hw', [(8, 'tf.nn.leaky_relu', (37, 45)), (4, 'tf.nn.leaky_relu', (16, 32)), (4, 'relu', (9, 70)), (8, 'linear', (7, 5)),
+                                            (8, 'tf.nn.leaky_relu', (50, 33))])
+def test_narrow_resnet_stage_runs_as_one_launch(filters, act, hw):
+    """Round 4: a 3 x 3 resnet stage of 4 / 8 channels with zero padding is ONE kernel (pcnn_resnet3_fwd: the tile's halo is
+    recomputed, conv0's and conv1's outputs live in LDS; an intermediate outside the image is the next convolution's zero padding).  Against the
+    fp64 oracle (blocks/resnet.py:29-39 restated in oracle/hpnn.resnet_forward): inference output, training output, every gradient through the
+    UNCHANGED backward pass (which consumes the three intermediates the fused launch leaves behind), and agreement with the three-launch chain.
+    Shapes: ragged tiles in both axes, images smaller than one tile (8-row tiles) and larger (16-row tiles)."""
+    from poisson_cnn_amd import _lib, ops
+    from poisson_cnn_amd.keras_layers import resnet
+    rng = np.random.default_rng(11)
+    x = f32(rng.standard_normal((2, filters) + hw))
+    dy = f32(rng.standard_normal((2, filters) + hw))
+    oact = {'tf.nn.leaky_relu': 'leaky_relu', 'relu': 'relu', 'linear': 'linear'}[act]
+    to_np = lambda t: t.detach().cpu().numpy().copy() if hasattr(t, 'detach') else np.array(t)
+    res = {}
+    try:
+        for fused in (True, False):
+            ops.set_stage_fusion(fused)
+            blk = resnet(2, padding_mode='constant', filters=filters, kernel_size=3, activation=act, data_format='channels_first', seed=5)
+            blk(x)
+            w = randomize(blk, np.random.default_rng(4))
+            calls = []
+            orig = _lib.Handle.call
+
+            def spy(self, name, *a):
+                calls.append(name)
+                return orig(self, name, *a)
+            _lib.Handle.call = spy
+            try:
+                y_inf = blk(x)
+                y = blk(x, training=True)
+            finally:
+                _lib.Handle.call = orig
+            if fused:
+                assert calls.count('pcnn_resnet3_fwd') == 2 and not any('conv2d_fwd' in c for c in calls), calls
+            else:
+                assert 'pcnn_resnet3_fwd' not in calls and sum('conv2d_fwd' in c for c in calls) == 6, calls
+            ref = ohpnn.resnet_forward(np_ops, w, 'resnet', x, 'CONSTANT', 0.0, oact, False)
+            assert rel(y_inf, ref) < 2e-6 and rel(y, ref) < 2e-6
+            dx = blk.backward(dy)
+            fn = lambda p, xx: ohpnn.resnet_forward(torch_twin, p, 'resnet', xx, 'CONSTANT', 0.0, oact, False)
+            check_grads(blk, w, fn, [x], dy, dx)
+            res[fused] = (to_np(y), to_np(dx), {n: to_np(g) for n, g in blk.gradients.items()})
+    finally:
+        ops.set_stage_fusion(True)
+    # same FMA chain per output value: the fused launch and the three-launch chain agree to the last bit where no sum is reordered
+    assert np.array_equal(res[True][0], res[False][0])
+    assert rel(res[True][1], res[False][1]) < 1e-6
+    for n, g in res[True][2].items():
+        assert rel(g, res[False][2][n]) < 2e-6, n
+
+
 def _oracle_bottleneck(ops_ns, p, x, *, f, up, k, n_convs, mode, val, act, method, pool, use_resnet, use_bn, kdown, kind, resize='bilinear'):
     """blocks/bottleneck_block.py:9-118 restated for every constructor path (conv / pool down-sampling, plain / resnet stages)."""
     H, W = x.shape[2], x.shape[3]
