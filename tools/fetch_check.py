@@ -20,7 +20,8 @@ inv = lambda n: n.startswith('spec_inv') or n.startswith('spec64_inv')
 mix = lambda n: n.startswith('spec_mix')
 wmix = lambda n: n.startswith('spec_wmix')
 print('GB per training step (2 x FETCH_SIZE for reads, WRITE_SIZE for writes)')
-print('forward transforms write %.1f | mixing reads %.1f + weight-gradient GEMM reads %.1f = %.1f (the dz spectrum is read by both, the x-tile spectrum by the GEMM only)'
+print('forward transforms write %.1f | mixing kernels (spec_mix: forward pass, spec_mixw: both gradients of the backward pass in one read of the dz spectrum) read %.1f '
+      '+ separate weight-gradient GEMM %.1f = %.1f (since spec_mixw every spectrum that is written is read exactly once: the two sides must agree)'
       % (wr(fwd), rd(mix), rd(wmix), rd(mix) + rd(wmix)))
 print('mixing writes %.1f (+ weight-gradient GEMM %.1f) | inverse transforms read %.1f (their residual / activation inputs included)' % (wr(mix), wr(wmix), rd(inv)))
 print('mixing: reads %.1f vs writes %.1f (equal channel counts in and out for most layers)' % (rd(mix), wr(mix)))
