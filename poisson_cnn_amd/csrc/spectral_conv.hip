@@ -773,7 +773,13 @@ int chunk_tiles(int Tg) {
   const int t = Tg == 64 ? v / 4 : v;
   return t < 32 ? 32 : t;
 }
-int wgrad_splits() { return 8; }   // partial sums of the weight-gradient GEMM: 2 workgroups x 4 waves per (slot, channel group)
+// partial sums of the weight-gradient GEMM: S / 4 workgroups x 4 waves per (slot, channel group).  64-point tiles have 2 048 slots - one workgroup
+// per slot already fills the chip four times over, and half the partial sums (128 instead of 256 MB written and read back per layer) are worth
+// 0.06-0.08 ms per 13- / 15-tap layer; at 32 points (512 slots) 8 is the measured optimum (4: +0.05 ms at 9 taps, 12 / 16: +0.04 ... 0.08 ms).
+int wgrad_splits(int Tg = 32) {
+  static const int s32 = getenv("PCNN_WSPLIT32") ? atoi(getenv("PCNN_WSPLIT32")) : 8, s64 = getenv("PCNN_WSPLIT64") ? atoi(getenv("PCNN_WSPLIT64")) : 4;
+  return Tg == 64 ? s64 : s32;
+}
 
 // workspace header: the constant tables of both tile sizes; the per-call regions follow
 constexpr size_t O_TAB32 = 0, O_SLOTS32 = O_TAB32 + ((TAB_FLOATS * 4 + 255) & ~255), O_TAB64 = O_SLOTS32 + NSLOT * 16,
@@ -1050,7 +1056,7 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
   const int pack = Tg == 64 ? 1 : pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
   const int64_t ntile = (int64_t)d->N * tiles_y * tgx;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
-  const int gin = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();
+  const int gin = pcnn_cdiv(d->Cin, 32), S = wgrad_splits(Tg);
   const int rows = Tg * Tg, nslot = rows / 2;
   // workspace: [C^ | x window spectra | dz tile spectra | partial sums]
   const size_t csp_b = align256(sp_bytes((size_t)d->Cin, rows)), part_b = align256((size_t)S * nslot * gin * 4 * 1024 * 4);
@@ -1161,7 +1167,7 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
   const int pack = Tg == 64 ? 1 : pack_for(d->Cin, d->Cout), cpt = 32 / pack, tgx = pcnn_cdiv(tiles_x, pack);
   const int64_t ntile = (int64_t)d->N * tiles_y * tgx;
   PCNN_REQUIRE(h, ntile < (1ll << 30), "spectral convolution: too many tiles");
-  const int gz = 1, gx = pcnn_cdiv(d->Cin, 32), S = wgrad_splits();       // channel groups of dz (<= 32 channels) and of x / dx
+  const int gz = 1, gx = pcnn_cdiv(d->Cin, 32), S = wgrad_splits(Tg);       // channel groups of dz (<= 32 channels) and of x / dx
   const int rows = Tg * Tg, nslot = rows / 2;
   // workspace: [filter spectrum | dz spectra (gz) | dx spectra (gx) | x-tile spectra (gx) | partial sums]; C^ reuses the filter-spectrum slot
   const size_t wsp_b = align256(sp_bytes((size_t)std::max(dg->Cin * gx, d->Cin), rows));
