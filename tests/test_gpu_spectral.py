@@ -120,6 +120,40 @@ def test_fused_backward_shares_the_gradient_spectrum(k, Cin, Cout, mode):
     assert np.linalg.norm(dw.cpu().numpy() - ref_dw) / np.linalg.norm(ref_dw) < 5e-6
 
 
+def test_fused_backward_in_chunks_under_a_workspace_limit():
+    """The fused backward under pcnn_set_workspace_limit: the tile grid is walked in several launches, the fused mixing kernel (spec_mixw_kernel: channel
+    mixing of the data gradient + weight-gradient GEMM from ONE read of the dz spectrum) ACCUMULATES its partial sums from chunk to chunk.  The data
+    gradient is bit-identical to the unchunked call (a tile's arithmetic does not depend on its launch), the weight gradient agrees to rounding (its
+    tile sum is split differently) and with the fp64 oracle."""
+    import ctypes
+    import torch.nn.functional as F
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(21)
+    N, H, W, k, C = 4, 150, 150, 7, 32
+    x = torch.randn(N, H, W, C, device='cuda', generator=g)
+    dz = torch.randn(N, H, W, C, device='cuda', generator=g)
+    w = torch.randn(k, k, C, C, device='cuda', generator=g) * 0.03
+    wf = ops.flip_transpose_weights(w)
+    ops.set_spectral_mode('force')
+    h = ops.handle()
+    try:
+        dw0 = torch.empty_like(w)
+        dx0 = ops.conv2d_bwd_fused(x, dz, w.shape, wf, pad_top=3, pad_left=3, pad_mode='CONSTANT', pad_value=0.0, dw=dw0, residual=None).clone()
+        h.call('pcnn_set_workspace_limit', ctypes.c_size_t(100 << 20))           # 144 tiles -> four launches of 36
+        dw1 = torch.empty_like(w)
+        dx1 = ops.conv2d_bwd_fused(x, dz, w.shape, wf, pad_top=3, pad_left=3, pad_mode='CONSTANT', pad_value=0.0, dw=dw1, residual=None)
+        assert torch.equal(dx0, dx1)
+        assert float((dw1 - dw0).norm() / dw0.norm()) < 1e-6
+    finally:
+        h.call('pcnn_set_workspace_limit', ctypes.c_size_t(0))
+        ops.set_spectral_mode('auto')
+    xt = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    wt = w.permute(3, 2, 0, 1).double().cpu().requires_grad_(True)
+    (F.conv2d(xt, wt, padding=3) * dz.permute(0, 3, 1, 2).double().cpu()).sum().backward()
+    assert float((dx1.permute(0, 3, 1, 2).double().cpu() - xt.grad).norm() / xt.grad.norm()) < 3e-6
+    assert float((dw1.permute(3, 2, 0, 1).double().cpu() - wt.grad).norm() / wt.grad.norm()) < 5e-6
+
+
 def test_random_narrow_shapes_through_the_packed_route():
     """Twenty seeded random layers of <= 16 channels (2 / 4 / 8 tiles per work item): even and odd filters 4 ... 15, images from one tile
     group up to a few, ragged last groups, every padding mode, N up to 3 - forward, data gradient and weight gradient of the fused backward
