@@ -50,6 +50,7 @@ constexpr int T = 32, ROWS = 1024, NSLOT = 512;
 // transforms of one radix-2 step of the 32-point complex DFT (see build_tables); GI2 the real-column inverse split into its two parities
 constexpr int TAB_G = 0, TAB_GI = 1024, TAB_F2 = 2048, TAB_FI2 = 4096, TAB_GI2 = 6144, TAB_FLOATS = 7168;
 constexpr size_t LDS_U = (size_t)T * T * 32 * sizeof(float);   // 128 KB
+constexpr size_t LDS_INV = LDS_U + 1024 * sizeof(float);       // the inverse kernel keeps the real-column table (GI2) behind U: see spec_inv_kernel
 // (a storage order with rows blocked 32 tiles wide - whole DRAM pages for the per-frequency kernels - was measured in round 2: no gain)
 __host__ __device__ __forceinline__ int64_t sp_item(int64_t item) { return pcnn_spec::sp_item(item, ROWS); }
 
@@ -254,13 +255,18 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
   const int total = p.ntile * p.groups;
   int item = blockIdx.x;
   if (item >= total) return;
-  float fireg[16], gireg[16], gi2reg[16];
+  // The table of the two real columns (GI2) is used by two of the eight waves, once per item: it lives in LDS behind U and is read where it is used
+  // (16 transient registers) instead of occupying 16 registers of EVERY wave for the whole kernel - those registers are what lets the epilogue
+  // request a whole output row's residual / activation values in ONE burst (BURST below).
+  float* const G2 = U + T * T * 32;
+  for (int i = tid; i < 1024; i += 512) G2[i] = p.tab[TAB_GI2 + i];
+  float fireg[16], gireg[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     fireg[ks] = p.tab[TAB_FI2 + h * 1024 + (2 * ks + half) * 32 + c];
     gireg[ks] = p.tab[TAB_GI + (2 * ks + half) * 32 + c];
-    gi2reg[ks] = q == 3 ? p.tab[TAB_GI2 + (2 * ks + half) * 32 + c] : 0.f;
   }
+  __syncthreads();
   float* const Uh = U + h * (16 * 32 * 32);
   float b[4][16];
   {
@@ -269,7 +275,11 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
     for (int u = 0; u < 4; ++u) inv_load_unit(in, q, h, loff, u, b[u]);
   }
   float ymax = 0.f;
-  constexpr int BURST = POST ? (RES ? 4 : 8) : 8;
+  // values of an output row whose residual / activation inputs are requested together, before any of the row's stores: the memory counter is
+  // in-order, so a burst issued behind the previous burst's stores waits until those stores have COMPLETED - every burst boundary is one exposed
+  // write latency.  One burst per row (two where both inputs are read) instead of two (four): an input stream cost 0.32 ms per 8 x 1024^2 x 32
+  // launch, now 0.10 (residual), 0.25 -> 0.06 (POST), 0.84 -> 0.34 (both) - tools/probe_epilogue_variants.py.
+  constexpr int BURST = POST ? (RES ? 8 : 16) : 16;
   float bsum = 0.f;                                                  // POST: sum of what this lane stored (its channel's bias-gradient share)
   for (;;) {
     const int next = item + gridDim.x;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
         }
       } else {                                                       // rows 16 par + y: both parities from this one wave
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = mfma(gi2reg[ks], b[u][ks], acc);
+        for (int ks = 0; ks < 16; ++ks) acc = mfma(G2[(2 * ks + half) * 32 + c], b[u][ks], acc);
         if (next < total) inv_load_unit(nin, q, h, loff, u, b[u]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -828,7 +838,7 @@ Geom geom_of(pcnn_handle h, int Tg) {
 }
 
 template <typename K>
-void set_lds(K kernel) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_U); }
+void set_lds(K kernel, size_t bytes = LDS_U) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
 // persistent kernels: one 8-wave workgroup per CU (128 KB of LDS each) walking the (tile, channel group) items
 template <bool MASKED, bool FENCE>
@@ -846,8 +856,8 @@ void launch_fwd(pcnn_handle h, const Geom& gm, FwdParams p, int ntile) {
 }
 template <bool TANH, bool RES>
 void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
-  set_lds(spec_inv_kernel<TANH, RES>);
-  hipLaunchKernelGGL((spec_inv_kernel<TANH, RES>), grid, dim3(512), LDS_U, h->stream, p);
+  set_lds(spec_inv_kernel<TANH, RES>, LDS_INV);
+  hipLaunchKernelGGL((spec_inv_kernel<TANH, RES>), grid, dim3(512), LDS_INV, h->stream, p);
 }
 void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
   p.ntile = ntile; p.tab = gm.tab;
@@ -856,9 +866,9 @@ void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
   if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)
     p.alpha = 1.f;
     p.galpha = p.gmode == PCNN_ACT_LINEAR ? 1.f : (p.gmode == PCNN_ACT_RELU ? 0.f : p.galpha);
-    set_lds(spec_inv_kernel<false, true, true>); set_lds(spec_inv_kernel<false, false, true>);
-    if (p.res) hipLaunchKernelGGL((spec_inv_kernel<false, true, true>), grid, dim3(512), LDS_U, h->stream, p);
-    else hipLaunchKernelGGL((spec_inv_kernel<false, false, true>), grid, dim3(512), LDS_U, h->stream, p);
+    set_lds(spec_inv_kernel<false, true, true>, LDS_INV); set_lds(spec_inv_kernel<false, false, true>, LDS_INV);
+    if (p.res) hipLaunchKernelGGL((spec_inv_kernel<false, true, true>), grid, dim3(512), LDS_INV, h->stream, p);
+    else hipLaunchKernelGGL((spec_inv_kernel<false, false, true>), grid, dim3(512), LDS_INV, h->stream, p);
     return;
   }
   if (p.act == PCNN_ACT_TANH) {
