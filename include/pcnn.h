@@ -162,8 +162,9 @@ int pcnn_conv2d_bwd_spectral(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
  * pcnn_conv2d_epilogue_bwd would do in a separate pass over the tensor before conv_prev's own backward (blocks/resnet.py:29-39 chains three
  * such layers; models/Homogeneous_Poisson_NN_Legacy.py:86-96 seven such blocks):
  *   v = dgrad(dz) (+ residual);  raw_out (optional, stride ld_raw) = v;  dx = v * act'(act_out);  dbias (optional, Cin floats) = sum over pixels of dx.
- * act_out (stride ld_act_out) is conv_prev's saved activation output, act / act_alpha its activation.  Available where the data gradient runs
- * on 32-point tiles with one channel group (ask _post_eligible); otherwise call pcnn_conv2d_bwd_spectral and pcnn_conv2d_epilogue_bwd. */
+ * act_out (stride ld_act_out) is conv_prev's saved activation output, act / act_alpha its activation.  Available where the data gradient has
+ * one channel group (Cin <= 32; both the 32-point and - since the second session of round 4 - the 64-point inverse kernel carry the epilogue; ask
+ * _post_eligible); otherwise call pcnn_conv2d_bwd_spectral and pcnn_conv2d_epilogue_bwd. */
 typedef struct pcnn_post_desc {
   const float* act_out; int ld_act_out; int act; float act_alpha;
   float* dbias; float* raw_out; int ld_raw;

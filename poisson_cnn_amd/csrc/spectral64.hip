@@ -413,7 +413,9 @@ constexpr int NR = 7;                  // output rows per wave: rows y = wave + 
 
 struct InvItem { int tg, q, vy; };
 
-template <bool TANH, bool RES>
+// POST (data-gradient launches, InvParams): the activation backward of the layer that produced this convolution's input - y2 (if given) receives
+// v = conv + residual, y receives v act'(gact), and every lane adds what it stored for its four channels into bsum[((block 8 + wave) 64 + lane) 4 + j]
+template <bool TANH, bool RES, bool POST = false>
 __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vycap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const TIY = lds;                                  // [hh][C S][yb][ks][lane]
@@ -474,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
 #pragma unroll
   for (int i = 0; i < NR; ++i) { XE[i][0] = zero4(); XE[i][1] = zero4(); XO[i][0] = zero4(); XO[i][1] = zero4(); }
   float ymax = 0.f;
+  f32x4 bsum = zero4();                                       // POST: this lane's share of the bias gradient (its four channels; a workgroup keeps one q)
   float z[32];
   InvItem ia, ib;                                             // ia: the item whose columns are being transformed, ib: the item being accumulated
   item_of(0, ia);
@@ -594,11 +597,25 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
           if (y < ib.vy && nv > 0 && !(p.cpt & 1)) {             // (p.cpt & 1: removal study - no epilogue)
             const int64_t rowpix = p.flip ? ((int64_t)n * p.Ho + (p.Ho - 1 - y0 - y)) * p.Wo + (p.Wo - 1 - x0) : ((int64_t)n * p.Ho + y0 + y) * p.Wo + x0;
             float* yrow = p.y + rowpix * p.ldy;
-            float* arow = p.act_out ? p.act_out + rowpix * p.ld_act : nullptr;
+            float* arow = (!POST && p.act_out) ? p.act_out + rowpix * p.ld_act : nullptr;
             const float* rrow = RES ? p.res + rowpix * p.ld_res : nullptr;
+            const float* grow = POST ? p.gact + rowpix * p.ld_gact : nullptr;
+            float* y2row = (POST && p.y2) ? p.y2 + rowpix * p.ld_y2 : nullptr;
             int chv = chan;
             asm volatile("" : "+v"(chv));                         // opaque: the pixel offsets below are formed here, not hoisted out of the item loop
-            f32x4 rv[4];
+            f32x4 rv[4], gv[4];
+            if (POST) {                                            // the producing layer's activation output: same burst form as the residual
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int xx = 32 * (e >> 1) + 16 * (e & 1) + xl;
+                const float* gp = grow + (xx < vx ? (int)(xsgn * xx * p.ld_gact) : 0) + chv;
+                if (vec) gv[e] = *reinterpret_cast<const f32x4*>(gp);
+                else {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) gv[e][j] = j < nv ? gp[j] : 0.f;
+                }
+              }
+            }
             if (RES) {                                             // the row's residual values first, as one burst of loads (no load between stores)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -619,23 +636,34 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
                 f32x4 a4, o4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                  float v = (hx ? XE[i][xb][j] - XO[i][xb][j] : XE[i][xb][j] + XO[i][xb][j]) + bias[j];
-                  v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
-                  a4[j] = v;
-                  v = v * sc[j] + sh[j];
+                  float v = hx ? XE[i][xb][j] - XO[i][xb][j] : XE[i][xb][j] + XO[i][xb][j];
+                  if (!POST) {                                     // (a data-gradient launch has no bias, activation, BN or act_out)
+                    v += bias[j];
+                    v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+                    a4[j] = v;
+                    v = v * sc[j] + sh[j];
+                  }
                   if (RES) v += rv[e][j];
+                  if (POST) {
+                    a4[j] = v;                                     // the un-multiplied gradient (skip connection): y2
+                    const float g = gv[e][j];
+                    v *= p.gmode == PCNN_ACT_TANH ? 1.f - g * g : (g > 0.f ? 1.f : p.galpha);
+                    if (j < nv) bsum[j] += v;
+                  }
                   o4[j] = v;
                   if (j < nv) ymax = fmaxf(ymax, fabsf(v));
                 }
                 const int xo = xsgn * xx;
+                float* second = POST ? y2row : arow;               // the second output: activation (forward) or raw gradient (POST)
+                const int ld2 = POST ? p.ld_y2 : p.ld_act;
                 if (vec) {
-                  if (arow) *reinterpret_cast<f32x4*>(arow + (int)(xo * p.ld_act) + chv) = a4;
+                  if (second) *reinterpret_cast<f32x4*>(second + (int)(xo * ld2) + chv) = a4;
                   *reinterpret_cast<f32x4*>(yrow + (int)(xo * p.ldy) + chv) = o4;
                 } else {
 #pragma unroll
                   for (int j = 0; j < 4; ++j)
                     if (j < nv) {
-                      if (arow) arow[(int)(xo * p.ld_act) + chv + j] = a4[j];
+                      if (second) second[(int)(xo * ld2) + chv + j] = a4[j];
                       yrow[(int)(xo * p.ldy) + chv + j] = o4[j];
                     }
                 }
@@ -649,6 +677,11 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
     }
     lds_barrier();
   }
+  if (POST && p.bsum) {                                        // own slot: launches of one call follow each other on the stream
+    float* bs = p.bsum + ((size_t)(blockIdx.x * 8 + wave) * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] += bsum[j];
+  }
   if (p.absmax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
@@ -659,7 +692,27 @@ __global__ __launch_bounds__(512, 2) void spec64_inv_kernel(InvParams p, int vyc
   }
 }
 
+// POST: dbias[ch] from the lanes' partial sums of spec64_inv_kernel<.., POST>, added in a fixed order.  Channel ch = 16 q + 4 g4 + j lives in the workgroups
+// with (block >> 3) & 1 == q (the grid is a multiple of 16: a workgroup keeps one q), lanes with lane >> 4 == g4, component j.  One workgroup per channel.
+__global__ __launch_bounds__(256) void spec_post_bias64_kernel(const float* __restrict__ bsum, int nblocks, float* __restrict__ dbias) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, t = threadIdx.x, q = ch >> 4, g4 = (ch & 15) >> 2, j = ch & 3;
+  float a = 0.f;
+  for (int sl = t; sl < nblocks * 8 * 16; sl += 256) {          // (block, wave, pixel lane)
+    const int px = sl & 15, bw = sl >> 4, block = bw >> 3;
+    if (((block >> 3) & 1) == q) a += bsum[((size_t)bw * 64 + g4 * 16 + px) * 4 + j];
+  }
+  red[t] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
+  if (t == 0) dbias[ch] = red[0];
+}
+
 }  // namespace
+
+void launch_post_bias64(pcnn_handle h, const float* bsum, int nblocks, int C, float* dbias) {
+  hipLaunchKernelGGL(spec_post_bias64_kernel, dim3((unsigned)C), dim3(256), 0, h->stream, bsum, nblocks, dbias);
+}
 
 // ------------------------------------------------------------------------------------------------------------------ host side
 void build_tables64(float* tab, int* slots) {
@@ -795,6 +848,18 @@ void launch_inv64(pcnn_handle h, InvParams p, int ntile) {
   const int ntg = ntile * p.groups;
   const unsigned grid = (unsigned)std::min((2 * ((ntg + 7) & ~7) + 15) & ~15, 256);
   const size_t lds = (8192 + 2 * (size_t)vycap * 256) * sizeof(float);
+  if (p.gact) {                                                  // data gradient + the producer's activation backward (linear conv epilogue)
+    p.alpha = 1.f;
+    p.galpha = p.gmode == PCNN_ACT_LINEAR ? 1.f : (p.gmode == PCNN_ACT_RELU ? 0.f : p.galpha);
+    if (p.res) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spec64_inv_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((spec64_inv_kernel<false, true, true>), dim3(grid), dim3(512), lds, h->stream, p, vycap);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spec64_inv_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((spec64_inv_kernel<false, false, true>), dim3(grid), dim3(512), lds, h->stream, p, vycap);
+    }
+    return;
+  }
   if (p.act == PCNN_ACT_TANH) {
     if (p.res) launch_inv64_t<true, true>(h, p, grid, vycap, lds); else launch_inv64_t<true, false>(h, p, grid, vycap, lds);
   } else {

@@ -79,5 +79,6 @@ constexpr int TAB64_FLOATS = 32768;
 void build_tables64(float* tab, int* slots);                 // TAB64_FLOATS floats, 2048 x int4 slots
 void launch_fwd64(pcnn_handle h, FwdParams p, int ntile);     // p.tab: the 64-point table block
 void launch_inv64(pcnn_handle h, InvParams p, int ntile);
+void launch_post_bias64(pcnn_handle h, const float* bsum, int nblocks, int C, float* dbias);   // POST at 64 points: bsum holds 4 floats per (block, wave, lane)
 
 }  // namespace pcnn_spec

@@ -1148,7 +1148,7 @@ extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_
 
 extern "C" int pcnn_conv2d_bwd_spectral_post_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg) {
   if (!pcnn_conv2d_bwd_spectral_eligible(h, d, dg)) return 0;
-  return pick_tile(h, dg) == 32 && d->Cin <= 32 ? 1 : 0;             // the 32-point inverse carries the POST epilogue; one channel group
+  return d->Cin <= 32 ? 1 : 0;                                       // both inverse kernels carry the POST epilogue; one channel group
 }
 
 static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
@@ -1187,7 +1187,7 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
   const int chunk = fit_chunk(h, (int)std::min<int64_t>(chunk_tiles(Tg) / gx, ntile), [&](int ch) { return wsp_b + part_b + 4096 + zs_bytes(ch) + 2 * ys_bytes(ch); });
   const size_t zs_b = zs_bytes(chunk), ys_b = ys_bytes(chunk);
   char* r;
-  const size_t bs_b = post ? (size_t)256 * 8 * 64 * sizeof(float) : 0;       // POST: one partial bias sum per (workgroup, wave, lane)
+  const size_t bs_b = post ? (size_t)256 * 8 * 64 * 4 * sizeof(float) : 0;   // POST: one partial bias sum per (workgroup, wave, lane) - four at 64 points (a lane holds four channels)
   if (int rc = ensure_workspace(h, wsp_b + zs_b + 2 * ys_b + part_b + bs_b + 4096, &r)) return rc;
   const Geom gm = geom_of(h, Tg);
   float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
@@ -1246,7 +1246,10 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
     launch_fwd(h, gm, fxm, nt);
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gx), dim3(256), 0, h->stream, wm);
   }
-  if (post && post->dbias) hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * 8, pack, cpt, post->dbias);
+  if (post && post->dbias) {
+    if (Tg == 64) launch_post_bias64(h, bsum, 256, dg->Cout, post->dbias);
+    else hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * 8, pack, cpt, post->dbias);
+  }
   float* csp = wsp;                                      // the filter spectrum is no longer needed: every mixing launch above has read it (same stream)
   hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gx), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);
   launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 1), 1);

@@ -91,8 +91,9 @@ def test_resnet_block(use_bn):
         resnet(2, filters=4, kernel_size=3)(x)
 
 
-@pytest.mark.parametrize('filters,k,act,hw', [(32, 7, 'tf.nn.leaky_relu', (70, 83)), (12, 5, 'tf.nn.tanh', (64, 64)), (20, 9, 'tf.nn.leaky_relu', (50, 41))])
-def test_resnet_block_fuses_the_activation_backward_into_the_data_gradient(filters, k, act, hw):
+@pytest.mark.parametrize('filters,k,act,hw,tile', [(32, 7, 'tf.nn.leaky_relu', (70, 83), 0), (12, 5, 'tf.nn.tanh', (64, 64), 0), (20, 9, 'tf.nn.leaky_relu', (50, 41), 0),
+                                                 (32, 15, 'tf.nn.leaky_relu', (70, 83), 64), (28, 13, 'tf.nn.tanh', (101, 60), 64), (24, 11, 'tf.nn.tanh', (66, 120), 64)])
+def test_resnet_block_fuses_the_activation_backward_into_the_data_gradient(filters, k, act, hw, tile):
     """Round 4: with zero padding and the data gradients on the 32-point spectral route, each convolution's data-gradient
     kernel applies the activation backward of the convolution BEFORE it (dz = dx act'(a), bias gradient from per-lane partial sums; conv2's also
     hands back the raw gradient for the skip connection).  The block's gradients must match the fp64 oracle exactly as without the fusion,
@@ -105,6 +106,7 @@ def test_resnet_block_fuses_the_activation_backward_into_the_data_gradient(filte
     oact = 'leaky_relu' if 'leaky' in act else 'tanh'
     res = {}
     ops.set_spectral_mode('force')
+    ops.set_spectral_tile(tile)                                # 64: the 64-point inverse kernel's POST epilogue (second session of round 4), ragged 16-channel halves
     try:
         for fused in (True, False):
             ops.set_post_fusion(fused)
@@ -133,6 +135,7 @@ def test_resnet_block_fuses_the_activation_backward_into_the_data_gradient(filte
             res[fused] = (to_np(dx), {n: to_np(g) for n, g in blk.gradients.items()})
     finally:
         ops.set_post_fusion(True)
+        ops.set_spectral_tile(0)
         ops.set_spectral_mode('auto')
     assert rel(res[True][0], res[False][0]) < 1e-6
     for n, g in res[True][1].items():
