@@ -21,6 +21,7 @@ struct DeconvParams {
   float* dx; int lddx;             // coarse gradient
   float* partial;                  // bwd-filter partials [S][f*f][Cout][Cin]
   int tiles_x, S;
+  float* dummy;                    // fwd: 64 floats that absorb the stores (and serve the loads) of lanes / pixels outside the output
 };
 
 // K (f,f,Cout,Cin) -> [tap][g][h][co32][4]: element j = K[tap][co][8g+4h+j]            (B operand of fwd: k = ci, n = co)
@@ -43,6 +44,12 @@ __global__ void pack_deconv_bwd_kernel(const float* __restrict__ k, float* __res
 }
 
 // ---------------------------------------------------------------- forward
+// The tap loop holds NO lane-dependent control flow: accesses of lanes / pixels outside the output go to a per-lane dummy word instead of being
+// predicated (this compiler puts even a single predicated store behind a branch, and behind a branch the number of memory operations is not
+// static: every wait then covers everything outstanding).  With a static count the accumulate mode (RMW: the branch merge, beta != 0) can request
+// the NEXT tap's sixteen old values BEFORE this tap's stores are issued - the memory counter is in-order, a load issued behind stores is waited for
+// until those stores have completed: one exposed write latency per tap in the form that loaded a tap's old values at the top of its own pass.
+template <bool RMW>
 __global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
   int wid = blockIdx.x * 4 + (threadIdx.x >> 6);               // wave -> (n, yc, x tile, filter row ty): one fine output row per wave, so
@@ -69,47 +76,60 @@ __global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
   }
   const float bias = (p.bias && col < p.Cout) ? p.bias[col] : 0.f;
   const f32x4* wl = reinterpret_cast<const f32x4*>(p.wp) + half * 32 + col;
-  {
-    const bool rmw = p.beta != 0.f;                              // uniform
-    const int64_t rowbase = (((int64_t)n * p.H + Y) * p.W) * p.ldy + col;
-    for (int tx = 0; tx < p.f; ++tx) {
-      const int tap = ty * p.f + tx;
-      // accumulate mode: this tap's sixteen old values as ONE burst of unconditional loads, issued before the MFMAs (a load between the
-      // stores is waited for with vmcnt(0) each: sixteen exposed latencies per tap - the read-modify-write ran at 27 % of the HBM peak)
-      float old[16];
-      if (rmw) {
+  float* const yrow = p.y + (((int64_t)n * p.H + Y) * p.W) * p.ldy + col;
+  // (the dummy word as an OFFSET from the row: a select between two pointers is turned back into a branch around the access, a select between two
+  // integer offsets of one base is a v_cndmask)
+  const int64_t doff = (p.dummy + lane) - yrow;
+  // element i of this lane for tap tx: fine pixel X = xc f + tx - px of coarse pixel xc = x0 + 8 (i >> 2) + 4 half + (i & 3)
+  auto where = [&](int i, int tx) -> float* {
+    const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
+    const int X = xc * p.f + tx - p.px;
+    const bool ok = col < p.Cout && xc < p.wc && X >= 0 && X < p.W;
+    int64_t off = ok ? (int64_t)X * p.ldy : doff;
+    asm volatile("" : "+v"(off));                              // opaque: otherwise the optimiser re-derives the two pointers and branches around the access
+    return yrow + off;
+  };
+  // the filter fragments of a tap (B operands: 4 channel groups x 16 bytes per lane; groups beyond ng re-read the last one - their A operands are zero)
+  auto load_b = [&](int tx, f32x4 (&b)[4]) {
+    const int tp = ty * p.f + tx;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
-          const int X = xc * p.f + tx - p.px;
-          const bool ok = col < p.Cout && xc < p.wc && X >= 0 && X < p.W;
-          old[i] = p.y[ok ? rowbase + (int64_t)X * p.ldy : rowbase - col];       // !ok: the row's first float
-        }
-      }
-      f32x16 acc;
+    for (int g = 0; g < 4; ++g) b[g] = wl[(int64_t)(tp * ng + min(g, ng - 1)) * 64];
+  };
+  float old[16];
+  f32x4 b[4];
+  load_b(0, b);
+  if (RMW) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g < ng) {
-          const f32x4 b = wl[(int64_t)(tap * ng + g) * 64];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][j], b[j], acc, 0, 0, 0);
-        }
-      }
-      if (col < p.Cout) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
-          const int X = xc * p.f + tx - p.px;
-          if (xc < p.wc && X >= 0 && X < p.W) {
-            const float v = p.alpha * (acc[i] + bias);
-            p.y[rowbase + (int64_t)X * p.ldy] = rmw ? p.beta * old[i] + v : v;
-          }
-        }
-      }
-    }
+    for (int i = 0; i < 16; ++i) old[i] = *where(i, 0);
   }
+  auto tap = [&](int tx) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][j], b[g][j], acc, 0, 0, 0);
+    float out[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = p.alpha * (acc[i] + bias);
+      out[i] = RMW ? p.beta * old[i] + v : v;
+    }
+    // the next tap's operands (the last tap re-reads its own): BEFORE this tap's stores.  (A filter load inside the MFMA loop used to be waited for
+    // with vmcnt(0) - four times per tap everything outstanding, the previous tap's stores included.)
+    const int tn = min(tx + 1, p.f - 1);
+    load_b(tn, b);
+    if (RMW) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) old[i] = *where(i, tn);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *where(i, tx) = out[i];
+  };
+  // first tap outside the loop: a pass inside it then always starts from the same memory-counter state
+  tap(0);
+  for (int tx = 1; tx < p.f; ++tx) tap(tx);
 }
 
 // ---------------------------------------------------------------- backward data
@@ -220,8 +240,8 @@ int pcnn_deconv_fwd_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, i
                          const float* bias, float alpha, float beta, float* y, int ldy) {
   if (Cin > 32 || Cout > 32 || Cin % 4 || ldx % 4 || !aligned16(x)) return -1;
   const int ng = (Cin + 7) >> 3;
-  const size_t need = (size_t)f * f * ng * 64 * 4 * sizeof(float);
-  if (!ensure_scratch(h, need)) PCNN_FAIL(h, "pcnn_deconv_fwd: cannot allocate filter scratch");
+  const size_t need = (size_t)f * f * ng * 64 * 4 * sizeof(float);                 // packed filter, then 64 dummy floats (deconv_fwd_mfma_kernel)
+  if (!ensure_scratch(h, need + 64 * sizeof(float))) PCNN_FAIL(h, "pcnn_deconv_fwd: cannot allocate filter scratch");
   const int64_t tot = (int64_t)f * f * ng * 64 * 4;
   hipLaunchKernelGGL(pack_deconv_fwd_kernel, dim3((unsigned)std::min<int64_t>(pcnn_cdiv64(tot, 256), 1024)), dim3(256), 0, h->stream, k,
                      static_cast<float*>(h->scratch), f * f, Cin, Cout, ng);
@@ -229,8 +249,10 @@ int pcnn_deconv_fwd_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int H, i
   p.N = N; p.hc = hc; p.wc = wc; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.f = f; p.py = (hc * f - H) / 2; p.px = (wc * f - W) / 2;
   p.x = x; p.ldx = ldx; p.wp = static_cast<const float*>(h->scratch); p.bias = bias; p.alpha = alpha; p.beta = beta; p.y = y; p.ldy = ldy;
   p.tiles_x = pcnn_cdiv(wc, 32);
+  p.dummy = static_cast<float*>(h->scratch) + need / sizeof(float);
   const int64_t waves = (int64_t)N * hc * p.tiles_x * f;
-  hipLaunchKernelGGL(deconv_fwd_mfma_kernel, dim3((unsigned)pcnn_cdiv64(waves, 4)), dim3(256), 0, h->stream, p);
+  if (beta != 0.f) hipLaunchKernelGGL(deconv_fwd_mfma_kernel<true>, dim3((unsigned)pcnn_cdiv64(waves, 4)), dim3(256), 0, h->stream, p);
+  else hipLaunchKernelGGL(deconv_fwd_mfma_kernel<false>, dim3((unsigned)pcnn_cdiv64(waves, 4)), dim3(256), 0, h->stream, p);
   PCNN_CHECK_LAUNCH(h, "pcnn_deconv_fwd(mfma)");
   return 0;
 }
