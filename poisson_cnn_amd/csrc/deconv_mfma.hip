@@ -133,11 +133,16 @@ __global__ __launch_bounds__(256) void deconv_fwd_mfma_kernel(DeconvParams p) {
 }
 
 // ---------------------------------------------------------------- backward data
+// One WORKGROUP owns 32 consecutive coarse pixels of one coarse row; its four waves split the f x f taps (wave w: filter rows ty = w, w + 4, ...) and
+// their partial sums are added in a fixed order through LDS - a 128 x up-sampling of an 8 x 8 grid used to be 64 waves of 16 384 taps each on a
+// 256-CU chip.  The tap loop is a two-stage software pipeline: the fine-gradient fragments (4 x 16 bytes per lane) and filter fragments of the NEXT
+// tap are requested before the current tap's sixteen MFMAs (they used to be loaded one channel group at a time, each waited for where it was issued:
+// four exposed latencies per tap); loads of lanes / rows outside the gradient re-read a valid address and are zeroed when consumed.
 __global__ __launch_bounds__(256) void deconv_bwd_data_mfma_kernel(DeconvParams p) {
+  __shared__ float red[4][16][64];
   const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
-  int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int total = p.N * p.hc * p.tiles_x;
-  if (wid >= total) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int wid = blockIdx.x;
   const int tx0 = wid % p.tiles_x; wid /= p.tiles_x;
   const int yc = wid % p.hc, n = wid / p.hc;
   const int x0 = tx0 * 32;
@@ -147,32 +152,49 @@ __global__ __launch_bounds__(256) void deconv_bwd_data_mfma_kernel(DeconvParams 
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const f32x4* wl = reinterpret_cast<const f32x4*>(p.wp) + half * 32 + col;
-  for (int ty = 0; ty < p.f; ++ty) {
-    const int Y = yc * p.f + ty - p.py;
-    if (Y < 0 || Y >= p.H) continue;
-    for (int tx = 0; tx < p.f; ++tx) {
-      const int tap = ty * p.f + tx;
-      const int X = xc_l * p.f + tx - p.px;
-      const bool v = xc_l < p.wc && X >= 0 && X < p.W;
-      const float* src = p.dy + (((int64_t)n * p.H + Y) * p.W + (v ? X : 0)) * p.lddy;
+  const float* img = p.dy + (int64_t)n * p.H * p.W * p.lddy;
+  // this wave's taps in order: (ty, tx), ty = wave, wave + 4, ...; tx = 0 .. f - 1
+  const int nrows = wave < p.f ? (p.f - wave + 3) / 4 : 0, ntap = nrows * p.f;
+  auto load_tap = [&](int t, f32x4 (&a)[4], f32x4 (&b)[4], bool& ok) {
+    const int ty = wave + 4 * (t / p.f), tx = t % p.f;
+    const int Y = yc * p.f + ty - p.py, X = xc_l * p.f + tx - p.px;
+    ok = xc_l < p.wc && X >= 0 && X < p.W && Y >= 0 && Y < p.H;
+    const float* src = img + ((int64_t)(ok ? Y : 0) * p.W + (ok ? X : 0)) * p.lddy;
+    const int tap = ty * p.f + tx;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g < ng) {
-          const int ch = 8 * g + 4 * half;
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          if (v && ch < p.Cout) a = *reinterpret_cast<const f32x4*>(src + ch);
-          const f32x4 b = wl[(int64_t)(tap * ng + g) * 64];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-        }
-      }
+    for (int g = 0; g < 4; ++g) {
+      const int ch = min(8 * g + 4 * half, p.Cout - 4);     // (Cout % 4 == 0: checked by the caller)
+      a[g] = *reinterpret_cast<const f32x4*>(src + ch);
+      b[g] = wl[(int64_t)(tap * ng + min(g, ng - 1)) * 64];
     }
+  };
+  auto mfma_tap = [&](const f32x4 (&a)[4], const f32x4 (&b)[4], bool ok) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bool use = ok && g < ng && 8 * g + 4 * half < p.Cout;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(use ? a[g][j] : 0.f, b[g][j], acc, 0, 0, 0);
+    }
+  };
+  f32x4 a0[4], b0[4], a1[4], b1[4];
+  bool ok0 = false, ok1 = false;
+  if (ntap > 0) load_tap(0, a0, b0, ok0);
+  for (int t = 0; t < ntap; t += 2) {
+    load_tap(min(t + 1, ntap - 1), a1, b1, ok1);
+    mfma_tap(a0, b0, ok0);
+    load_tap(min(t + 2, ntap - 1), a0, b0, ok0);
+    mfma_tap(a1, b1, ok1 && t + 1 < ntap);
   }
-  if (col < p.Cin) {
+  // cross-wave sum in a fixed order
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+  __syncthreads();
+  if (wave == 0 && col < p.Cin) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int xc = x0 + 8 * (i >> 2) + 4 * half + (i & 3);
-      if (xc < p.wc) p.dx[(((int64_t)n * p.hc + yc) * p.wc + xc) * p.lddx + col] = p.alpha * acc[i];
+      const float s = ((red[0][i][lane] + red[1][i][lane]) + red[2][i][lane]) + red[3][i][lane];
+      if (xc < p.wc) p.dx[(((int64_t)n * p.hc + yc) * p.wc + xc) * p.lddx + col] = p.alpha * s;
     }
   }
 }
@@ -187,6 +209,8 @@ __global__ __launch_bounds__(256) void deconv_bwd_filter_mfma_kernel(DeconvParam
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // (measured and rejected: a flattened two-stage software pipeline over (row, eight-pixel step) - the index arithmetic per four MFMAs costs more than
+  // the exposed loads: 0.38 -> 0.52 ms per launch)
   for (int r = blockIdx.x * 4 + wave; r < rows; r += p.S * 4) {
     const int yc = r % p.hc, n = r / p.hc;
     const int Y = yc * p.f + ty - p.py;
@@ -270,8 +294,8 @@ int pcnn_deconv_bwd_data_mfma(pcnn_handle h, int N, int hc, int wc, int Cin, int
   p.N = N; p.hc = hc; p.wc = wc; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.f = f; p.py = (hc * f - H) / 2; p.px = (wc * f - W) / 2;
   p.dy = dy; p.lddy = lddy; p.wp = static_cast<const float*>(h->scratch); p.alpha = alpha; p.dx = dx; p.lddx = lddx;
   p.tiles_x = pcnn_cdiv(wc, 32);
-  const int64_t waves = (int64_t)N * hc * p.tiles_x;
-  hipLaunchKernelGGL(deconv_bwd_data_mfma_kernel, dim3((unsigned)pcnn_cdiv64(waves, 4)), dim3(256), 0, h->stream, p);
+  const int64_t groups = (int64_t)N * hc * p.tiles_x;            // one workgroup (four waves sharing the taps) per 32 coarse pixels of a row
+  hipLaunchKernelGGL(deconv_bwd_data_mfma_kernel, dim3((unsigned)groups), dim3(256), 0, h->stream, p);
   PCNN_CHECK_LAUNCH(h, "pcnn_deconv_bwd_data(mfma)");
   return 0;
 }
