@@ -843,7 +843,7 @@ void launch_inv64(pcnn_handle h, InvParams p, int ntile) {
   p.cpt = (dbg64() >> 2) & 3;
   // bit 2: every tensor the epilogue touches allows 16-byte accesses at channel offsets that are multiples of four
   auto al = [](const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
-  if (al(p.y, p.ldy) && al(p.act_out, p.ld_act) && al(p.res, p.ld_res) && (p.cstride & 3) == 0) p.cpt |= 4;
+  if (al(p.y, p.ldy) && al(p.act_out, p.ld_act) && al(p.res, p.ld_res) && al(p.gact, p.ld_gact) && al(p.y2, p.ld_y2) && (p.cstride & 3) == 0) p.cpt |= 4;
   const int vycap = std::min(p.Vy, p.Ho);                        // <= 56: checked by the caller (pick of the tile size)
   const int ntg = ntile * p.groups;
   const unsigned grid = (unsigned)std::min((2 * ((ntg + 7) & ~7) + 15) & ~15, 256);
