@@ -65,6 +65,31 @@ def test_conv_adjoint_identities_at_full_size(k, ci, co, mode, pad_mode):
         ops.set_math_mode(prev)
 
 
+@pytest.mark.parametrize('f', [8, 32, 128])
+def test_transposed_convolution_adjoint_identities_at_full_size(f):
+    """8 x 1024^2 x 32 channels, the merge of hpnn.json's bottleneck branches (blocks/bottleneck_block_deconvupsample -> layers/deconvupscale.py:100-106):
+    <deconv(x; K), g> = <x, deconv_bwd_data(g; K)> = <K, deconv_bwd_filter(x, g)> tie the three kernels of csrc/deconv_mfma.hip to each other at the size
+    where no oracle runs - factor 8 (many coarse pixels, few taps), 32 and 128 (an 8 x 8 coarse grid with 16 384 taps: the data gradient's four waves share the
+    taps) - and the accumulate mode of the forward (the branch merge: y <- beta y + alpha deconv) against its write mode."""
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(f)
+    N, H, C = 8, 1024, 32
+    hc = H // f
+    x = torch.randn(N, hc, hc, C, device='cuda', generator=g)
+    K = torch.randn(f, f, C, C, device='cuda', generator=g) * 0.1
+    gy = torch.randn(N, H, H, C, device='cuda', generator=g)
+    y = ops.deconv_fwd(x, K, None, (H, H), f)
+    dx = ops.deconv_bwd_data(gy, K, (hc, hc), f)
+    dK = ops.deconv_bwd_filter(x, gy, f)
+    a, b, c = dot64(y, gy), dot64(x, dx), dot64(K, dK)
+    scale = float(y.double().norm() * gy.double().norm())
+    assert abs(a - b) < 2e-6 * scale and abs(a - c) < 2e-6 * scale, (a, b, c)
+    acc = gy.clone()
+    ops.deconv_fwd(x, K, None, (H, H), f, alpha=0.5, beta=2.0, out=acc)
+    ref = 2.0 * gy.double() + 0.5 * y.double()
+    assert float((acc.double() - ref).norm() / ref.norm()) < 1e-6
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'split_f16'])
 def test_model_at_c4_size_sample_independence_and_train_step(mode):
     """hpnn.json at 8 x 1024^2 (bench workload c4; fp32 is the benchmarked library default, split_f16 the opt-in mode): every sample's solution is independent of its batch
