@@ -119,6 +119,16 @@ def test_model_at_c4_size_sample_independence_and_train_step(mode):
         assert np.isfinite(float(logs['loss'])) and np.isfinite(float(logs['mse']))
         assert torch.isfinite(model.store.flat_g).all() and float(model.store.flat_g.abs().max()) > 0
         assert torch.isfinite(model.store.flat_w).all() and not torch.equal(w0, model.store.flat_w)
+        # determinism: every reduction of the backward pass adds its partial sums in a fixed order (split-K weight gradients, the fused mixing kernel's
+        # tile sums, per-lane bias sums of the POST epilogues, the transposed convolution's cross-wave sums), also with one stream per bottleneck branch:
+        # two evaluations of the same step give bit-identical gradients
+        tgt = torch.randn((8, 1, 1024, 1024), generator=g).cuda() * 0.1
+        dxc = dx.reshape(8, -1)[:, :1].contiguous()
+        model._loss_and_grads(rhs, dxc, tgt)
+        g1 = model.store.flat_g.clone()
+        model._loss_and_grads(rhs, dxc, tgt)
+        torch.cuda.synchronize()
+        assert torch.equal(g1, model.store.flat_g)
     finally:
         ops.set_math_mode(prev)
 
