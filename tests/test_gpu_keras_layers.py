@@ -195,6 +195,37 @@ def test_narrow_resnet_stage_runs_as_one_launch(filters, act, hw):
         assert rel(g, res[False][2][n]) < 2e-6, n
 
 
+def test_fused_stage_refuses_what_it_does_not_cover():
+    """pcnn_resnet3_fwd is an optimisation with a narrow domain: outside it the library says so (and layers.resnet never asks: 12 channels, tanh, 5 x 5
+    filters, SYMMETRIC padding and BatchNormalization all take the three-launch chain)."""
+    from poisson_cnn_amd import _lib, ops
+    from poisson_cnn_amd.keras_layers import resnet
+    assert ops.resnet3_eligible(8, 'leaky_relu') and ops.resnet3_eligible(4, 'relu')
+    assert not ops.resnet3_eligible(12, 'leaky_relu') and not ops.resnet3_eligible(8, 'tanh') and not ops.resnet3_eligible(6, 'linear')
+    x = torch.randn(1, 9, 9, 12, device='cuda')
+    w = torch.randn(3, 3, 12, 12, device='cuda')
+    with pytest.raises(RuntimeError, match='eligible'):
+        ops.resnet3_fwd(x, w, None, w, None, w, None, act='leaky_relu', training=False)
+    rng = np.random.default_rng(0)
+    for kw in (dict(filters=12, kernel_size=3, activation='tf.nn.leaky_relu'), dict(filters=8, kernel_size=3, activation='tf.nn.tanh'),
+               dict(filters=8, kernel_size=5, activation='tf.nn.leaky_relu'), dict(filters=8, kernel_size=3, activation='tf.nn.leaky_relu', padding_mode='symmetric'),
+               dict(filters=8, kernel_size=3, activation='tf.nn.leaky_relu', use_batchnorm=True)):
+        kw.setdefault('padding_mode', 'constant')
+        blk = resnet(2, data_format='channels_first', seed=1, **kw)
+        calls = []
+        orig = _lib.Handle.call
+
+        def spy(self, name, *a):
+            calls.append(name)
+            return orig(self, name, *a)
+        _lib.Handle.call = spy
+        try:
+            blk(f32(rng.standard_normal((1, kw['filters'], 20, 33))))
+        finally:
+            _lib.Handle.call = orig
+        assert 'pcnn_resnet3_fwd' not in calls, kw
+
+
 def _oracle_bottleneck(ops_ns, p, x, *, f, up, k, n_convs, mode, val, act, method, pool, use_resnet, use_bn, kdown, kind, resize='bilinear'):
     """blocks/bottleneck_block.py:9-118 restated for every constructor path (conv / pool down-sampling, plain / resnet stages)."""
     H, W = x.shape[2], x.shape[3]
