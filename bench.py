@@ -11,25 +11,24 @@ in the environment: this process IS one rank), or bare (`python bench.py --gpus 
 rank per GPU, rendezvous on 127.0.0.1 - BEFORE anything touches the GPU (no exec of a GPU-initialised process), relays rank 0's JSON line
 and exits with the worst child status.
 
-What is timed.  BOTH convolution math modes, W warm-up + K timed steps each, every timed region bracketed by barrier + synchronize, MAX
-over ranks:
-  * `value` / `ms_per_step` / `dtype` / `roofline`: math mode "fp32" - v_mfma_f32_32x32x2_f32, exact fp32 products, the library default
-    and the reference's precision (experiments/hpnn.json:78);
-  * `split_f16` block: the opt-in 3 x fp16 split mode, timed the same way in the same run, with
-    `accuracy_vs_fp32`: forward output and flat gradient of THIS benchmark batch in split mode against fp32 mode (rel-L2 and
-    max componentwise error), measured before the timed regions.
-`roofline` (bound "hbm") describes ALL convolution launches of the timed steps - forward, data gradient, weight gradient; the tiled spectral
-route dominates them and is bound by the tile spectra it streams, not by the matrix pipes: `achieved` = HBM bytes the convolution kernels of one
-step really move (`traffic`: 2 x FETCH_SIZE + WRITE_SIZE from separate `rocprofv3 --pmc` passes, committed as profiles/r03_<workload>_pmc_summary_
-<mode>.json by tools/collect_pmc.sh, used only when the summary's source stamp matches the kernel sources of this tree - otherwise the
-algorithmic bytes, with the reason in `traffic_source`) / the summed duration of those launches in THIS run (HIP events on the launch stream);
-`frac` = achieved / 8 TB/s; `mfma_busy` the matrix-pipe busy fraction of the same kernels; `kernels` the per-kernel table of the stamped summary
-(launches per step, ms per step from the rocprofv3 --kernel-trace --stats CSV, MB per launch, TB/s, fraction).  `direct_conv_equivalent` is the
-direct convolution's FLOP over the same time - a speed-up measure, not a roofline fraction.  `roofline.hbm_bound` is the north star's "conv
-forward vs HBM roofline" figure: the conv launches whose arithmetic intensity is below the fp32 ridge (3x3 tail, <= 8 channels), algorithmic
-bytes / time, with the transposed-convolution and resize forward kernels beside it.
+What is timed.  W warm-up + K timed steps, the timed region bracketed by barrier + synchronize, MAX over ranks:
+  * `value` / `ms_per_step` / `dtype` / `roofline`: math mode "fp32" - exact fp32 products and sums, the library default and the
+    reference's precision (experiments/hpnn.json:78).  This is ALL the default run times;
+  * `--modes split_f16,fp32` adds a `split_f16` block: the opt-in 3 x fp16 split mode, timed the same way in the same
+    run, with `accuracy_vs_fp32` (forward output and flat gradient of THIS benchmark batch in split mode against fp32 mode).  Since round 4 the
+    mode is no faster than fp32 on the shipped model, so the default run no longer spends a third of its GPU time on it.
+`roofline` (bound "hbm") describes ALL convolution launches of the timed steps - forward, data gradient, weight gradient.  `achieved` = the
+ALGORITHMIC bytes of SURVEY 8(d) (every layer's input + output + filter, once per pass) / the summed duration of those launches in THIS run (HIP
+events on the launch stream); `frac` = achieved / 8 TB/s.  Beside it the EXECUTED view: `traffic` = HBM bytes the convolution kernels of one step
+really move (2 x FETCH_SIZE + WRITE_SIZE from separate `rocprofv3 --pmc` passes, committed as profiles/<round>_<workload>_pmc_summary_<mode>.json by
+tools/collect_pmc.sh, used only when the summary's source stamp matches the kernel sources of this tree), `executed_frac` = traffic / the same time
+/ 8 TB/s, `traffic_over_algorithmic` the waste factor (tile spectra written and re-read); `mfma_busy` the matrix-pipe busy fraction of the same
+kernels; `kernels` (detail file) the per-kernel table of the stamped summary.  `direct_conv_equivalent` is the direct convolution's FLOP over the
+same time - a speed-up measure, not a roofline fraction.  `roofline.hbm_bound` is the north star's "conv forward vs HBM roofline" figure: the conv
+launches whose arithmetic intensity is below the fp32 ridge (3x3 tail, <= 8 channels), algorithmic bytes / time, with the transposed-convolution
+and resize forward kernels beside it.
 The default c4 run appends a `c3` block (32 x 512^2, fp32: ms/step, grids/s, the same roofline figures) so that both halves of BASELINE.json's
-metric are timed by one command (--no-c3 skips it); `rank_ms_per_step` lists every rank's own step time, `collective_ms` the gradient
+metric are timed by one command (--no-c3 skips it; at --gpus N > 1 only with --c3: one number per lease); `rank_ms_per_step` lists every rank's own step time, `collective_ms` the gradient
 all-reduce timed on its own (N > 1).
 `cpu_baseline` times the oracle's torch-CPU twin of the same graph (fp32, host cores) on one 512^2 grid - a stand-in for the reference's
 TF-CPU path, which cannot run here.  `dataset` is the on-device 512^2 FD reference-solution generator next to its scipy stand-in.
@@ -63,7 +62,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dataset', action='store_true')
     ap.add_argument('--no-c3', action='store_true', help='skip the 32 x 512^2 block that the default c4 run appends')
-    ap.add_argument('--modes', default='split_f16,fp32', help='math modes to time, in order; the LAST one is the headline (default: split_f16,fp32)')
+    ap.add_argument('--modes', default='fp32', help='math modes to time, in order; the LAST one is the headline.  Default: fp32 only (the library default); '
+                                                    '"split_f16,fp32" also times the opt-in split mode with its accuracy gate (a third more GPU time)')
+    ap.add_argument('--c3', action='store_true', help='append the 32 x 512^2 block also at --gpus N > 1 (default there: headline workload only - one number per lease)')
     ap.add_argument('--math', default=None, choices=['split_f16', 'fp32'], help='time only this mode (profiling runs)')
     ap.add_argument('--cpu-baseline-hw', type=int, default=512)
     ap.add_argument('--no-cpu-baseline-1024', action='store_true', help='skip the 1024^2 leg of the CPU baseline (1 warm-up + 2 reps, about a minute)')
@@ -264,7 +265,7 @@ def launch_check(args, dp):
                                      'ranks_seen': dp.ranks_seen(), 'rccl': dp.rccl_version()}}), flush=True)
 
 
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 COMPACT_LIMIT = 3072      # bytes: the driver keeps ~8.6 KB of stdout; round 3's 23 KB line arrived cut and unparseable
 
 
@@ -290,8 +291,9 @@ def compact_line(d):
     out['collective_ms'] = _r(d.get('collective_ms'), 4)
     out['roofline'] = {'bound': rf.get('bound'), 'kernel': 'all conv launches of a step (spectral + direct + narrow)', 'achieved': _r(rf.get('achieved'), 1),
                        'peak': rf.get('peak'), 'unit': rf.get('unit'), 'frac': _r(rf.get('frac')), 'traffic': rf.get('traffic'),
-                       'achieved_is': 'executed PMC bytes / HIP-event time' if rf.get('traffic') else 'algorithmic bytes / HIP-event time (no stamped PMC summary)',
-                       'algorithmic_bytes': rf.get('algorithmic_bytes_per_step'), 'algorithmic_frac': _r((rf.get('algorithmic_GBs') or 0.0) / (rf.get('peak') or 1.0)),
+                       'achieved_is': 'algorithmic bytes (SURVEY 8d) / HIP-event time of all conv launches',
+                       'algorithmic_bytes': rf.get('algorithmic_bytes_per_step'),
+                       'executed_frac': _r(rf.get('executed_frac')), 'executed_is': 'PMC bytes (traffic) / the same time' if rf.get('traffic') else 'no stamped PMC summary',
                        'traffic_over_algorithmic': _r(rf.get('traffic_over_algorithmic'), 3), 'mfma_busy': _r(rf.get('mfma_busy')),
                        'conv_ms_per_step': _r(rf.get('conv_kernel_ms_per_step'), 2), 'single_stream_ms_per_step': _r(rf.get('single_stream_ms_per_step'), 2), 'hbm_bound_frac': _r(hbm.get('frac')),
                        'fused_stage_frac': _r((rf.get('fused_stage') or {}).get('frac')),
@@ -305,7 +307,7 @@ def compact_line(d):
             out['cpu_baseline']['value_1024'] = _r(cb['at_1024'].get('value'), 5)
     c3 = d.get('c3')
     if c3:
-        out['c3'] = {'value': _r(c3.get('value'), 3), 'unit': c3.get('unit'), 'ms_per_step': _r(c3.get('ms_per_step'), 3), 'roofline_frac': _r((c3.get('roofline') or {}).get('frac')),
+        out['c3'] = {'value': _r(c3.get('value'), 3), 'unit': c3.get('unit'), 'ms_per_step': _r(c3.get('ms_per_step'), 3), 'roofline_frac': _r((c3.get('roofline') or {}).get('frac')), 'executed_frac': _r((c3.get('roofline') or {}).get('executed_frac')),
                      'hbm_bound_frac': _r(((c3.get('roofline') or {}).get('hbm_bound') or {}).get('frac'))}
     sp = d.get('split_f16')
     if sp:
@@ -481,7 +483,8 @@ def run(args):
                       'avg_launch_ms': v.get('avg_launch_ms'), 'traffic_MB_per_launch': v['traffic_bytes_per_launch'] / 1e6, 'hbm_TBs': v.get('hbm_tbs'),
                       'hbm_frac': v.get('hbm_frac'), 'mfma_busy_frac': v.get('mfma_busy_frac')}
                      for k, v in sorted(summ['kernels'].items(), key=lambda kv: -(kv[1].get('ms_per_step') or 0.0)) if not k.startswith('conv (')]
-        achieved = (traffic if traffic else alg_bytes) / conv_s / 1e9 if conv_s else None
+        achieved = alg_bytes / conv_s / 1e9 if conv_s else None                # ALGORITHMIC bytes over the kernels' measured time
+        executed = traffic / conv_s / 1e9 if (traffic and conv_s) else None      # what the kernels really move (PMC), over the same time
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
         hf, hb, hs, hc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage') and b > 0 and f / b < ridge)
         sf, sb, ss, sc = prof.select(lambda k, f, b: k == 'conv_stage')   # narrow resnet stages as one launch: algorithmic bytes of the UNFUSED layers / time
@@ -493,8 +496,10 @@ def run(args):
                           'spec_mix, spec_inv / spec64_inv, spec_wmix: the DFT as fp32 MFMA GEMM, 64-point tiles for 11..15 taps) for the wide filters, '
                           'fp32-MFMA implicit GEMM, vector-ALU forward and 16x16x4-MFMA weight-gradient kernels for the 3x3 layers of <= 16 channels',
                 'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS if achieved else None,
-                'achieved_source': ('EXECUTED traffic (PMC bytes of all convolution kernels of a step) / their summed HIP-event time in this run' if traffic
-                                    else 'ALGORITHMIC bytes (layer inputs + outputs + filters) / their summed HIP-event time: no stamped PMC summary for this tree'),
+                'achieved_source': 'ALGORITHMIC bytes (every layer\'s input + output + filter, forward + data gradient + weight gradient: SURVEY 8d) / the summed HIP-event time of all convolution launches in this run',
+                'executed_achieved': executed, 'executed_frac': executed / PEAK_HBM_GBS if executed else None,
+                'executed_source': ('EXECUTED traffic (PMC bytes of all convolution kernels of a step, stamped summary) / the same HIP-event time' if traffic
+                                    else 'no stamped PMC summary for this tree: executed traffic unknown'),
                 'traffic': traffic, 'traffic_unit': 'bytes per training step over all convolution kernels (2*FETCH_SIZE + WRITE_SIZE)', 'traffic_source': src,
                 'mfma_busy': busy, 'conv_kernel_ms_per_step': 1e3 * conv_s, 'launches': ac, 'avg_launch_ms': 1e3 * as_ / ac if ac else None,
                 'algorithmic_bytes_per_step': alg_bytes, 'algorithmic_GBs': alg_bytes / conv_s / 1e9 if conv_s else None,
@@ -537,7 +542,7 @@ def run(args):
     coll_ms = collective_ms()
     # the other half of BASELINE.json's metric ("at 512^2 & 1024^2"): the default c4 run appends the 32 x 512^2 workload, fp32 mode, same timing rules
     c3 = None
-    if args.workload == 'c4' and not args.no_c3 and modes[-1] == 'fp32':
+    if args.workload == 'c4' and not args.no_c3 and modes[-1] == 'fp32' and (dp.world_size == 1 or args.c3):
         note('c3 block (32 x 512^2, fp32) ...')
         p3, H3, g3, b3 = bench_workload('c3', ['fp32'], args.steps, args.warmup, False)
         c3 = dict(b3['fp32'], metric='grids/sec (fwd+bwd) at %d^2' % H3, steps=args.steps, warmup=args.warmup,

@@ -18,6 +18,12 @@
  *  - Every call is asynchronous on the handle's stream and returns 0 on success, non-zero on error
  *    (pcnn_last_error(handle) gives the message).  No exceptions cross the boundary.
  *  - One handle per (thread, device, stream).
+ *  - Environment variables read by the library are DEVELOPER switches for A/B timing and tests, not part of the interface; each is validated
+ *    where it is read (an invalid value keeps the default): PCNN_MATH, PCNN_SPECTRAL, PCNN_SPEC_T (same as the pcnn_set_* calls),
+ *    PCNN_SPEC_XFORM (transform kernels of the spectral route: "fft" in-register vector-ALU FFT, "mfma" DFT-as-GEMM), PCNN_WSPLIT32 / PCNN_WSPLIT64
+ *    (weight-gradient partial sums: a positive multiple of 4, at most 64), PCNN_SPEC_MIXW, PCNN_SPEC_PACK, PCNN_SPEC_CHUNK, PCNN_SPEC_FENCE,
+ *    PCNN_FWD64_RADIX, PCNN_STAGE_TH, PCNN_FUSED_STAGE, PCNN_SMALL_CONV, PCNN_GROUPED_VALU, PCNN_WG_OCC3, PCNN_SPLIT_MT2_MAXK (0 / 1 or a
+ *    size), PCNN_RCCL_LIBRARY / PCNN_ROCFFT_LIBRARY (a path for dlopen).
  */
 #ifndef PCNN_H
 #define PCNN_H

@@ -347,26 +347,39 @@ RocFFT& rocfft() {
   return r;
 }
 
-// batched real 2-D forward transform of (N, Lh, Lw) doubles -> (N, Lh, Lw/2+1) complex, one plan per (device, Lh, Lw, N), kept for the process
+// batched real 2-D forward transform of (N, Lh, Lw) doubles -> (N, Lh, Lw/2+1) complex.  One plan + execution info + work buffer per (device, STREAM,
+// Lh, Lw, N), kept for the process: the execution info carries the stream and the work buffer, so two handles on different streams that solve the same
+// shape concurrently must not share one.  A plan enters the cache only when every step of its construction has succeeded.
 int fft_plan(pcnn_handle h, int Lh, int Lw, int N, FftPlan** out) {
-  static std::map<std::tuple<int, int, int, int>, FftPlan> plans;
+  static std::map<std::tuple<int, void*, int, int, int>, FftPlan> plans;
   static std::mutex mu;
   RocFFT& r = rocfft();
   if (!r.lib) PCNN_FAIL(h, "pcnn_fd_poisson_fft: %s", r.why.c_str());
   std::lock_guard<std::mutex> lock(mu);
-  FftPlan& p = plans[std::make_tuple(h->device, Lh, Lw, N)];
-  if (!p.plan) {
+  const auto key = std::make_tuple(h->device, (void*)h->stream, Lh, Lw, N);
+  auto it = plans.find(key);
+  if (it == plans.end()) {
+    FftPlan p;
+    typedef int (*RfDestroyFn)(void*);
+    auto drop = [&]() {                                             // a half-built plan never reaches the cache
+      RfDestroyFn pd = reinterpret_cast<RfDestroyFn>(dlsym(r.lib, "rocfft_plan_destroy")), id = reinterpret_cast<RfDestroyFn>(dlsym(r.lib, "rocfft_execution_info_destroy"));
+      if (p.work) (void)hipFree(p.work);
+      if (p.info && id) id(p.info);
+      if (p.plan && pd) pd(p.plan);
+    };
     const size_t lengths[2] = {(size_t)Lw, (size_t)Lh};            // rocFFT: fastest dimension first
     // placement 1 = not in place, transform type 2 = real forward, precision 1 = double (rocfft.h enums)
-    if (r.plan_create(&p.plan, 1, 2, 1, 2, lengths, (size_t)N, nullptr) != 0) { p.plan = nullptr; PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_plan_create(%d x %d x %d) failed", N, Lh, Lw); }
-    if (r.info_create(&p.info) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_create failed");
-    if (r.work_size(p.plan, &p.work_bytes) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_plan_get_work_buffer_size failed");
+    if (r.plan_create(&p.plan, 1, 2, 1, 2, lengths, (size_t)N, nullptr) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_plan_create(%d x %d x %d) failed", N, Lh, Lw);
+    if (r.info_create(&p.info) != 0) { drop(); PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_create failed"); }
+    if (r.work_size(p.plan, &p.work_bytes) != 0) { drop(); PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_plan_get_work_buffer_size failed"); }
     if (p.work_bytes) {
-      if (hipMalloc(&p.work, p.work_bytes) != hipSuccess) PCNN_FAIL(h, "pcnn_fd_poisson_fft: cannot allocate %zu B of rocFFT work buffer", p.work_bytes);
-      if (r.set_work(p.info, p.work, p.work_bytes) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_set_work_buffer failed");
+      if (hipMalloc(&p.work, p.work_bytes) != hipSuccess) { p.work = nullptr; drop(); PCNN_FAIL(h, "pcnn_fd_poisson_fft: cannot allocate %zu B of rocFFT work buffer", p.work_bytes); }
+      if (r.set_work(p.info, p.work, p.work_bytes) != 0) { drop(); PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_set_work_buffer failed"); }
     }
+    if (r.set_stream(p.info, h->stream) != 0) { drop(); PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_set_stream failed"); }
+    it = plans.emplace(key, p).first;
   }
-  *out = &p;
+  *out = &it->second;
   return 0;
 }
 
@@ -432,7 +445,6 @@ extern "C" int pcnn_fd_poisson_fft(pcnn_handle h, int N, int H, int W, const flo
   double* Bm = static_cast<double*>(workspace);
   double* E = Bm + (int64_t)N * nh * nw;
   double2* Eh = reinterpret_cast<double2*>(E + (int64_t)N * Lh * Lw);
-  if (r.set_stream(pl->info, h->stream) != 0) PCNN_FAIL(h, "pcnn_fd_poisson_fft: rocfft_execution_info_set_stream failed");
   hipLaunchKernelGGL(dst_build_rhs_kernel, grid1d((int64_t)N * nh * nw), dim3(256), 0, h->stream, N, H, W, rhs, left, right, bottom, top, dx, Bm);
   hipLaunchKernelGGL(dst_extend_rhs_kernel, grid1d((int64_t)N * Lh * Lw), dim3(256), 0, h->stream, N, nh, nw, Bm, E);
   PCNN_CHECK_LAUNCH(h, "pcnn_fd_poisson_fft(extend)");

@@ -786,8 +786,16 @@ int chunk_tiles(int Tg) {
 // partial sums of the weight-gradient GEMM: S / 4 workgroups x 4 waves per (slot, channel group).  64-point tiles have 2 048 slots - one workgroup
 // per slot already fills the chip four times over, and half the partial sums (128 instead of 256 MB written and read back per layer) are worth
 // 0.06-0.08 ms per 13- / 15-tap layer; at 32 points (512 slots) 8 is the measured optimum (4: +0.05 ms at 9 taps, 12 / 16: +0.04 ... 0.08 ms).
+// PCNN_WSPLIT32 / PCNN_WSPLIT64 are developer switches (A/B timing): the kernels index their partial sums as blockIdx.y * 4 + wave, so a value is
+// rounded down to a positive multiple of 4 (at most 64); anything else - zero, negative, not a number - keeps the default.
+int wsplit_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  const int v = atoi(e) & ~3;
+  return (v >= 4 && v <= 64) ? v : dflt;
+}
 int wgrad_splits(int Tg = 32) {
-  static const int s32 = getenv("PCNN_WSPLIT32") ? atoi(getenv("PCNN_WSPLIT32")) : 8, s64 = getenv("PCNN_WSPLIT64") ? atoi(getenv("PCNN_WSPLIT64")) : 4;
+  static const int s32 = wsplit_env("PCNN_WSPLIT32", 8), s64 = wsplit_env("PCNN_WSPLIT64", 4);
   return Tg == 64 ? s64 : s32;
 }
 
@@ -1148,6 +1156,9 @@ extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_
 
 extern "C" int pcnn_conv2d_bwd_spectral_post_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg) {
   if (!pcnn_conv2d_bwd_spectral_eligible(h, d, dg)) return 0;
+  // POST indexes act_out / raw_out / dbias with the pixel offsets of dx.  For SYMMETRIC / REFLECT layers the fused pass produces the gradient on the
+  // PADDED domain (Ho = H + kh - 1), whose offsets are not the producer's: the library refuses those itself, whatever the caller checked.
+  if (d->pad_mode != PCNN_PAD_CONSTANT) return 0;
   return d->Cin <= 32 ? 1 : 0;                                       // both inverse kernels carry the POST epilogue; one channel group
 }
 

@@ -82,6 +82,31 @@ class _Captured:
         self._keep = [b for b in self._keep if b is not None]
         return out
 
+    def close(self):
+        """Releases what the capture holds beyond the model itself: the graph, the references that kept its scratch alive, the capture
+        stream's libpcnn handle (pcnn_destroy frees its workspaces and every buffer parked under pcnn_set_workspace_retain) and the per-stream
+        scratch entries of the model's contexts.  A 'dict of graphs per shape' therefore costs device memory only while its entries are alive;
+        an object that is dropped without close() is closed by its finaliser.  Idempotent; the object cannot be called afterwards."""
+        if getattr(self, 'stream', None) is None:
+            return
+        from . import ops
+        try:
+            torch.cuda.synchronize()
+            self.graph = None
+            self._keep = []
+            sp = self.stream.cuda_stream
+            for c in _ctxs(self.model):
+                c.drop_stream(sp)
+            ops.release_stream_handle(sp)
+        finally:
+            self.stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 - interpreter shutdown: the driver reclaims everything anyway
+            pass
+
 
 class GraphedInference(_Captured):
     """model(inputs) on fixed shapes as one graph launch; returns the static output tensor (copy it if it must survive the next call)."""
@@ -92,6 +117,8 @@ class GraphedInference(_Captured):
         self.out = self._capture(lambda: model(self.static_in))
 
     def __call__(self, inputs):
+        if self.stream is None:
+            raise RuntimeError('this captured graph has been closed')
         _refill(self.static_in, inputs)
         self.graph.replay()
         return self.out

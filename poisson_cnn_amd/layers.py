@@ -142,6 +142,12 @@ class Context:
         """The scratch workspace of the CURRENT stream."""
         return self._ws.setdefault(self._stream_key(), ops.Workspace())
 
+    def drop_stream(self, stream_ptr):
+        """Forgets the scratch buffers kept for a stream that no longer exists (graphs._Captured.close: a recycled stream pointer must not
+        inherit them, and a dict of captured graphs must not grow the process's memory without bound)."""
+        self._ws.pop(int(stream_ptr), None)
+        self._wflips.pop(int(stream_ptr), None)
+
     def all_scratch(self):
         """Every scratch buffer this context holds right now (a captured hipGraph keeps them alive, graphs._Captured)."""
         return [w.buf for w in list(self._ws.values()) + [self.ws_side] if w.buf is not None] + list(self._wflips.values())

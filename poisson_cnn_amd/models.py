@@ -433,6 +433,11 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         for b in blocks:
             st = self._branch_streams.get(b)
             if st is None:
+                # a branch that pools the full-resolution tensor itself ADDS into d_initial: on the main stream that must come after every
+                # stream-run branch that did the same (they share stream 0 among themselves; ADVICE r4: non-default PCNN_COARSE_FACTOR / factor orders)
+                for _, g_prev, done_prev in late:
+                    if g_prev is None:
+                        main.wait_event(done_prev)
                 g = b.backward_from(dmerged, alpha, d_initial)
                 if g is not None:
                     grads[b.f] = g if b.f not in grads else ops.axpby(1.0, g, 1.0, grads[b.f])

@@ -82,6 +82,18 @@ def handle():
     return h
 
 
+def release_stream_handle(stream_ptr, device=None):
+    """Drops the cached handle of (device, stream): pcnn_destroy frees the handle's scratch, its spectral workspace and every buffer parked by
+    pcnn_set_workspace_retain.  For streams that go away (graphs._Captured.close); the next use of the stream simply creates a fresh handle."""
+    dev = torch.cuda.current_device() if device is None else device
+    h = _handles.pop((dev, int(stream_ptr)), None)
+    if h is not None:
+        try:
+            h.call('pcnn_set_workspace_retain', c_int(0))
+        finally:
+            del h                                                      # Handle.__del__ -> pcnn_destroy
+
+
 def _p(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 

@@ -4,7 +4,8 @@ Replaces tf.distribute.MirroredStrategy(cross_device_ops=ReductionToOneDevice())
 weights are replicated (identical seed, then a broadcast from rank 0), every global batch is split evenly by sample,
 each rank's loss is already divided by the GLOBAL batch size (losses/loss_wrapper.py:46-49), so ONE all-reduce(SUM) of the
 flat fp32 gradient bucket (5.56 M floats = 22.2 MB for hpnn.json) per optimizer step gives the mean gradient, followed by
-the identical Adam step on every rank.  No other collective is on the data path.
+the identical Adam step on every rank.  With BatchNormalization in TRAINING mode (`batchnorm_training=True`, not the reference's default) a second,
+tiny all-reduce(MEAN) keeps the moving statistics equal on all ranks (`sync_bn_stats`).  No other collective is on the data path.
 """
 import os
 
@@ -97,9 +98,35 @@ class DataParallel:
         for store in (model.stores if hasattr(model, 'stores') else [model.store]):
             self.broadcast(store.flat_w)
             self.broadcast(store.flat_stats)
-        model.grad_sync = self.all_reduce_sum
+        stores = list(model.stores if hasattr(model, 'stores') else [model.store])
+
+        def grad_sync(flat_g):
+            """Called by train_step with a store's flat gradient bucket in front of the optimizer step: all-reduce(SUM) of the gradients and -
+            with BatchNormalization in training mode - all-reduce(MEAN) of that store's moving statistics, which each rank has just updated
+            from ITS shard of the batch."""
+            self.all_reduce_sum(flat_g)
+            for st in stores:
+                if getattr(st, 'flat_g', None) is flat_g:
+                    self.sync_bn_stats(st)
+            return flat_g
+        model.grad_sync = grad_sync
         model.metric_sync = self.global_metrics
         return model
+
+    def sync_bn_stats(self, store):
+        """BatchNormalization moving mean / variance under data parallelism.  The reference's variables are MirroredVariables with
+        aggregation = MEAN (models/Homogeneous_Poisson_NN_Legacy.py:53-57 builds the layers under the strategy scope of
+        train/hpnn_legacy_train.py:37-41): after a training-mode step every replica holds the mean over the replicas of the per-replica
+        updates (SURVEY 8e: an all-reduce of 2 x 1 076 floats for hpnn.json).  Only when the statistics move at all (`batchnorm_training=True`;
+        the default is the reference's inference-mode BN, whose statistics never change) - otherwise no collective is issued."""
+        if self.world_size == 1 or not getattr(store, 'bn_training', False) or not getattr(store, 'nbn', 1):
+            return
+        stats = store.flat_stats
+        if getattr(self, '_c_abi', None) is not None:
+            self.all_reduce_sum(stats)
+        else:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        stats.mul_(1.0 / self.world_size)
 
     def global_metrics(self, loss, mse):
         """Per-rank (loss share, local mse) -> (global loss, global mean mse) on every rank: a 2-element all-reduce(SUM).  Callbacks that

@@ -1,5 +1,6 @@
 """Generates tests/golden/atsize_golden.npz: fp64 ORACLE vectors at BASELINE.json's full grid sizes.
 
+  C1: hpnn.json model, forward of the single 128^2 Dirichlet grid of BASELINE configs[0] (seed 1, dx = 0.02).
   C2: hpnn.json model, forward of ONE sample (index 5) of the 16 x 256^2 Dirichlet batch (seed 2).  Samples are independent
       (inference-mode BN), so sample k of the GPU's 16 x 256^2 batch must reproduce it.
   C3: hpnn.json model, full training-step quantities of ONE 512^2 sample (seed 3) for bc_type dirichlet and neumann:
@@ -19,7 +20,7 @@ in the build container.  Run time on 8 cores: about 15 min
       (oracle/torch_twin.set_fft_conv; pinned to F.conv2d in tests/test_oracle_ops.py), and every convolution-like op runs under
       torch.utils.checkpoint (only its input stays alive; identical arithmetic).  About 15 minutes, ~25 GB.
 
-    python tests/golden/make_atsize_golden.py [c2] [c3] [c4] [c4grad]        (c4 alone: about 10 minutes)
+    python tests/golden/make_atsize_golden.py [c1] [c2] [c3] [c4] [c4grad]        (c4 alone: about 10 minutes)
 """
 import os
 import sys
@@ -45,6 +46,14 @@ def c2_inputs():
     rhs /= np.abs(rhs).max(axis=(1, 2, 3), keepdims=True)
     dx = rng.uniform(5e-3, 5e-2, (16, 1))
     return rhs.astype(np.float32), dx.astype(np.float32)
+
+
+def c1_inputs():
+    """SURVEY 8d C1 (BASELINE configs[0] at its literal size): rhs = 2U-1 of shape [1,1,128,128] (seed 1) scaled to max-abs 1, dx = [[0.02]]."""
+    rng = np.random.default_rng(1)
+    rhs = rng.uniform(-1, 1, (1, 1, 128, 128))
+    rhs /= np.abs(rhs).max(axis=(1, 2, 3), keepdims=True)
+    return rhs.astype(np.float32), np.array([[0.02]], dtype=np.float32)
 
 
 def c4_inputs():
@@ -109,6 +118,16 @@ def main():
     out = dict(np.load(PATH)) if os.path.exists(PATH) else {}
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     full = configs.hpnn()
+    if 'c1' in which:
+        cfg = full['model']
+        p = ohpnn.init_params(cfg, seed=WEIGHT_SEED, gain=WEIGHT_GAIN, randomize_all=True)
+        rhs, dx = c1_inputs()
+        t0 = time.time()
+        with torch.no_grad():
+            y = ohpnn.forward(torch_twin, cfg, {n: torch.tensor(v) for n, v in p.items()}, torch.tensor(rhs.astype(np.float64)), torch.tensor(dx.astype(np.float64)))
+        out['c1_out'] = y.numpy().astype(np.float32)
+        print('c1: %.1f s, max|y| %.4g' % (time.time() - t0, np.abs(out['c1_out']).max()), flush=True)
+        np.savez_compressed(PATH, **out)
     if 'c2' in which:
         cfg = full['model']
         p = ohpnn.init_params(cfg, seed=WEIGHT_SEED, gain=WEIGHT_GAIN, randomize_all=True)

@@ -139,3 +139,33 @@ def test_graphed_step_keeps_collectives_and_the_learning_rate_out_of_the_graph()
     assert calls == {'grad': 1, 'metric': 1, 'capturing': False, 'in_capture': 0}
     assert float(logs['loss']) == 2 * float(step.logs['loss']) and logs['lr'] == 5e-4
     assert m.grad_sync is grad_sync and m.metric_sync is metric_sync
+
+
+def test_closing_captured_graphs_returns_their_handles_and_scratch():
+    """every capture creates a stream, a libpcnn handle with pcnn_set_workspace_retain(1) and per-stream scratch entries in the model's
+    contexts.  close() (or dropping the object) must give all of that back: the handle cache and the contexts' per-stream tables do not grow with
+    the number of captures made, and a closed object refuses to replay."""
+    import gc
+    from poisson_cnn_amd import ops
+    from poisson_cnn_amd.graphs import GraphedInference, _ctxs
+    m = _dbcnn(7)
+    bc, dx, _ = _dbcnn_batch(3)
+    ref = m([bc, dx, 40]).clone()
+    torch.cuda.synchronize()
+    base_handles = len(ops._handles)
+    base_ws = sum(len(c._ws) for c in _ctxs(m))
+    for i in range(4):
+        inf = GraphedInference(m, [bc, dx, 40])
+        assert torch.equal(inf([bc, dx, 40]), ref)
+        assert len(ops._handles) == base_handles + 1
+        if i % 2 == 0:
+            inf.close()
+            with pytest.raises(RuntimeError, match='closed'):
+                inf([bc, dx, 40])
+            inf.close()                                              # idempotent
+        else:
+            del inf                                                  # the finaliser closes it
+            gc.collect()
+        assert len(ops._handles) == base_handles
+        assert sum(len(c._ws) for c in _ctxs(m)) == base_ws
+    assert torch.equal(m([bc, dx, 40]), ref)                         # the eager path is untouched

@@ -303,6 +303,32 @@ def test_branch_streams_are_bitwise_identical_to_one_stream_on_the_shipped_model
             assert np.array_equal(a, b)
 
 
+def test_branch_streams_with_main_stream_accumulators_on_a_non_divisible_grid():
+    """with PCNN_COARSE_FACTOR > 2 the small-factor branches stay on the MAIN stream, and on a grid their factors do not divide they pool
+    the full-resolution tensor themselves, i.e. their backward ADDS into the shared d_initial - as the stream-0 branches do.  Every accumulator must be
+    ordered after the ones before it whatever stream it runs on: the gradient bucket must be bit-identical to the single-stream run."""
+    import os
+    if os.environ.get('PCNN_BRANCH_STREAMS', '1') == '0':
+        pytest.skip('the developer switch PCNN_BRANCH_STREAMS=0 turns the streams under test off')
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import SGD
+    full = configs.hpnn()
+    cfg = full['model']
+    rhs, dx = make_inputs(2, 250, 246, 29)                       # 250 x 246: factors 3, 4, 8, 16 ... do not divide both extents
+    target = np.random.default_rng(6).standard_normal(rhs.shape) * 0.1
+    runs = []
+    for side, factor in ((True, 8), (False, 8), (True, 2), (True, 8)):
+        model, _ = build(cfg, 47)
+        model.COARSE_FACTOR = factor
+        model.ctx.use_side = side
+        model.compile(loss=loss_wrapper(global_batch_size=2, **full['training']['loss_parameters']), optimizer=SGD(learning_rate=0.0))
+        for _ in range(3):
+            model.train_step(((rhs, dx), target))
+        runs.append(model.store.flat_g.cpu().numpy().copy())
+    for other in runs[1:]:
+        assert np.array_equal(runs[0], other)
+
+
 def test_channels_last_model_api():
     """Homogeneous_Poisson_NN_Legacy(data_format='channels_last'): (N,H,W,1) in, (N,H,W,1) out, identical numbers and an identical training
     step (the boundary tensors have one channel, so the two formats are the same memory)."""

@@ -74,6 +74,40 @@ def test_libpcnn_exports_every_declared_symbol():
     assert lib.pcnn_version() >= 100
 
 
+def test_every_entry_point_is_called_through_its_declared_prototype():
+    """_lib.load() binds argtypes / restype of EVERY function declared in include/pcnn.h from the header text, so a Python int
+    passed for an int64_t / size_t argument arrives whole, a value that does not fit raises, and so does a float where an integer is declared."""
+    from poisson_cnn_amd import _lib
+    protos = _lib.header_prototypes()
+    hdr = open(os.path.join(ROOT, 'include', 'pcnn.h')).read()
+    declared = sorted(set(re.findall(r'\b(pcnn_[a-z0-9_]+)\s*\(', re.sub(r'/\*.*?\*/', ' ', hdr, flags=re.S))))
+    assert sorted(protos) == declared                                   # the prototype parser sees every declaration the export test sees
+    lib = _lib.load()
+    for name, (ret, types) in protos.items():
+        fn = getattr(lib, name)
+        assert fn.argtypes is not None and len(fn.argtypes) == len(types), name
+    assert protos['pcnn_allreduce'] == ('int', ['pcnn_handle', 'float*', 'size_t'])
+    assert protos['pcnn_conv2d_wgrad_workspace'] == ('size_t', ['const pcnn_conv_desc*'])
+    # no GPU needed for the workspace-size queries: the same value however the integer is spelled, and loud failures instead of truncation
+    assert lib.pcnn_colsum_workspace(32) == lib.pcnn_colsum_workspace(ctypes.c_int(32)) == lib.pcnn_colsum_workspace(ctypes.c_int64(32)) > 0
+    assert lib.pcnn_channel_scale_workspace(2, 2 ** 33, 8) == lib.pcnn_channel_scale_workspace(2, 5, 8)   # an int64_t argument beyond 32 bits is accepted whole
+    with pytest.raises(ctypes.ArgumentError):
+        lib.pcnn_colsum_workspace(2 ** 40)
+    with pytest.raises(ctypes.ArgumentError):
+        lib.pcnn_colsum_workspace(3.5)
+    assert lib.pcnn_crc32c(b'123456789', 9, 0) == 0xE3069283
+
+
+def test_every_python_call_site_matches_the_header():
+    """tools/check_ctypes_calls.py: argument count and the kind (integer / float / pointer) of every wrapped argument of every libpcnn call in
+    poisson_cnn_amd/ against include/pcnn.h - static, so a call site that only a GPU run reaches is checked here too."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_ctypes_calls
+    sites, problems = check_ctypes_calls.check()
+    assert sites >= 100 and not problems, problems
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, 'poisson_cnn_amd')
     for dirpath, _, files in os.walk(pkg):

@@ -131,6 +131,46 @@ def test_resize_bicubic_properties():
     assert np.allclose(M2 @ np.arange(5.0), ref, atol=1e-5)
 
 
+def test_bicubic_and_bilinear_vs_pil():
+    """Third-party cross-check of the ASSUMED tf.image.resize (half-pixel, antialias=False) semantics (VERDICT r4 missing #2): Pillow's up-sampling
+    filters are independent code for the same definition - Keys a = -0.5 cubic / triangle, half-pixel centres, out-of-range taps dropped and the
+    weights renormalised.  Dyadic ratios (every up-sampling factor of hpnn.json: the branch outputs are 8 -> 1024 ... 512 -> 1024) agree to float32
+    rounding; at a non-dyadic ratio TensorFlow's 1024-entry coefficient table quantises the phase (|delta error| <= 2^-11 -> ~7e-4 in the values),
+    which Pillow's exact evaluation does not share - hence the looser bound there."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for n_in, n_out, tol in [(8, 256, 1e-6), (16, 512, 1e-6), (32, 1024, 1e-6), (64, 128, 1e-6), (11, 350, 2e-3), (9, 31, 2e-3)]:
+        x = rng.standard_normal((n_in, n_in + 3)).astype(np.float32)
+        My, Mx = np_ops.resize_matrix(n_in, n_out, 'bicubic'), np_ops.resize_matrix(n_in + 3, 2 * n_out, 'bicubic')
+        pil = np.asarray(Image.fromarray(x, mode='F').resize((2 * n_out, n_out), Image.BICUBIC), dtype=np.float64)      # PIL size = (width, height)
+        assert rel(My @ x.astype(np.float64) @ Mx.T, pil) < (tol if (2 * n_out) % (n_in + 3) == 0 else 2e-3), (n_in, n_out)
+        Ms = np_ops.resize_matrix(n_in, n_out, 'bicubic')
+        xs = rng.standard_normal((n_in, n_in)).astype(np.float32)
+        pil = np.asarray(Image.fromarray(xs, mode='F').resize((n_out, n_out), Image.BICUBIC), dtype=np.float64)
+        assert rel(Ms @ xs.astype(np.float64) @ Ms.T, pil) < tol, (n_in, n_out)
+        Mb = np_ops.resize_matrix(n_in, n_out, 'bilinear')
+        pil = np.asarray(Image.fromarray(xs, mode='F').resize((n_out, n_out), Image.BILINEAR), dtype=np.float64)
+        assert rel(Mb @ xs.astype(np.float64) @ Mb.T, pil) < 1e-6, (n_in, n_out)
+    # through the public op (NCHW), one dyadic case
+    x4 = rng.standard_normal((1, 1, 16, 16)).astype(np.float32)
+    pil = np.asarray(Image.fromarray(x4[0, 0], mode='F').resize((128, 128), Image.BICUBIC), dtype=np.float64)
+    assert rel(np_ops.resize2d(x4.astype(np.float64), (128, 128), 'bicubic')[0, 0], pil) < 1e-6
+
+
+def test_padded_conv_vs_scipy_ndimage():
+    """Third-party cross-check of tf.pad SYMMETRIC / REFLECT / CONSTANT + VALID correlation (H1 / H2): scipy.ndimage.correlate implements the same
+    three boundary rules under its own names (half-sample symmetric = 'reflect', whole-sample symmetric = 'mirror', 'constant') in independent C code."""
+    from scipy import ndimage
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 1, 13, 17))
+    for k in (3, 5, 7):
+        w = rng.standard_normal((k, k, 1, 1))
+        for tf_mode, sp_mode in (('SYMMETRIC', 'reflect'), ('REFLECT', 'mirror'), ('CONSTANT', 'constant')):
+            got = np_ops.padded_conv2d(x, w, None, tf_mode, 0.0, 'linear')
+            ref = ndimage.correlate(x[0, 0], w[:, :, 0, 0], mode=sp_mode, cval=0.0)
+            assert got.shape == x.shape and rel(got[0, 0], ref) < 1e-13, (k, tf_mode)
+
+
 def test_spp_and_split_indices():
     assert list(np_ops.split_indices(229, 4)) == [0, 58, 115, 172, 229]      # dataset/utils/split_indices.py:13
     rng = np.random.default_rng(2)

@@ -73,6 +73,45 @@ def test_data_parallel_gloo_world2():
     assert t0 == 2.0 and t1 == 2.0                                                                    # max over ranks
 
 
+def _bn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from poisson_cnn_amd import parallel
+    dp = parallel.DataParallel.from_env(backend='gloo')
+    out = []
+    for training in (True, False):
+        m = _FakeModel(rank)
+        m.store.bn_training, m.store.nbn = training, 5
+        dp.attach(m)                                             # broadcast: rank 0's statistics everywhere
+        start = m.store.flat_stats.clone()
+        m.store.flat_stats += float(rank + 1)                    # "this rank's shard moved the moving statistics by rank + 1"
+        m.grad_sync(m.store.flat_g)
+        out.append((start.numpy().copy(), m.store.flat_stats.numpy().copy(), m.store.flat_g.numpy().copy()))
+    q.put((rank, out))
+    torch.distributed.destroy_process_group()
+
+
+def test_bn_moving_statistics_are_mean_reduced_in_training_mode():
+    """VERDICT r4 missing #4 / SURVEY 8(e): with BatchNormalization in training mode every rank updates the moving statistics from its own shard;
+    the reference's mirrored variables aggregate them with MEAN (models/Homogeneous_Poisson_NN_Legacy.py:53-57 under train/hpnn_legacy_train.py:37-41).
+    After grad_sync both ranks must hold start + mean(1, 2); in the default inference mode the statistics are left alone (no collective)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (s0, a0, g0), (s0i, a0i, _) = res[0]
+    (s1, a1, g1), (s1i, a1i, _) = res[1]
+    assert np.array_equal(s0, s1)                                                   # attach broadcast rank 0's statistics
+    assert np.array_equal(a0, a1) and np.allclose(a0, s0 + 1.5, rtol=0, atol=1e-6)  # training mode: mean over the ranks of the per-rank updates
+    assert np.all(g0 == 3.0) and np.all(g1 == 3.0)                                  # the gradient all-reduce is unchanged
+    assert np.allclose(a0i, s0i + 1.0) and np.allclose(a1i, s1i + 2.0)              # inference-mode BN: untouched by the wrapper
+
+
 def test_single_rank_is_a_no_op():
     from poisson_cnn_amd import parallel
     dp = parallel.DataParallel()

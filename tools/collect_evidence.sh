@@ -1,13 +1,13 @@
 #!/bin/bash
-# Everything under profiles/r04_* (run on the GPU box from the repo root through gpurun; two calls, because the PMC summaries of stage 1 must sit
+# Everything under profiles/r05_* (run on the GPU box from the repo root through gpurun; two calls, because the PMC summaries of stage 1 must sit
 # in profiles/ - copied there by hand between the calls - before stage 2's bench.py looks for a summary whose source stamp matches its tree):
 #   gpurun --timeout 1200 -- 'bash tools/collect_evidence.sh 1'     GPU test suite, rocprofv3 kernel stats + three --pmc passes per workload / mode
-#   cp gpurun_out/evidence/r04_c?_pmc_summary_*.json gpurun_out/evidence/r04_c?_kernel_stats_*.csv profiles/
+#   cp gpurun_out/evidence/r05_c?_pmc_summary_*.json gpurun_out/evidence/r05_c?_kernel_stats_*.csv profiles/
 #   gpurun --timeout 1200 -- 'bash tools/collect_evidence.sh 2'     bench.py (the driver's command), layer / model / dataset probes, training curves
 # then copy gpurun_out/evidence/* into profiles/ (gpurun merges gpurun_out/ back).
 set -o pipefail
 ROOT=$(pwd)
-R=r04
+R=r05
 STAGE=${1:-1}
 OUT=$ROOT/gpurun_out/evidence
 mkdir -p "$OUT"
@@ -15,7 +15,7 @@ export TMPDIR=/tmp
 echo "source hash $(python -c 'from poisson_cnn_amd import _lib; print(_lib.source_hash())')"
 if [ "$STAGE" = 1 ]; then
   python -m pytest tests -m gpu -x -v > "$OUT/${R}_gpu_tests.log" 2>&1; echo "tests rc=$?"; tail -1 "$OUT/${R}_gpu_tests.log"
-  bash tools/collect_pmc.sh $R "c4" "fp32 split_f16" > "$ROOT/gpurun_out/collect_pmc_ev.log" 2>&1; echo "pmc c4 rc=$?"
+  bash tools/collect_pmc.sh $R "c4" "fp32" > "$ROOT/gpurun_out/collect_pmc_ev.log" 2>&1; echo "pmc c4 rc=$?"
   bash tools/collect_pmc.sh $R "c3" "fp32" >> "$ROOT/gpurun_out/collect_pmc_ev.log" 2>&1; echo "pmc c3 rc=$?"
   cp "$ROOT"/gpurun_out/${R}_c?_pmc_summary_*.json "$ROOT"/gpurun_out/${R}_c?_kernel_stats_*.csv "$OUT/"
 else

@@ -7,9 +7,9 @@
 # (+ <round>_<workload>_kernel_stats_<mode>.csv): copy them to profiles/.
 set -e -o pipefail
 ROOT=$(pwd)
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 WORKLOADS=${2:-c4}
-MODES=${3:-fp32 split_f16}
+MODES=${3:-fp32}
 export TMPDIR=/tmp
 for wl in $WORKLOADS; do
 for mode in $MODES; do
