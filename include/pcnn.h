@@ -90,6 +90,14 @@ int pcnn_get_spectral_mode(pcnn_handle h);
  * its batch neighbours); 32 / 64 = that size wherever the layer allows it (64: 9..15 taps, more than 16 channels on one side). */
 int pcnn_set_spectral_tile(pcnn_handle h, int tile);
 int pcnn_get_spectral_tile(pcnn_handle h);
+/* Transform kernels of the spectral route (same spectrum layout, same arithmetic class - exact fp32 -, results agree to ~1e-7):
+ *   PCNN_XFORM_MFMA: the DFT as a GEMM on the matrix cores (v_mfma_f32_32x32x2_f32; csrc/spectral_conv.hip, spectral64.hip);
+ *   PCNN_XFORM_FFT:  in-register FFTs on the vector ALUs, lane = channel (csrc/spectral_fft.hip, fft_regs.h): fp32 MFMA has no rate advantage
+ *                    over the vector ALUs on gfx950, so the FFT needs ~9x fewer issue cycles, half the registers and twice the waves per CU.
+ * Environment PCNN_SPEC_XFORM=fft|mfma sets the default of new handles. */
+enum { PCNN_XFORM_MFMA = 0, PCNN_XFORM_FFT = 1 };
+int pcnn_set_spectral_transform(pcnn_handle h, int xform);
+int pcnn_get_spectral_transform(pcnn_handle h);
 /* The ONE buffer a handle owns besides small scratch: the spectral workspace (tile spectra of the layer in flight, mixing matrices,
  * constant tables).  By default it grows to a whole layer per launch - 8 x 1024^2 x 32 channels at 15 taps: ~11 GB, sized for 288 GB of
  * HBM.  pcnn_set_workspace_limit caps it (bytes; 0 = no cap): the launches then cover fewer tiles each (never fewer than 32; a layer that
@@ -178,6 +186,13 @@ typedef struct pcnn_post_desc {
 int pcnn_conv2d_bwd_spectral_post_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg);
 int pcnn_conv2d_bwd_spectral_post(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
                                   const float* residual, float* dx, float* dw, const pcnn_post_desc* post);
+
+/* Diagnostics (tests / tools only; no reference counterpart): the tile spectra of one image exactly as the forward transform of a spectral
+ * convolution writes them, with the transform kernels the handle currently selects - out: [tile groups][channel groups][T*T rows][32] floats
+ * (layout: csrc/spectral_common.h).  tests/test_gpu_spectral_fft.py and test_gpu_spectral64.py compare the kernel families row by row. */
+int pcnn_debug_forward_spectrum32(pcnn_handle h, int H, int W, int C, const float* x, int Vy, int Vx, int oy, int ox, int pad_mode, float pad_value,
+                                  int ylim, int xlim, int pack, float* out, size_t out_floats);
+int pcnn_debug_tile_spectrum64(pcnn_handle h, int H, int W, int C, const float* x, int ylim, int xlim, float* out);
 
 /* Backward of the fused epilogue: given dy (gradient at y) and the saved activation a = act(z),
  *   dz = dy * bn_scale[c] * act'(z)      (act' recovered from a: leaky -> a>0 ? 1 : alpha, tanh -> 1-a^2)

@@ -14,6 +14,7 @@ extern "C" int pcnn_create(int device, void* hip_stream, pcnn_handle* out) {
   h->stream = static_cast<hipStream_t>(hip_stream);
   if (const char* e = getenv("PCNN_SPECTRAL")) h->spectral_mode = atoi(e);
   if (const char* e = getenv("PCNN_SPEC_T")) h->spectral_tile = atoi(e);
+  if (const char* e = getenv("PCNN_SPEC_XFORM")) h->spectral_xform = (e[0] == 'f' || e[0] == '1') ? PCNN_XFORM_FFT : PCNN_XFORM_MFMA;
   *out = h;
   return 0;
 }
@@ -75,6 +76,15 @@ extern "C" int pcnn_set_spectral_tile(pcnn_handle h, int tile) {
 }
 
 extern "C" int pcnn_get_spectral_tile(pcnn_handle h) { return h ? h->spectral_tile : -1; }
+
+extern "C" int pcnn_set_spectral_transform(pcnn_handle h, int xform) {
+  if (!h) return 1;
+  PCNN_REQUIRE(h, xform == PCNN_XFORM_MFMA || xform == PCNN_XFORM_FFT, "pcnn_set_spectral_transform: unknown transform %d", xform);
+  h->spectral_xform = xform;
+  return 0;
+}
+
+extern "C" int pcnn_get_spectral_transform(pcnn_handle h) { return h ? h->spectral_xform : -1; }
 
 // CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a HOST buffer: the checksum of TensorFlow's TensorBundle checkpoint files
 // (tensorflow/core/lib/hash/crc32c.h) that poisson_cnn_amd/tf_checkpoint.py reads and writes.  Host-only helper, no device work.

@@ -81,4 +81,10 @@ void launch_fwd64(pcnn_handle h, FwdParams p, int ntile);     // p.tab: the 64-p
 void launch_inv64(pcnn_handle h, InvParams p, int ntile);
 void launch_post_bias64(pcnn_handle h, const float* bsum, int nblocks, int C, float* dbias);   // POST at 64 points: bsum holds 4 floats per (block, wave, lane)
 
+// 32-point tiles as in-register FFTs on the vector ALUs (spectral_fft.hip); same parameter blocks, same spectrum layout.  16 waves per workgroup:
+// the POST partial sums hold one float per (block, wave, lane) with FFT_WAVES waves per block
+constexpr int FFT_WAVES = 16;
+void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile);
+void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile);
+
 }  // namespace pcnn_spec

@@ -858,6 +858,7 @@ void launch_fwd(pcnn_handle h, const Geom& gm, FwdParams p, int ntile) {
   static const int fence = getenv("PCNN_SPEC_FENCE") ? atoi(getenv("PCNN_SPEC_FENCE")) : 0;
   p.ntile = ntile; p.tab = gm.tab;
   if (gm.T == 64) { launch_fwd64(h, p, ntile); return; }
+  if (h->spectral_xform == PCNN_XFORM_FFT) { launch_fwd_fft32(h, p, ntile); return; }
   const bool masked = p.ylim < T || p.xlim < T;
   if (masked) { if (fence) launch_fwd_t<true, true>(h, p, ntile); else launch_fwd_t<true, false>(h, p, ntile); }
   else { if (fence) launch_fwd_t<false, true>(h, p, ntile); else launch_fwd_t<false, false>(h, p, ntile); }
@@ -870,6 +871,7 @@ void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
 void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
   p.ntile = ntile; p.tab = gm.tab;
   if (gm.T == 64) { launch_inv64(h, p, ntile); return; }
+  if (h->spectral_xform == PCNN_XFORM_FFT) { launch_inv_fft32(h, p, ntile); return; }
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)
     p.alpha = 1.f;
@@ -1140,6 +1142,35 @@ extern "C" int pcnn_debug_tile_spectrum64(pcnn_handle h, int H, int W, int C, co
   return 0;
 }
 
+// Diagnostic (tests): the 32-point tile spectra of ONE image exactly as the forward transform of a convolution writes them - tiles of Vy x Vx
+// outputs, window origin (-oy, -ox), the given padding, optional masks (ylim / xlim < 32: gradient-style tiles) and tile packing (pack = 1, 2, 4, 8:
+// that many x-adjacent tiles of a <= 32 / pack-channel image share the lanes) - with the transform kernels the handle currently selects
+// (pcnn_set_spectral_transform).  out: [tile groups][channel groups][1024 rows][32] floats.  tests/test_gpu_spectral_fft.py compares the two kernel
+// families row by row.
+extern "C" int pcnn_debug_forward_spectrum32(pcnn_handle h, int H, int W, int C, const float* x, int Vy, int Vx, int oy, int ox, int pad_mode, float pad_value,
+                                             int ylim, int xlim, int pack, float* out, size_t out_floats) {
+  PCNN_REQUIRE(h, h && x && out && H >= 1 && W >= 1 && C >= 1 && C <= 64 && Vy >= 1 && Vy <= 32 && Vx >= 1 && Vx <= 32, "pcnn_debug_forward_spectrum32: bad argument");
+  PCNN_REQUIRE(h, pack == 1 || ((pack == 2 || pack == 4 || pack == 8) && C <= 32 / pack), "pcnn_debug_forward_spectrum32: pack = %d with %d channels", pack, C);
+  const int tiles_y = pcnn_cdiv(H, Vy), tiles_x = pcnn_cdiv(W, Vx), tgx = pcnn_cdiv(tiles_x, pack), groups = pack > 1 ? 1 : pcnn_cdiv(C, 32);
+  const int ntile = tiles_y * tgx;
+  PCNN_REQUIRE(h, out_floats >= (size_t)ntile * groups * 1024 * 32, "pcnn_debug_forward_spectrum32: output holds %zu floats, %zu needed", out_floats, (size_t)ntile * groups * 1024 * 32);
+  const size_t sp_b = align256(sp_bytes((size_t)ntile * groups, 1024));
+  char* r;
+  if (int rc = ensure_workspace(h, sp_b, &r)) return rc;
+  const Geom gm = geom_of(h, 32);
+  FwdParams f;
+  f.x = x; f.sp = reinterpret_cast<float*>(r); f.tab = gm.tab; f.H = H; f.W = W; f.C = C; f.ld = C; f.groups = groups; f.cstride = 32; f.cvalid = 32;
+  f.tiles_x = tiles_x; f.tiles_y = tiles_y; f.tile0 = 0; f.Vy = Vy; f.Vx = Vx; f.oy = oy; f.ox = ox; f.pad_mode = pad_mode; f.pad_value = pad_value;
+  f.ylim = ylim; f.xlim = xlim; f.ext_y = 1 << 30; f.ext_x = 1 << 30; f.pack = pack; f.cpt = 32 / pack; f.tgx = tgx;
+  if (pack > 1) { f.cstride = f.cpt; f.cvalid = f.cpt; }
+  launch_fwd(h, gm, f, ntile);
+  PCNN_CHECK_LAUNCH(h, "pcnn_debug_forward_spectrum32");
+  for (int i = 0; i < ntile * groups; ++i)
+    if (hipMemcpyAsync(out + (size_t)i * 1024 * 32, f.sp + pcnn_spec::sp_item(i, 1024), 1024 * 32 * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+      PCNN_FAIL(h, "pcnn_debug_forward_spectrum32: copy failed");
+  return 0;
+}
+
 extern "C" int pcnn_conv2d_bwd_spectral_eligible(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg) {
   if (!h || !d || !dg) return 0;
   if (d->Cout > 32 || d->Cin > 64) return 0;
@@ -1259,7 +1290,7 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
   }
   if (post && post->dbias) {
     if (Tg == 64) launch_post_bias64(h, bsum, 256, dg->Cout, post->dbias);
-    else hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * 8, pack, cpt, post->dbias);
+    else hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * (h->spectral_xform == PCNN_XFORM_FFT ? FFT_WAVES : 8), pack, cpt, post->dbias);
   }
   float* csp = wsp;                                      // the filter spectrum is no longer needed: every mixing launch above has read it (same stream)
   hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gx), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);

@@ -1,0 +1,409 @@
+// The transforms of the tiled spectral convolution as IN-REGISTER FFTs on the vector ALUs (round 5).
+//
+// spectral_conv.hip / spectral64.hip apply the DFT as a GEMM on the matrix cores.  On gfx950 an fp32 MFMA issues at exactly the fp32 vector
+// rate (64 FLOP/clk/SIMD), so that form spends T multiply-adds per point where an FFT spends ~2.5 log2 T at the same issue rate - and its
+// accumulator tiles cost 256 registers per lane, one workgroup of 8 waves per CU, whose memory and matrix phases add up (profiles/r04: every
+// transform kernel at ~0.4 of HBM AND ~0.4 matrix-pipe busy).  Here the CHANNEL stays in the lane (every global access is still a pixel's /
+// spectrum row's 128-byte channel vector) and a lane holds a whole 32-point row or column OF ITS CHANNEL in registers: the butterflies never
+// cross lanes (fft_regs.h), a tile costs ~7 k vector instructions instead of 1 024 MFMAs (= 65 k SIMD cycles), the kernels need <= 128 registers
+// and run 16 waves per CU, so one wave's loads and stores fly under the other waves' arithmetic.
+//
+//   fft32_fwd_kernel   item = (tile, 32 channels).  x axis: wave w owns window rows 2w, 2w + 1 (one per lane half): 32 loads per lane (prefetched
+//                      one item ahead), real FFT in registers (rfft_fwd<32>), half-complex result to LDS U[y][s][c] (128 KB).  y axis: wave 0 owns
+//                      the two real columns (fx = 0 / 16, one per lane half: a real FFT again), wave fx = 1..15 the complex column fx with the
+//                      output-frequency PARITY in the lane half (one radix-2 decimation-in-frequency step while reading LDS, then cfft_dif<16>);
+//                      32 stores per lane, each instruction two whole 128-byte spectrum rows.
+//   fft32_inv_kernel   the mirror image + the fused convolution epilogue of spec_inv_kernel: y axis straight from global (wave 0: the real
+//                      columns by rfft_inv<32>; wave fx: the even / odd input frequencies per lane half -> E / O halves of a decimation-in-time
+//                      step in LDS), x axis: u = E +- O while reading LDS, rfft_inv<32>, epilogue from registers.
+// Spectrum layout, parameter blocks, tables of slots: spectral_common.h - identical to the matrix-core kernels, which stay selectable
+// (pcnn_set_spectral_transform / PCNN_SPEC_XFORM) and are the reference of tests/test_gpu_spectral_fft.py (spectra equal to <= 1e-6 row by row).
+#include "spectral_common.h"
+#include "fft_regs.h"
+#include <algorithm>
+
+#ifndef PCNN_NT
+#define PCNN_NT 17
+#endif
+#define NT_LOAD(bit, p) ((PCNN_NT & (bit)) ? __builtin_nontemporal_load(p) : *(p))
+#define NT_STORE(bit, v, p) do { if (PCNN_NT & (bit)) __builtin_nontemporal_store(v, p); else *(p) = (v); } while (0)
+
+namespace pcnn_spec {
+
+namespace {
+using namespace pcnn_fft;
+
+constexpr int T = 32, ROWS = 1024;
+constexpr int EO = 16 * 32 * 32;                               // floats between the E and the O half of the inverse kernel's LDS image
+constexpr size_t LDS_BYTES = (size_t)T * T * 32 * sizeof(float);   // 128 KB
+__host__ __device__ __forceinline__ int64_t sp_item32(int64_t item) { return pcnn_spec::sp_item(item, ROWS); }
+
+// tf.pad index map without control flow (selects only); constant padding: any valid pixel (replaced when the value is consumed)
+__device__ __forceinline__ int pad_sel(int i, int n, int mode) {
+  const int refl = mode == PCNN_PAD_SYMMETRIC ? (i < 0 ? -i - 1 : 2 * n - 1 - i) : (i < 0 ? -i : 2 * n - 2 - i);
+  const int rc = min(max(refl, 0), n - 1);
+  return (unsigned)i < (unsigned)n ? i : (mode == PCNN_PAD_CONSTANT ? 0 : rc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ forward transform
+// what a lane keeps of an item between requesting its window row and consuming it
+struct FwdRow {
+  float fill;            // lane: value of a row that is not read from memory (0: beyond ylim / no such channel; the padding constant)
+  unsigned cmask;        // lane: bit x set - column x is constant padding (boundary windows only)
+  int xlim;              // lane: columns >= xlim are zero (gradient / input tiles of the backward pass)
+  bool use_fill;         // lane
+  bool fast;             // uniform: every window of the item lies inside the image in x
+};
+
+// requests window row y (lane: y = 2 wave + half) of `item`: 32 loads with always-valid addresses; padding and masks are applied on consumption
+__device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int wave, int y, int c, FwdRow& it, float (&R)[32]) {
+  const int g = item % p.groups;
+  int t = p.tile0 + item / p.groups;
+  const int txg = t % p.tgx; t /= p.tgx;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int sub = p.pack > 1 ? c / p.cpt : 0, cc = c - sub * p.cpt;            // this lane's tile of the group, and its channel
+  const int tx = txg * p.pack + sub;
+  const int chan = g * p.cstride + cc;
+  const bool cok = cc < p.cvalid && chan < p.C && tx < p.tiles_x;
+  const float* img = p.x + (int64_t)n * p.H * p.W * p.ld;
+  const int wy0 = ty * p.Vy - p.oy, wx0 = tx * p.Vx - p.ox;
+  const int ylim = min(p.ylim, p.ext_y - ty * p.Vy);                           // uniform
+  it.xlim = min(p.xlim, p.ext_x - tx * p.Vx);
+  const int gy = wy0 + y;
+  const bool rowconst = p.pad_mode == PCNN_PAD_CONSTANT && (unsigned)gy >= (unsigned)p.H;
+  const bool rowzero = !cok || y >= ylim;
+  it.use_fill = rowzero || rowconst;
+  it.fill = rowzero ? 0.f : p.pad_value;
+  it.cmask = 0u;
+  const int wx_first = txg * p.pack * p.Vx - p.ox, wx_last = wx_first + (p.pack - 1) * p.Vx;
+  it.fast = wx_first >= 0 && wx_last + T <= p.W;                               // uniform
+  if (2 * wave >= ylim) return;                                                // uniform: both rows of this wave are zero rows - nothing to fetch
+  const int sy = pad_sel(gy, p.H, p.pad_mode);
+  const unsigned ch = (unsigned)(cok ? chan : 0);
+  if (it.fast) {
+    // one lane offset for all 32 loads; the uniform pointer steps from pixel to pixel on the scalar ALU
+    const unsigned lo = (unsigned)((sy * p.W + wx0) * p.ld) + ch;
+    const float* rp = img;
+#pragma unroll
+    for (int x = 0; x < T; ++x) { R[x] = rp[lo]; rp += p.ld; }
+  } else {
+    const unsigned rowoff = (unsigned)(sy * p.W * p.ld) + ch;
+#pragma unroll
+    for (int x = 0; x < T; ++x) {
+      const int gx = wx0 + x;
+      if (p.pad_mode == PCNN_PAD_CONSTANT && (unsigned)gx >= (unsigned)p.W) it.cmask |= 1u << x;
+      R[x] = img[rowoff + (unsigned)(pad_sel(gx, p.W, p.pad_mode) * p.ld)];
+    }
+  }
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void fwd_consume(const FwdParams& p, const FwdRow& it, float (&R)[32]) {
+#pragma unroll
+  for (int x = 0; x < T; ++x) {
+    float v = R[x];
+    if (!it.fast && ((it.cmask >> x) & 1u)) v = p.pad_value;
+    if (it.use_fill) v = it.fill;
+    if (MASKED && x >= it.xlim) v = 0.f;
+    R[x] = v;
+  }
+}
+
+// half-complex entry s of a transformed row held as rfft_fwd<32> leaves it: s <= 16: Re X[s], s > 16: Im X[s - 16]
+__device__ __forceinline__ float hc_get(const float (&R)[32], int s) {
+  bool neg = false;
+  const int pos = s <= 16 ? rfft_pos(32, s, false, neg) : rfft_pos(32, s - 16, true, neg);
+  return neg ? -R[pos] : R[pos];
+}
+__device__ __forceinline__ void hc_put(float (&R)[32], int s, float v) {
+  bool neg = false;
+  const int pos = s <= 16 ? rfft_pos(32, s, false, neg) : rfft_pos(32, s - 16, true, neg);
+  R[pos] = neg ? -v : v;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*32 + c]
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = p.ntile * p.groups;
+  int item = blockIdx.x;
+  if (item >= total) return;
+  const int y = 2 * wave + half;
+  float R[32];
+  FwdRow cur;
+  fwd_request(p, item, wave, y, c, cur, R);
+  // ---- x axis: this lane's window row, real -> half-complex, into LDS
+  auto x_phase = [&]() {
+    fwd_consume<MASKED>(p, cur, R);
+    rfft_fwd<32>(R);
+    float* u = U + (y * 32) * 32 + c;
+#pragma unroll
+    for (int s = 0; s < T; ++s) u[s * 32] = hc_get(R, s);
+  };
+  // (first x phase outside the loop: every x phase inside it then meets the same memory-counter state - the next item's loads, then this item's
+  // stores - as in spec_fwd_kernel)
+  x_phase();
+  for (;;) {
+    const int next = item + gridDim.x;
+    if (next < total) fwd_request(p, next, wave, y, c, cur, R);      // lands under the y phase below
+    lds_barrier();
+    float* out = p.sp + sp_item32(item);
+    float V[32];
+    if (wave == 0) {
+      // the two real columns fx = 0 (lanes 0-31) and fx = 16 (lanes 32-63): half-complex along y as well
+      const float* u = U + (half ? 16 : 0) * 32 + c;
+#pragma unroll
+      for (int yy = 0; yy < T; ++yy) V[yy] = u[yy * 1024];
+      rfft_fwd<32>(V);
+      float* o = out + (half ? 32 : 0) * RS + c;
+#pragma unroll
+      for (int s = 0; s < T; ++s) NT_STORE(1, hc_get(V, s), &o[s * RS]);
+    } else {
+      // complex column fx = wave; lane half = parity of the output frequencies: Z[2m + par] = FFT16( (u[y] +- u[y + 16]) W32^(par y) )[m]
+      const float* ur = U + wave * 32 + c, *ui = U + (16 + wave) * 32 + c;
+      float* vr = V, *vi = V + 16;
+      int par = half;
+      asm volatile("" : "+v"(par));                                  // opaque: the 30 per-lane twiddle selects below are formed here, item by item -
+                                                                     // left alone they are hoisted out of the persistent loop into 30 registers (spills)
+      const float osign = par ? -1.f : 1.f;
+#pragma unroll
+      for (int yy = 0; yy < 16; ++yy) {
+        const float lr = ur[yy * 1024], hr = ur[(yy + 16) * 1024], li = ui[yy * 1024], hi = ui[(yy + 16) * 1024];
+        const float ar = fma_(osign, hr, lr), ai = fma_(osign, hi, li);
+        if (yy == 0) { vr[yy] = ar; vi[yy] = ai; }
+        else {
+          const float wr = par ? tw_re<32>(yy) : 1.f, wi = par ? tw_im<32>(yy) : 0.f;
+          vr[yy] = fma_(ar, wr, -(ai * wi));
+          vi[yy] = fma_(ar, wi, ai * wr);
+        }
+      }
+      cfft_dif<16, -1>(vr, vi);
+      // register q holds Z[2 bitrev(q) + par]: spectrum rows 64 + 64 (fx - 1) + fy (real part), + 32 (imaginary part)
+      float* o = out + (64 + 64 * (wave - 1) + half) * RS + c;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        NT_STORE(1, vr[bitrev(m, 16)], &o[(2 * m) * RS]);
+        NT_STORE(1, vi[bitrev(m, 16)], &o[(32 + 2 * m) * RS]);
+      }
+    }
+    if (next >= total) break;
+    item = __builtin_amdgcn_readfirstlane(next);
+    lds_barrier();                                                       // U is free for the next item
+    x_phase();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ inverse transform + epilogue
+// requests this wave's column of an item (`in`: its spectrum): wave 0 - lane half = real column 0 / 16, its 32 half-complex entries in row order;
+// wave fx - lane half = parity, B[m] = Re Z[2m + par], B[16 + m] = Im Z[2m + par] (spectrum rows 2j + par of the column's 64, j = 0..31).
+// ONE code path for both (a uniform row step on the scalar ALU): the prefetch registers then have a single definition point in the item loop.
+__device__ __forceinline__ void inv_request(const float* in, int wave, int half, int c, float (&B)[32]) {
+  const float* sp = in + (wave == 0 ? 0 : (64 + 64 * (wave - 1)) * RS);
+  const int step = wave == 0 ? RS : 2 * RS;
+  const unsigned lo = (unsigned)((wave == 0 ? 32 * RS : RS) * half + c);
+#pragma unroll
+  for (int j = 0; j < T; ++j) { B[j] = NT_LOAD(8, &sp[lo]); sp += step; }
+}
+
+// TANH = false: linear / relu / leaky-relu as one select with the negative-side slope in p.alpha (1 / 0 / alpha)
+template <bool TANH, bool RES, bool POST>
+__global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float U[];          // E[(y*32 + s)*32 + c], y < 16, then O
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int total = p.ntile * p.groups;
+  int item = blockIdx.x;
+  if (item >= total) return;
+  float B[32];
+  inv_request(p.sp + sp_item32(item), wave, half, c, B);
+  float ymax = 0.f, bsum = 0.f;
+  constexpr int BURST = (POST && RES) ? 4 : ((POST || RES) ? 8 : 16); // pixels whose epilogue inputs are requested together, before any of their stores (registers: 128 per lane)
+  for (;;) {
+    const int next = item + gridDim.x;
+    // ---- y axis inverse (unnormalised: the 1 / 1024 of both axes is applied once, after the x axis)
+    {
+      float V[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) V[i] = B[i];
+      if (next < total) inv_request(p.sp + sp_item32(next), wave, half, c, B);      // lands under the rest of this item
+      if (wave == 0) {
+        float W[32];
+#pragma unroll
+        for (int s = 0; s < T; ++s) hc_put(W, s, V[s]);
+        rfft_inv<32>(W);                                             // W[y] = 32 u[y]
+        float* e = U + (half ? 16 : 0) * 32 + c;
+#pragma unroll
+        for (int yy = 0; yy < 16; ++yy) {
+          e[yy * 1024] = 0.5f * (W[yy] + W[yy + 16]);                // the x axis forms u[y] = E + O, u[y + 16] = E - O for every column alike
+          e[EO + yy * 1024] = 0.5f * (W[yy] - W[yy + 16]);
+        }
+      } else {
+        float* vr = V, *vi = V + 16;
+        cfft_dif<16, +1>(vr, vi);                                    // register q: E (par = 0) or O-before-twiddle (par = 1) at y = bitrev(q)
+        float* er = U + (half ? EO : 0) + wave * 32 + c, *ei = er + 16 * 32;
+        int par = half;
+        asm volatile("" : "+v"(par));                                // opaque: the per-lane twiddle selects are formed here, not hoisted out of the item loop
+#pragma unroll
+        for (int yy = 0; yy < 16; ++yy) {
+          const float ar = vr[bitrev(yy, 16)], ai = vi[bitrev(yy, 16)];
+          if (yy == 0) { er[0] = ar; ei[0] = ai; }
+          else {
+            const float wr = par ? tw_re<32>(yy) : 1.f, wi = par ? -tw_im<32>(yy) : 0.f;        // conj(W32^y) for the odd half
+            er[yy * 1024] = fma_(ar, wr, -(ai * wi));
+            ei[yy * 1024] = fma_(ar, wi, ai * wr);
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- x axis inverse of this lane's output row + the fused epilogue (lane = channel: per-channel constants are per-lane scalars)
+    {
+      const int g = item % p.groups;
+      int t = p.tile0 + item / p.groups;
+      const int txg = t % p.tgx; t /= p.tgx;
+      const int ty = t % p.tiles_y;
+      const int n = t / p.tiles_y;
+      const int sub = p.pack > 1 ? c / p.cpt : 0, cc = c - sub * p.cpt;
+      const int subx = sub * p.Vx;
+      const int y0 = ty * p.Vy, x0 = txg * p.pack * p.Vx;
+      const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0 - subx);
+      const int chan = g * p.cstride + cc;
+      const bool cok = cc < p.cvalid && chan < p.C;
+      if (2 * wave < vy) {                                            // uniform: at least the even row of this wave is an output row
+        const int yy = 2 * wave + half;
+        const bool rowok = cok && yy < vy;
+        float X[32];
+        {
+          // u = E +- O in batches of eight entries: left alone, the scheduler requests all 64 operands first (64 registers beside the 32 of the
+          // next item's prefetch: spills)
+          const float* e = U + ((yy & 15) * 32) * 32 + c;
+          const float osign = wave < 8 ? 1.f : -1.f;
+#pragma unroll
+          for (int s0 = 0; s0 < T; s0 += 8) {
+#pragma unroll
+            for (int s = s0; s < s0 + 8; ++s) hc_put(X, s, fma_(osign, e[EO + s * 32], e[s * 32]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        rfft_inv<32>(X);                                             // X[x] = 1024 * pixel (yy, x)
+        const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
+        const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
+        // addresses: a uniform IMAGE base per tensor plus an unsigned 32-bit lane offset (scalar base + vector offset form: no 64-bit address
+        // lives in vector registers); the lane's first pixel, then one pixel to the right (left when the output is stored flipped) per x
+        const int sgn = p.flip ? -1 : 1;
+        const int prow = p.flip ? p.Ho - 1 - y0 - yy : y0 + yy, pcol = p.flip ? p.Wo - 1 - x0 - subx : x0 + subx;
+        unsigned pix0 = (unsigned)(prow * p.Wo + pcol);
+        asm volatile("" : "+v"(pix0));                               // opaque: per-pixel offsets are recomputed, not hoisted into 32 registers per tensor
+        const int64_t ipix = (int64_t)n * p.Ho * p.Wo;
+        float* yimg = p.y + ipix * p.ldy;
+        float* aimg = (!POST && p.act_out) ? p.act_out + ipix * p.ld_act : nullptr;
+        const float* rimg = RES ? p.res + ipix * p.ld_res : nullptr;
+        const float* gimg = POST ? p.gact + ipix * p.ld_gact : nullptr;
+        float* y2img = (POST && p.y2) ? p.y2 + ipix * p.ld_y2 : nullptr;
+        const unsigned chv = (unsigned)chan;
+        if (rowok) {
+#pragma unroll
+          for (int x0b = 0; x0b < T; x0b += BURST) {
+            float rv[BURST], gv[BURST];
+            // the burst's inputs first, as unconditional loads (pixels beyond vx read the lane's first pixel): a load placed between stores is
+            // waited for together with the stores in front of it (in-order memory counter)
+            if (RES) {
+#pragma unroll
+              for (int r = 0; r < BURST; ++r) {
+                const int xx = x0b + r;
+                rv[r] = rimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_res + chv];
+              }
+            }
+            if (POST) {
+#pragma unroll
+              for (int r = 0; r < BURST; ++r) {
+                const int xx = x0b + r;
+                gv[r] = gimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_gact + chv];
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < BURST; ++r) {
+              const int xx = x0b + r;
+              if (xx < vx) {
+                float v = X[xx] * (1.f / 1024.f);
+                const unsigned pix = pix0 + (unsigned)(sgn * xx);
+                if (!POST) {                                           // (a data-gradient launch has no bias, activation, BN or act_out)
+                  v += bias;
+                  v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+                  if (aimg) aimg[pix * (unsigned)p.ld_act + chv] = v;
+                  v = v * sc + sh;
+                }
+                if (RES) v += rv[r];
+                if (POST) {
+                  if (y2img) y2img[pix * (unsigned)p.ld_y2 + chv] = v;
+                  const float gq = gv[r];
+                  v *= p.gmode == PCNN_ACT_TANH ? 1.f - gq * gq : (gq > 0.f ? 1.f : p.galpha);
+                  bsum += v;
+                }
+                yimg[pix * (unsigned)p.ldy + chv] = v;
+                ymax = fmaxf(ymax, fabsf(v));
+              }
+            }
+          }
+        }
+      }
+    }
+    if (next >= total) break;
+    item = __builtin_amdgcn_readfirstlane(next);
+    lds_barrier();                                                       // the LDS image is free for the next item
+  }
+  if (POST && p.bsum) p.bsum[(blockIdx.x * 16 + wave) * 64 + lane] += bsum;   // own slot: launches of one call follow each other on the stream
+  if (p.absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (lane == 0) {
+      const unsigned bits = __float_as_uint(ymax <= 3.0e38f ? ymax : 3.0e38f);
+      if (bits > __atomic_load_n(p.absmax, __ATOMIC_RELAXED)) atomicMax(p.absmax, bits);
+    }
+  }
+}
+
+template <typename K>
+void set_lds(K kernel) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES); }
+
+template <bool TANH, bool RES, bool POST>
+void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
+  set_lds(fft32_inv_kernel<TANH, RES, POST>);
+  hipLaunchKernelGGL((fft32_inv_kernel<TANH, RES, POST>), grid, dim3(1024), LDS_BYTES, h->stream, p);
+}
+
+}  // namespace
+
+// persistent kernels: one 16-wave workgroup per CU (128 KB of LDS) walking the (tile, channel group) items
+void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
+  p.ntile = ntile;
+  const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
+  if (p.ylim < T || p.xlim < T) {
+    set_lds(fft32_fwd_kernel<true>);
+    hipLaunchKernelGGL((fft32_fwd_kernel<true>), grid, dim3(1024), LDS_BYTES, h->stream, p);
+  } else {
+    set_lds(fft32_fwd_kernel<false>);
+    hipLaunchKernelGGL((fft32_fwd_kernel<false>), grid, dim3(1024), LDS_BYTES, h->stream, p);
+  }
+}
+
+void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile) {
+  p.ntile = ntile;
+  const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
+  if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)
+    p.alpha = 1.f;
+    p.galpha = p.gmode == PCNN_ACT_LINEAR ? 1.f : (p.gmode == PCNN_ACT_RELU ? 0.f : p.galpha);
+    if (p.res) launch_inv_t<false, true, true>(h, p, grid); else launch_inv_t<false, false, true>(h, p, grid);
+    return;
+  }
+  if (p.act == PCNN_ACT_TANH) {
+    if (p.res) launch_inv_t<true, true, false>(h, p, grid); else launch_inv_t<true, false, false>(h, p, grid);
+  } else {
+    p.alpha = p.act == PCNN_ACT_LINEAR ? 1.f : (p.act == PCNN_ACT_RELU ? 0.f : p.alpha);     // slope of the negative side
+    if (p.res) launch_inv_t<false, true, false>(h, p, grid); else launch_inv_t<false, false, false>(h, p, grid);
+  }
+}
+
+}  // namespace pcnn_spec

@@ -63,6 +63,23 @@ def get_spectral_tile():
     return _spectral_tile
 
 
+XFORMS = {'mfma': 0, 'fft': 1}
+_spectral_xform = XFORMS[{'f': 'fft', '1': 'fft'}.get(__import__('os').environ.get('PCNN_SPEC_XFORM', 'mfma')[:1], 'mfma')]
+
+
+def set_spectral_transform(xform):
+    """'mfma' (the DFT as a GEMM on the matrix cores) or 'fft' (in-register FFTs on the vector ALUs): the transform kernels of the spectral route,
+    include/pcnn.h pcnn_set_spectral_transform.  Environment: PCNN_SPEC_XFORM."""
+    global _spectral_xform
+    _spectral_xform = XFORMS[xform]
+    for h in _handles.values():
+        h.call('pcnn_set_spectral_transform', c_int(_spectral_xform))
+
+
+def get_spectral_transform():
+    return [k for k, v in XFORMS.items() if v == _spectral_xform][0]
+
+
 def get_math_mode():
     return [k for k, v in MATH_MODES.items() if v == _math_mode][0]
 
@@ -78,6 +95,7 @@ def handle():
         h.call('pcnn_set_math_mode', c_int(_math_mode))
         h.call('pcnn_set_spectral_mode', c_int(_spectral_mode))
         h.call('pcnn_set_spectral_tile', c_int(_spectral_tile))
+        h.call('pcnn_set_spectral_transform', c_int(_spectral_xform))
         _handles[(dev, st)] = h
     return h
 

@@ -119,7 +119,7 @@ def test_bench_two_ranks_bare_invocation_on_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     env['PCNN_DIST_BACKEND'] = 'gloo'
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'small', '--steps', '1', '--warmup', '1',
-                        '--no-cpu-baseline', '--no-dataset'], env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--no-dataset', '--modes', 'split_f16,fp32'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout

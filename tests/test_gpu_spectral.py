@@ -10,13 +10,17 @@ from oracle import np_ops
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def spectral_forced():
+@pytest.fixture(autouse=True, params=['mfma', 'fft'])
+def spectral_forced(request):
+    """Every test of this file runs through BOTH transform kernel families of the route: the DFT as a GEMM on the matrix cores and the in-register
+    FFTs on the vector ALUs (csrc/spectral_fft.hip, round 5) - same spectrum layout, same tolerances."""
     from poisson_cnn_amd import ops
-    prev = ops.get_spectral_mode()
+    prev, prev_x = ops.get_spectral_mode(), ops.get_spectral_transform()
     ops.set_spectral_mode('force')
+    ops.set_spectral_transform(request.param)
     yield
     ops.set_spectral_mode(prev)
+    ops.set_spectral_transform(prev_x)
 
 
 def test_route_is_taken_and_differs_from_direct_only_by_rounding():
