@@ -857,7 +857,7 @@ void launch_fwd_t(pcnn_handle h, const FwdParams& p, int ntile) {
 void launch_fwd(pcnn_handle h, const Geom& gm, FwdParams p, int ntile) {
   static const int fence = getenv("PCNN_SPEC_FENCE") ? atoi(getenv("PCNN_SPEC_FENCE")) : 0;
   p.ntile = ntile; p.tab = gm.tab;
-  if (gm.T == 64) { launch_fwd64(h, p, ntile); return; }
+  if (gm.T == 64) { if (h->spectral_xform == PCNN_XFORM_FFT) launch_fwd_fft64(h, p, ntile); else launch_fwd64(h, p, ntile); return; }
   if (h->spectral_xform == PCNN_XFORM_FFT) { launch_fwd_fft32(h, p, ntile); return; }
   const bool masked = p.ylim < T || p.xlim < T;
   if (masked) { if (fence) launch_fwd_t<true, true>(h, p, ntile); else launch_fwd_t<true, false>(h, p, ntile); }

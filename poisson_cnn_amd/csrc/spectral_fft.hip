@@ -49,7 +49,7 @@ __device__ __forceinline__ int pad_sel(int i, int n, int mode) {
 // what a lane keeps of an item between requesting its window row and consuming it
 struct FwdRow {
   float fill;            // lane: value of a row that is not read from memory (0: beyond ylim / no such channel; the padding constant)
-  unsigned cmask;        // lane: bit x set - column x is constant padding (boundary windows only)
+  int cl, cr;            // lane: window columns x < cl or x >= cr are constant padding (boundary windows with CONSTANT padding; else 0, T)
   int xlim;              // lane: columns >= xlim are zero (gradient / input tiles of the backward pass)
   bool use_fill;         // lane
   bool fast;             // uniform: every window of the item lies inside the image in x
@@ -75,7 +75,7 @@ __device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int wa
   const bool rowzero = !cok || y >= ylim;
   it.use_fill = rowzero || rowconst;
   it.fill = rowzero ? 0.f : p.pad_value;
-  it.cmask = 0u;
+  it.cl = 0; it.cr = T;
   const int wx_first = txg * p.pack * p.Vx - p.ox, wx_last = wx_first + (p.pack - 1) * p.Vx;
   it.fast = wx_first >= 0 && wx_last + T <= p.W;                               // uniform
   if (2 * wave >= ylim) return;                                                // uniform: both rows of this wave are zero rows - nothing to fetch
@@ -89,12 +89,9 @@ __device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int wa
     for (int x = 0; x < T; ++x) { R[x] = rp[lo]; rp += p.ld; }
   } else {
     const unsigned rowoff = (unsigned)(sy * p.W * p.ld) + ch;
+    if (p.pad_mode == PCNN_PAD_CONSTANT) { it.cl = -wx0; it.cr = p.W - wx0; }
 #pragma unroll
-    for (int x = 0; x < T; ++x) {
-      const int gx = wx0 + x;
-      if (p.pad_mode == PCNN_PAD_CONSTANT && (unsigned)gx >= (unsigned)p.W) it.cmask |= 1u << x;
-      R[x] = img[rowoff + (unsigned)(pad_sel(gx, p.W, p.pad_mode) * p.ld)];
-    }
+    for (int x = 0; x < T; ++x) R[x] = img[rowoff + (unsigned)(pad_sel(wx0 + x, p.W, p.pad_mode) * p.ld)];
   }
 }
 
@@ -103,11 +100,18 @@ __device__ __forceinline__ void fwd_consume(const FwdParams& p, const FwdRow& it
 #pragma unroll
   for (int x = 0; x < T; ++x) {
     float v = R[x];
-    if (!it.fast && ((it.cmask >> x) & 1u)) v = p.pad_value;
+    if (!it.fast && (x < it.cl || x >= it.cr)) v = p.pad_value;
     if (it.use_fill) v = it.fill;
     if (MASKED && x >= it.xlim) v = 0.f;
     R[x] = v;
   }
+}
+
+// The values are needed NOW: without this the compiler sinks a whole sub-transform to its first use - a phase later - and keeps (spills) its 64
+// inputs instead of its 32 results.  No instruction is emitted.
+template <int N> __device__ __forceinline__ void pin(float* a) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
 }
 
 // half-complex entry s of a transformed row held as rfft_fwd<32> leaves it: s <= 16: Re X[s], s > 16: Im X[s - 16]
@@ -157,9 +161,10 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
 #pragma unroll
       for (int yy = 0; yy < T; ++yy) V[yy] = u[yy * 1024];
       rfft_fwd<32>(V);
-      float* o = out + (half ? 32 : 0) * RS + c;
+      // (stores: uniform base + 32-bit lane offset + immediate - no 64-bit address per 4 KB window in vector registers)
+      const unsigned lo = (unsigned)((half ? 32 : 0) * RS + c);
 #pragma unroll
-      for (int s = 0; s < T; ++s) NT_STORE(1, hc_get(V, s), &o[s * RS]);
+      for (int s = 0; s < T; ++s) NT_STORE(1, hc_get(V, s), &(out + (s * RS))[lo]);
     } else {
       // complex column fx = wave; lane half = parity of the output frequencies: Z[2m + par] = FFT16( (u[y] +- u[y + 16]) W32^(par y) )[m]
       const float* ur = U + wave * 32 + c, *ui = U + (16 + wave) * 32 + c;
@@ -181,11 +186,12 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
       }
       cfft_dif<16, -1>(vr, vi);
       // register q holds Z[2 bitrev(q) + par]: spectrum rows 64 + 64 (fx - 1) + fy (real part), + 32 (imaginary part)
-      float* o = out + (64 + 64 * (wave - 1) + half) * RS + c;
+      float* o = out + (64 + 64 * (wave - 1)) * RS;                   // uniform
+      const unsigned lo = (unsigned)(half * RS + c);
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        NT_STORE(1, vr[bitrev(m, 16)], &o[(2 * m) * RS]);
-        NT_STORE(1, vi[bitrev(m, 16)], &o[(32 + 2 * m) * RS]);
+        NT_STORE(1, vr[bitrev(m, 16)], &(o + ((2 * m) * RS))[lo]);
+        NT_STORE(1, vi[bitrev(m, 16)], &(o + ((32 + 2 * m) * RS))[lo]);
       }
     }
     if (next >= total) break;
@@ -365,8 +371,262 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
   }
 }
 
+// =================================================================================================================== 64-point tiles
+// A 64 x 64 x 32-channel tile is 512 KB - the whole register file of a CU.  item = (tile, 16 channels): the lanes of a wave are 4 x 16 channels
+// (every global access a 64-byte half of a pixel's / spectrum row's channel vector; the two halves of a 32-channel group run at the same time on
+// workgroups b and b + 8, i.e. on one XCD, so the second half of every 128-byte line comes from its L2), and the tile passes through LDS in TWO
+// phases of 128 KB, one per parity of the x frequency:
+//   x axis   wave w, lane group r: window row 4w + r, rfft_fwd<64> in 64 registers.  Its first step IS the parity split: the even bins are the real
+//            FFT of e[n] = x[n] + x[n + 32] (-> phase 0), the odd bins X[4m + 1] = one complex FFT of 16 points (-> phase 1; X[4m + 3] = conj X[61 - 4m]).
+//   y axis   per phase 16 columns x 64 rows x 16 channels in LDS, one column per wave; the lane group is the CLASS cl = fy mod 4 of the output
+//            frequencies: Z[4m + cl] = FFT16( W64^(cl y) sum_q (-i)^(q cl) u[y + 16 q] )[m] - a radix-4 decimation-in-frequency step formed while reading
+//            LDS, then cfft_dif<16> in 32 registers.  The two real columns (fx = 0, 32: phase 0) take one wave: lane groups (column, half) with
+//            half E: the even fy as rfft_fwd<32>(u[y] + u[y + 32]), half D: the odd fy as the complex 16-point FFT of the real split.
+constexpr int T64 = 64, ROWS64 = 4096;
+__host__ __device__ __forceinline__ int64_t sp_item64(int64_t item) { return pcnn_spec::sp_item(item, ROWS64); }
+
+// virtual work item v of the persistent grid -> (tile-and-group index, 16-channel half): v and v + 8 are the two halves of one 32-channel group
+__device__ __forceinline__ void item64(int v, int& tg, int& hf) { tg = (v >> 4) * 8 + (v & 7); hf = (v >> 3) & 1; }
+
+// what a wave keeps of an item between requesting its window rows and consuming them
+struct FwdItem64 {
+  const float* img;      // uniform: image n
+  int cl, cr;            // uniform: window columns x < cl or x >= cr are constant padding
+  int xlim;              // uniform: columns >= xlim are zero
+  unsigned voff;         // lane = window column x: float offset of that column's source pixel in an image row (tf.pad index map applied)
+};
+struct FwdRow64 {
+  float fill;            // lane: value of a row that is not read from memory (0: beyond ylim / no such channel; the padding constant)
+  unsigned lo;           // lane: float offset of (source row, channel)
+  bool use_fill;         // lane
+  bool fetch;            // uniform: at least one of the unit's four rows is read from memory
+};
+
+// describes virtual item v (window, column map) and the unit's row y (lane: y = 4 unit + lane group)
+__device__ __forceinline__ void fwd64_describe(const FwdParams& p, int v, int lane, int c16, FwdItem64& it, FwdRow64 (&row)[2], int unit0) {
+  int tg, hf;
+  item64(v, tg, hf);
+  const int g = tg % p.groups;
+  int t = p.tile0 + tg / p.groups;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int cc = 16 * hf + c16, chan = g * p.cstride + cc;
+  const bool cok = cc < p.cvalid && chan < p.C;
+  it.img = p.x + (int64_t)n * p.H * p.W * p.ld;
+  const int wy0 = ty * p.Vy - p.oy, wx0 = tx * p.Vx - p.ox;
+  const int ylim = min(p.ylim, p.ext_y - ty * p.Vy);
+  it.xlim = min(p.xlim, p.ext_x - tx * p.Vx);
+  it.cl = 0; it.cr = T64;
+  if (p.pad_mode == PCNN_PAD_CONSTANT) { it.cl = -wx0; it.cr = p.W - wx0; }
+  // the column map is the same for every row and lane of the item: lane x forms entry x ONCE (vector selects), the loads read it back as a
+  // scalar (v_readlane) and add it to the uniform image pointer - interior and boundary windows take the same path, one load + three scalar
+  // instructions per pixel, and no index arithmetic per load
+  it.voff = (unsigned)(pad_sel(wx0 + lane, p.W, p.pad_mode) * p.ld);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int y = 4 * (unit0 + u) + (lane >> 4);
+    const int gy = wy0 + y;
+    const bool rowconst = p.pad_mode == PCNN_PAD_CONSTANT && (unsigned)gy >= (unsigned)p.H;
+    const bool rowzero = !cok || y >= ylim;
+    row[u].use_fill = rowzero || rowconst;
+    row[u].fill = rowzero ? 0.f : p.pad_value;
+    row[u].fetch = 4 * (unit0 + u) < ylim;
+    row[u].lo = (unsigned)(pad_sel(gy, p.H, p.pad_mode) * p.W * p.ld) + (unsigned)(cok ? chan : 0);
+  }
+}
+
+// requests the two window rows of this wave's units: always-valid addresses; padding and masks are applied on consumption
+__device__ __forceinline__ void fwd64_request(const FwdItem64& it, const FwdRow64 (&row)[2], float (&R)[2][64]) {
+#pragma unroll
+  for (int x = 0; x < T64; ++x) {
+    const float* rp = it.img + (unsigned)__builtin_amdgcn_readlane((int)it.voff, x);
+    R[0][x] = row[0].fetch ? rp[row[0].lo] : 0.f;                      // (defined on every path: otherwise R is carried around the item loop)
+    R[1][x] = row[1].fetch ? rp[row[1].lo] : 0.f;
+  }
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void fwd64_consume(const FwdParams& p, const FwdItem64& it, const FwdRow64& row, float (&R)[64]) {
+#pragma unroll
+  for (int x = 0; x < T64; ++x) {
+    float v = R[x];
+    if (x < it.cl || x >= it.cr) v = p.pad_value;
+    if (row.use_fill) v = row.fill;
+    if (MASKED && x >= it.xlim) v = 0.f;
+    R[x] = v;
+  }
+}
+
+// tw: this lane's row of the twiddle table in LDS, tw[2 y] + i tw[2 y + 1] = W64^(cl y) (gfx950 VOP3 selects take no literal operands: as a select
+// chain over compile-time constants the 90 twiddles sit in 90 registers)
+__device__ __forceinline__ void y64_gather(const float* ur, const float* ui, int cl, float isign, const float* tw, float* vr, float* vi) {
+  const bool odd = cl & 1;
+  const float sg2 = odd ? -1.f : 1.f;                                // a = u0 + sg2 u2, w = u1 + sg2 u3
+  const float s = (cl & 2) ? -1.f : 1.f;                             // v = a + s b,  b = w (cl even) | -i w (cl odd; with s: cl = 1: -i w, cl = 3: +i w)
+#pragma unroll
+  for (int y = 0; y < 16; ++y) {
+    const float u0r = ur[y * 512], u1r = ur[(y + 16) * 512], u2r = ur[(y + 32) * 512], u3r = ur[(y + 48) * 512];
+    const float u0i = isign * ui[y * 512], u1i = isign * ui[(y + 16) * 512], u2i = isign * ui[(y + 32) * 512], u3i = isign * ui[(y + 48) * 512];
+    const float ar = fma_(sg2, u2r, u0r), ai = fma_(sg2, u2i, u0i);
+    const float wr_ = fma_(sg2, u3r, u1r), wi_ = fma_(sg2, u3i, u1i);
+    const float br = odd ? wi_ : wr_, bi = odd ? -wr_ : wi_;
+    const float xr = fma_(s, br, ar), xi = fma_(s, bi, ai);
+    if (y == 0) { vr[0] = xr; vi[0] = xi; }
+    else {
+      const float tr = tw[2 * y], ti = tw[2 * y + 1];
+      vr[y] = fma_(xr, tr, -(xi * ti));
+      vi[y] = fma_(xr, ti, xi * tr);
+    }
+    if (y & 1) __builtin_amdgcn_sched_barrier(0);                    // batches of two rows: 16 LDS operands in flight, not 128
+  }
+}
+
+// 8 waves of up to 256 registers, two units per wave and phase (unit u of wave w: window rows 4 (2w + u) + lane group, column 2w + u): the
+// whole next item (two rows of 64 values per lane) is requested while the second y phase runs.  (A 16-wave build of the same phases - 128
+// registers - cannot hold a row of 64 beside the y-axis state: it spilled 50-110 registers in every arrangement tried.)
+template <bool MASKED>
+__global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) {
+  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*16 + c16], y < 64, s < 32: one x-parity phase
+  const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntg = p.ntile * p.groups;
+  int v = blockIdx.x;
+  if (v >= nvirt) return;
+  float* const TW = U + 64 * 32 * 16;                                // W64^(cl y), cl < 4, y < 16: 128 floats behind the phase image
+  if (tid < 64) { TW[2 * tid] = cos64(((tid >> 4) * (tid & 15)) & 63); TW[2 * tid + 1] = -sin64(((tid >> 4) * (tid & 15)) & 63); }
+  const float* const tw = TW + lg * 32;
+  float R[2][64];
+  FwdItem64 cur;
+  FwdRow64 row[2];
+  // the padded tail of the virtual item list (tg >= ntg) runs as a copy of a real item that stores nothing: the workgroup keeps its barriers
+  auto safe = [&](int vv) { int tg, hf; item64(vv, tg, hf); return tg < ntg ? vv : (vv & 8); };
+  auto request = [&](int vv) {
+    fwd64_describe(p, safe(vv), lane, c16, cur, row, 2 * wave);
+    fwd64_request(cur, row, R);
+  };
+  static_assert(true, "");
+  for (;;) {
+    const int next = v + gridDim.x;
+    const bool more = next < nvirt;
+    // No register prefetch of the next item (128 values per lane beside the y-axis state: 60-110 spilled registers in every arrangement tried).  While
+    // this workgroup waits for its burst of loads, its own spectrum stores are still draining and the other CUs keep HBM busy.
+    request(v);
+    // ---- x axis: the whole real FFT of this lane's two rows.  The ODD bins go through LDS first (16 complex columns, every unit the same path)
+    // while the even bins wait in R[u][0..32).
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_sched_barrier(0);                                 // one unit after the other: interleaved, the two transforms need twice the registers
+      fwd64_consume<MASKED>(p, cur, row[u], R[u]);
+      rfft_fwd<64>(R[u]);
+      pin<32>(R[u]);
+      float* urow = U + ((4 * (2 * wave + u) + lg) * 32) * 16 + c16;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {                                     // C[m] = X[4m + 1]: Re at s = m, Im at s = 16 + m
+        urow[m * 16] = R[u][32 + bitrev(m, 16)];
+        urow[(16 + m) * 16] = R[u][48 + bitrev(m, 16)];
+      }
+    }
+    lds_barrier();
+    int tg, hf;
+    item64(v, tg, hf);
+    const bool store = tg < ntg;
+    float* out = p.sp + sp_item64(store ? tg : 0) + 16 * hf;              // uniform; the lane adds (class row) * RS + c16
+    int cl = lg;
+    asm volatile("" : "+v"(cl));                                     // opaque: the per-lane constants of a phase are formed in the phase, not hoisted
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // ---- y axis, odd fx.  column index q = 2 wave + u: fx = 2q + 1; q even: fx = 4j + 1 = C[j] (j = q / 2); q odd: fx = 4j + 3 = conj C[15 - j]
+      __builtin_amdgcn_sched_barrier(0);
+      const int q = 2 * wave + u;
+      const int mcol = (q & 1) ? 15 - (q >> 1) : (q >> 1);
+      float V[32];
+      float* vr = V, *vi = V + 16;
+      y64_gather(U + mcol * 16 + c16, U + (16 + mcol) * 16 + c16, cl, (q & 1) ? -1.f : 1.f, tw, vr, vi);
+      cfft_dif<16, -1>(vr, vi);
+      if (store) {
+        float* o = out + (128 + 128 * (2 * q)) * RS;
+        const unsigned lo = (unsigned)(cl * RS + c16);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          NT_STORE(1, vr[bitrev(m, 16)], &(o + ((4 * m) * RS))[lo]);
+          NT_STORE(1, vi[bitrev(m, 16)], &(o + ((64 + 4 * m) * RS))[lo]);
+        }
+      }
+    }
+    lds_barrier();                                                       // the odd phase has been read: U is free
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float* urow = U + ((4 * (2 * wave + u) + lg) * 32) * 16 + c16;
+      float (&E)[32] = *reinterpret_cast<float (*)[32]>(&R[u][0]);
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) urow[s2 * 16] = hc_get(E, s2);     // s <= 16: Re X[2s], s > 16: Im X[2 (s - 16)]
+    }
+    lds_barrier();
+    asm volatile("" : "+v"(cl));
+    // ---- y axis, even fx.  q = 0..14: complex column fx = 2 (q + 1) (Re at s = q + 1, Im at s = 17 + q); q = 15: the two real columns
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int q = 2 * wave + u;
+      float V[32];
+      float* vr = V, *vi = V + 16;
+      if (q < 15) {
+        y64_gather(U + (q + 1) * 16 + c16, U + (17 + q) * 16 + c16, cl, 1.f, tw, vr, vi);
+        cfft_dif<16, -1>(vr, vi);
+        if (store) {
+          float* o = out + (128 + 128 * (2 * (q + 1) - 1)) * RS;
+          const unsigned lo = (unsigned)(cl * RS + c16);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) {
+            NT_STORE(1, vr[bitrev(m, 16)], &(o + ((4 * m) * RS))[lo]);
+            NT_STORE(1, vi[bitrev(m, 16)], &(o + ((64 + 4 * m) * RS))[lo]);
+          }
+        }
+      } else {
+        // lane groups: (column fx = 0, E), (0, D), (32, E), (32, D).  E: even fy = real FFT of u[y] + u[y + 32]; D: odd fy by the real split
+        const float* uu = U + ((cl & 2) ? 16 : 0) * 16 + c16;
+        float* o = out;
+        const unsigned lo = (unsigned)(((cl & 2) ? 64 : 0) * RS + c16);
+        if ((cl & 1) == 0) {
+#pragma unroll
+          for (int yy = 0; yy < 32; ++yy) V[yy] = uu[yy * 512] + uu[(yy + 32) * 512];
+          rfft_fwd<32>(V);
+          if (store) {
+#pragma unroll
+            for (int k = 0; k <= 16; ++k) NT_STORE(1, hc_get(V, k), &(o + ((2 * k) * RS))[lo]);                 // Re Z[2k] -> row 2k
+#pragma unroll
+            for (int k = 1; k < 16; ++k) NT_STORE(1, hc_get(V, 16 + k), &(o + ((32 + 2 * k) * RS))[lo]);        // Im Z[2k] -> row 32 + 2k
+          }
+        } else {
+          // d[n] = u[n] - u[n + 32]; c[n] = (d[n] - i d[n + 16]) W64^n, n < 16; C[m] = Z[4m + 1]; Z[4m + 3] = conj C[15 - m]
+#pragma unroll
+          for (int n2 = 0; n2 < 16; ++n2) {
+            const float dr = uu[n2 * 512] - uu[(n2 + 32) * 512], di = uu[(n2 + 48) * 512] - uu[(n2 + 16) * 512];
+            mul_tw<64, -1>(n2, dr, di, vr[n2], vi[n2]);
+          }
+          cfft_dif<16, -1>(vr, vi);
+          if (store) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+              NT_STORE(1, vr[bitrev(m, 16)], &(o + ((4 * m + 1) * RS))[lo]);
+              NT_STORE(1, vi[bitrev(m, 16)], &(o + ((32 + 4 * m + 1) * RS))[lo]);
+              NT_STORE(1, vr[bitrev(15 - m, 16)], &(o + ((4 * m + 3) * RS))[lo]);
+              NT_STORE(1, -vi[bitrev(15 - m, 16)], &(o + ((32 + 4 * m + 3) * RS))[lo]);
+            }
+          }
+        }
+      }
+    }
+    if (!more) break;
+    v = __builtin_amdgcn_readfirstlane(next);
+    lds_barrier();                                                       // U is free for the next item
+  }
+}
+
+constexpr size_t LDS64_BYTES = LDS_BYTES + 128 * sizeof(float);       // + the twiddle table of the radix-4 step
 template <typename K>
-void set_lds(K kernel) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES); }
+void set_lds(K kernel, size_t bytes = LDS_BYTES) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
 template <bool TANH, bool RES, bool POST>
 void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
@@ -386,6 +646,21 @@ void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
   } else {
     set_lds(fft32_fwd_kernel<false>);
     hipLaunchKernelGGL((fft32_fwd_kernel<false>), grid, dim3(1024), LDS_BYTES, h->stream, p);
+  }
+}
+
+void launch_fwd_fft64(pcnn_handle h, FwdParams p, int ntile) {
+  p.ntile = ntile;
+  const int ntg = ntile * p.groups;
+  const int nvirt = 2 * ((ntg + 7) & ~7);                            // (tile-and-group) x two 16-channel halves, in blocks of 8 + 8 (item64)
+  const dim3 grid((unsigned)std::min((nvirt + 15) & ~15, 256));
+  const bool masked = p.ylim < T64 || p.xlim < T64 || p.ext_y < (1 << 29) || p.ext_x < (1 << 29);
+  if (masked) {
+    set_lds(fft64_fwd_kernel<true>, LDS64_BYTES);
+    hipLaunchKernelGGL((fft64_fwd_kernel<true>), grid, dim3(512), LDS64_BYTES, h->stream, p, nvirt);
+  } else {
+    set_lds(fft64_fwd_kernel<false>, LDS64_BYTES);
+    hipLaunchKernelGGL((fft64_fwd_kernel<false>), grid, dim3(512), LDS64_BYTES, h->stream, p, nvirt);
   }
 }
 

@@ -120,3 +120,86 @@ def test_layer_results_of_the_two_transforms_agree():
         ops.set_spectral_mode(prev_m); ops.set_spectral_transform(prev_x); ops.set_spectral_tile(prev_t)
     for a, b in zip(res['fft'], res['mfma']):
         assert 0 <= float((a - b).norm() / b.norm()) < 1e-6
+
+
+def _layout64(X):
+    """The 4096 spectrum rows of one 64 x 64 window (csrc/spectral_common.h) from its full complex 2-D DFT X[fy][fx][c]."""
+    C = X.shape[2]
+    out = np.zeros((4096, C))
+    for base, fx in ((0, 0), (64, 32)):                                  # the two real columns: half-complex along y
+        out[base:base + 33] = X[0:33, fx].real
+        out[base + 33:base + 64] = X[1:32, fx].imag
+    for fx in range(1, 32):
+        out[128 + 128 * (fx - 1):128 + 128 * (fx - 1) + 64] = X[:, fx].real
+        out[128 + 128 * (fx - 1) + 64:128 + 128 * fx] = X[:, fx].imag
+    return out
+
+
+@pytest.mark.parametrize('ylim,xlim,C', [(64, 64, 32), (64, 64, 20), (50, 50, 32), (37, 64, 7), (15, 15, 64), (64, 64, 48)])
+def test_forward_spectra_64_every_row_against_numpy_and_the_matrix_core_form(ylim, xlim, C):
+    """The 64-point forward transform as in-register FFTs (fft64_fwd_kernel: 16-channel items, two x-parity phases through LDS, radix-4 step on the y
+    axis) writes, for ONE window, every one of the 4 096 spectrum rows that numpy's FFT predicts (layout: csrc/spectral_common.h) and agrees with the
+    matrix-core kernels row by row - full and masked windows, ragged channel groups (the 16-channel halves of a 20- / 7- / 48-channel image)."""
+    from poisson_cnn_amd import ops
+    from poisson_cnn_amd.ops import _p
+    g = torch.Generator(device='cuda').manual_seed(ylim + C)
+    x = torch.randn(64, 64, C, device='cuda', generator=g)
+    groups = (C + 31) // 32
+
+    def spectrum(xf):
+        prev = ops.get_spectral_transform()
+        ops.set_spectral_transform(xf)
+        try:
+            out = torch.full((groups * 4096, 32), float('nan'), device='cuda')
+            ops.handle().call('pcnn_debug_tile_spectrum64', 64, 64, C, _p(x), ylim, xlim, _p(out))
+            torch.cuda.synchronize()
+            return out.cpu().numpy().astype(np.float64)
+        finally:
+            ops.set_spectral_transform(prev)
+    ref, got = spectrum('mfma'), spectrum('fft')
+    xm = x.cpu().numpy().astype(np.float64).copy()
+    xm[ylim:, :, :] = 0
+    xm[:, xlim:, :] = 0
+    X = np.fft.fft2(xm, axes=(0, 1))
+    scale = np.abs(X).max()
+    for gi in range(groups):
+        c0, c1 = 32 * gi, min(C, 32 * gi + 32)
+        want = _layout64(X[:, :, c0:c1])
+        blk = got[4096 * gi:4096 * (gi + 1)]
+        assert np.isfinite(blk).all()
+        assert np.abs(blk[:, :c1 - c0] - want).max() < 2e-6 * scale
+        assert c1 - c0 == 32 or np.abs(blk[:, c1 - c0:]).max() == 0.0    # channels that do not exist: zero spectrum rows
+        assert np.abs(blk - ref[4096 * gi:4096 * (gi + 1)]).max() < 2e-6 * scale
+
+
+@pytest.mark.parametrize('k,Cin,Cout,H,W,mode', [(15, 32, 32, 150, 131, 'CONSTANT'), (13, 28, 28, 75, 140, 'SYMMETRIC'), (11, 16, 32, 128, 128, 'REFLECT'), (9, 24, 40, 70, 201, 'CONSTANT')])
+def test_layers_on_64_point_tiles_through_the_fft_forward_transform(k, Cin, Cout, H, W, mode):
+    """Whole layers on 64-point tiles with the FFT forward transform (boundary and interior windows, several tiles, N > 1): forward, weight gradient and
+    fused backward against torch-CPU fp64 at the tolerances of the matrix-core route."""
+    import torch.nn.functional as F
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(k + Cin)
+    N, p = 2, k // 2
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    dz = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    tmode = {'CONSTANT': 'constant', 'SYMMETRIC': 'symmetric', 'REFLECT': 'reflect'}[mode]
+    xp = torch.tensor(np.pad(x.astype(np.float64), ((0, 0), (0, 0), (p, p), (p, p)), mode=tmode), requires_grad=True)
+    y = F.conv2d(xp, wt.permute(3, 2, 0, 1))
+    (y * torch.tensor(dz, dtype=torch.float64)).sum().backward()
+    xd = torch.tensor(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), device='cuda')
+    dzd = torch.tensor(np.ascontiguousarray(dz.transpose(0, 2, 3, 1)), device='cuda')
+    wd = torch.tensor(w, device='cuda')
+    prev_m, prev_x, prev_t = ops.get_spectral_mode(), ops.get_spectral_transform(), ops.get_spectral_tile()
+    ops.set_spectral_mode('force'); ops.set_spectral_transform('fft'); ops.set_spectral_tile(64)
+    try:
+        got = ops.conv2d_fwd(xd, wd, None, pad_top=p, pad_left=p, pad_mode=mode).cpu().numpy().transpose(0, 3, 1, 2)
+        ref = y.detach().numpy()
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-6
+        if Cout <= 32:
+            dw = ops.conv2d_wgrad(xd, dzd, w.shape, pad_top=p, pad_left=p, pad_mode=mode).cpu().numpy()
+            assert np.linalg.norm(dw - wt.grad.numpy()) / np.linalg.norm(wt.grad.numpy()) < 5e-6
+    finally:
+        ops.set_spectral_mode(prev_m); ops.set_spectral_transform(prev_x); ops.set_spectral_tile(prev_t)
