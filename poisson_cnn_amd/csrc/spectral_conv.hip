@@ -870,7 +870,7 @@ void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
 }
 void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
   p.ntile = ntile; p.tab = gm.tab;
-  if (gm.T == 64) { launch_inv64(h, p, ntile); return; }
+  if (gm.T == 64) { if (h->spectral_xform == PCNN_XFORM_FFT) launch_inv_fft64(h, p, ntile); else launch_inv64(h, p, ntile); return; }
   if (h->spectral_xform == PCNN_XFORM_FFT) { launch_inv_fft32(h, p, ntile); return; }
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)
@@ -1289,7 +1289,8 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
     hipLaunchKernelGGL(spec_wmix_kernel, dim3(nslot, S / 4, gx), dim3(256), 0, h->stream, wm);
   }
   if (post && post->dbias) {
-    if (Tg == 64) launch_post_bias64(h, bsum, 256, dg->Cout, post->dbias);
+    if (Tg == 64 && h->spectral_xform == PCNN_XFORM_FFT) launch_post_bias_fft64(h, bsum, 256, dg->Cout, post->dbias);
+    else if (Tg == 64) launch_post_bias64(h, bsum, 256, dg->Cout, post->dbias);
     else hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * (h->spectral_xform == PCNN_XFORM_FFT ? FFT_WAVES : 8), pack, cpt, post->dbias);
   }
   float* csp = wsp;                                      // the filter spectrum is no longer needed: every mixing launch above has read it (same stream)

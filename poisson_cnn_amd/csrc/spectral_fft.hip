@@ -624,6 +624,241 @@ __global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ 64-point inverse + epilogue
+// The mirror image: item = (tile, 16 channels), 8 waves x 2 units.  Per x-parity phase (odd fx first, then even fx): unit q owns one column - lane
+// group = class cl of the INPUT frequencies fy = 4m + cl: 32 spectrum loads per lane, G_cl[y] = conj(W64^(cl y)) IFFT16(Z[4m + cl])[y] into LDS (four
+// class planes of 16 rows); then unit q owns output rows 4q .. 4q + 3 (lane group = row): u[y + 16 j] = sum_cl i^(j cl) G_cl[y] - the radix-4 decimation-
+// in-time step, formed while reading LDS - lands in its place of the row's rfft_inv<64> input.  The two real columns fx = 0 / 32 are ONE complex column
+// Z = A + i B (their Hermitian halves are read back from the half-complex rows), so every unit runs the same code.  After both phases: rfft_inv<64> of
+// the row in registers and the fused convolution epilogue of spec64_inv_kernel.
+constexpr int G_YS = 528, G_CS = 16 * G_YS + 16;                     // floats between rows / class planes of the LDS image (odd multiples of 16: no bank conflicts)
+constexpr size_t LDS64I_BYTES = (4 * G_CS + 128) * sizeof(float);
+
+template <bool TANH, bool RES, bool POST>
+__global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) {
+  extern __shared__ __attribute__((aligned(16))) float G[];          // G[cl * G_CS + y * G_YS + s * 16 + c16], y < 16, s < 32
+  const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntg = p.ntile * p.groups;
+  int v = blockIdx.x;
+  if (v >= nvirt) return;
+  float* const TW = G + 4 * G_CS;                                    // W64^(cl y), cl < 4, y < 16
+  if (tid < 64) { TW[2 * tid] = cos64(((tid >> 4) * (tid & 15)) & 63); TW[2 * tid + 1] = -sin64(((tid >> 4) * (tid & 15)) & 63); }
+  const float* const tw = TW + lg * 32;
+  float ymax = 0.f, bsum = 0.f;
+  constexpr int BURST = (POST && RES) ? 8 : 16;
+  for (;;) {
+    const int next = v + gridDim.x;
+    int tg, hf;
+    item64(v, tg, hf);
+    const bool live = tg < ntg;                                      // the padded tail of the virtual item list: a copy of a real item that stores nothing
+    const float* in = p.sp + sp_item64(live ? tg : 0) + 16 * hf;      // uniform
+    float R[2][64];
+    int cl = lg;
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase) {                          // 0: odd fx (C[m] = X[4m + 1] of the rows), 1: even fx
+      lds_barrier();                                                     // the image of the previous phase / item has been read
+      asm volatile("" : "+v"(cl));                                   // opaque: per-lane constants are formed in the phase, not hoisted out of the item loop
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = 2 * wave + u;                                    // column index of the phase
+        float V[32];
+        float* vr = V, *vi = V + 16;
+        int sre;                                                       // s of the column's real part in the phase image (imaginary part: 16 + sre)
+        if (phase == 1 && q == 15) {
+          // the two real columns as one complex column Z = A + i B: A[fy] from rows [0, 64), B[fy] from rows [64, 128) (half-complex; fy > 32: the
+          // conjugate of 64 - fy)
+          sre = 0;
+          const unsigned lo = (unsigned)c16;
+#pragma unroll
+          for (int m = 0; m < 16; ++m) {
+            const int fy = 4 * m + cl, fp = fy <= 32 ? fy : 64 - fy;
+            const float sg = fy <= 32 ? 1.f : -1.f;
+            const bool hasim = fp != 0 && fp != 32;
+            const unsigned rr = (unsigned)(fp * RS), ri = (unsigned)((32 + (hasim ? fp : 1)) * RS);
+            const float ar = NT_LOAD(8, &in[lo + rr]), br = NT_LOAD(8, &(in + 64 * RS)[lo + rr]);
+            float ai = NT_LOAD(8, &in[lo + ri]), bi = NT_LOAD(8, &(in + 64 * RS)[lo + ri]);
+            ai = hasim ? sg * ai : 0.f; bi = hasim ? sg * bi : 0.f;
+            vr[m] = ar - bi; vi[m] = ai + br;
+          }
+        } else {
+          int fx;
+          if (phase == 0) {                                            // q even: fx = 4j + 1 -> C[j]; q odd: fx = 4j + 3 = conj C[15 - j]
+            fx = 2 * q + 1;
+            sre = (q & 1) ? 15 - (q >> 1) : (q >> 1);
+          } else { fx = 2 * (q + 1); sre = q + 1; }
+          const float* src = in + (128 + 128 * (fx - 1)) * RS;       // uniform
+          const unsigned lo = (unsigned)(cl * RS + c16);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) {
+            vr[m] = NT_LOAD(8, &(src + (4 * m) * RS)[lo]);
+            vi[m] = NT_LOAD(8, &(src + (64 + 4 * m) * RS)[lo]);
+          }
+        }
+        cfft_dif<16, +1>(vr, vi);                                      // register j: y = bitrev(j)
+        int goff = cl * G_CS + sre * 16 + c16;
+        asm volatile("" : "+v"(goff));                                 // opaque: LDS addresses are lane constants - left alone, ~100 of them are hoisted
+        float* g = G + goff;                                           // out of the item loop into registers of their own (everything else then spills)
+#pragma unroll
+        for (int y = 0; y < 16; ++y) {
+          const float ar = vr[bitrev(y, 16)], ai = vi[bitrev(y, 16)];
+          float gr, gi;
+          if (y == 0) { gr = ar; gi = ai; }
+          else {
+            const float tr = tw[2 * y], ti = -tw[2 * y + 1];          // conj(W64^(cl y))
+            gr = fma_(ar, tr, -(ai * ti));
+            gi = fma_(ar, ti, ai * tr);
+          }
+          g[y * G_YS] = gr;
+          g[y * G_YS + 256] = gi;                                      // s = 16 + sre
+        }
+      }
+      lds_barrier();
+      // ---- this unit's rows: u[y + 16 j] = sum_cl i^(j cl) G_cl[y], j = row >> 4 (uniform per unit), into the row's place of the x-axis inverse
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int unit = 2 * wave + u, j = unit >> 2;                  // rows 4 unit + lg = 16 j + y
+        const int y = (4 * unit + lg) & 15;
+        int goff = y * G_YS + c16;
+        asm volatile("" : "+v"(goff));                                 // opaque (see above)
+        const float* g0 = G + goff;
+        // i^(j cl): cl = 1: (1, i, -1, -i)[j]; cl = 2: (-1)^j; cl = 3: (1, -i, -1, i)[j]
+        const bool swp = j & 1;                                        // odd j: the cl = 1, 3 terms swap real and imaginary part
+        const float s2 = (j & 1) ? -1.f : 1.f;
+        const float s1r = (j == 0) ? 1.f : (j == 1 ? -1.f : (j == 2 ? -1.f : 1.f)), s1i = (j == 0) ? 1.f : (j == 1 ? 1.f : (j == 2 ? -1.f : -1.f));
+        const float s3r = (j == 0) ? 1.f : (j == 1 ? 1.f : (j == 2 ? -1.f : -1.f)), s3i = (j == 0) ? 1.f : (j == 1 ? -1.f : (j == 2 ? -1.f : 1.f));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float a0 = g0[k * 16], b0 = g0[k * 16 + 256];
+          const float a1 = g0[G_CS + k * 16], b1 = g0[G_CS + k * 16 + 256];
+          const float a2 = g0[2 * G_CS + k * 16], b2 = g0[2 * G_CS + k * 16 + 256];
+          const float a3 = g0[3 * G_CS + k * 16], b3 = g0[3 * G_CS + k * 16 + 256];
+          // i^j (a1 + i b1): j = 1: (-b1, a1), j = 2: (-a1, -b1), j = 3: (b1, -a1);  (-i)^j (a3 + i b3): j = 1: (b3, -a3), j = 2: (-a3, -b3), j = 3: (-b3, a3)
+          const float p1 = swp ? b1 : a1, q1 = swp ? a1 : b1, p3 = swp ? b3 : a3, q3 = swp ? a3 : b3;
+          float re = fma_(s2, a2, a0), im = fma_(s2, b2, b0);
+          re = fma_(s1r, p1, re); im = fma_(s1i, q1, im);
+          re = fma_(s3r, p3, re); im = fma_(s3i, q3, im);
+          asm volatile("" : "+v"(re), "+v"(im));                       // needed NOW: otherwise the sums are sunk to the x-axis transform and their 8 operands kept
+          if (phase == 0) {                                            // C[k]: Re at 32 + bitrev(k), Im at 48 + bitrev(k) of the rfft_inv<64> input;
+            R[u][32 + bitrev(k, 16)] = re;                             // k >= 8 came through the columns fx = 4j + 3 = conj C[15 - j]: conjugate the SUM
+            R[u][48 + bitrev(k, 16)] = k >= 8 ? -im : im;              // (the class terms carry factors i^(j cl): conjugation does not commute with them)
+          } else {                                                     // pair k: Re X[2k] | Im X[2k] (k = 1..15); k = 0: the real columns fx = 0 (re) and 32 (im)
+            float (&E)[32] = *reinterpret_cast<float (*)[32]>(&R[u][0]);
+            if (k == 0) { hc_put(E, 0, re); hc_put(E, 16, im); }
+            else { hc_put(E, k, re); hc_put(E, 16 + k, im); }
+          }
+          if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- x axis inverse of this lane's two output rows + the fused epilogue (lane = channel: per-channel constants are per-lane scalars)
+    {
+      const int g = tg % p.groups;
+      int t = p.tile0 + (live ? tg : 0) / p.groups;
+      const int tx = t % p.tiles_x; t /= p.tiles_x;
+      const int ty = t % p.tiles_y;
+      const int n = t / p.tiles_y;
+      const int y0 = ty * p.Vy, x0 = tx * p.Vx;
+      const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0);
+      const int cc = 16 * hf + c16, chan = g * p.cstride + cc;
+      const bool cok = live && cc < p.cvalid && chan < p.C;
+      const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
+      const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
+      const int sgn = p.flip ? -1 : 1;
+      const int64_t ipix = (int64_t)n * p.Ho * p.Wo;
+      float* yimg = p.y + ipix * p.ldy;
+      float* aimg = (!POST && p.act_out) ? p.act_out + ipix * p.ld_act : nullptr;
+      const float* rimg = RES ? p.res + ipix * p.ld_res : nullptr;
+      const float* gimg = POST ? p.gact + ipix * p.ld_gact : nullptr;
+      float* y2img = (POST && p.y2) ? p.y2 + ipix * p.ld_y2 : nullptr;
+      const unsigned chv = (unsigned)chan;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int unit = 2 * wave + u;
+        if (4 * unit >= vy) continue;                                  // uniform: none of the unit's four rows is an output row
+        const int yy = 4 * unit + lg;
+        rfft_inv<64>(R[u]);                                            // R[u][x] = 4096 * pixel (yy, x)
+        const int prow = p.flip ? p.Ho - 1 - y0 - yy : y0 + yy, pcol = p.flip ? p.Wo - 1 - x0 : x0;
+        unsigned pix0 = (unsigned)(prow * p.Wo + pcol);
+        asm volatile("" : "+v"(pix0));                               // opaque: per-pixel offsets are recomputed, not hoisted into registers per tensor
+        if (cok && yy < vy) {
+#pragma unroll
+          for (int x0b = 0; x0b < T64; x0b += BURST) {
+            float rv[BURST], gv[BURST];
+            if (RES) {
+#pragma unroll
+              for (int r = 0; r < BURST; ++r) {
+                const int xx = x0b + r;
+                rv[r] = rimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_res + chv];
+              }
+            }
+            if (POST) {
+#pragma unroll
+              for (int r = 0; r < BURST; ++r) {
+                const int xx = x0b + r;
+                gv[r] = gimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_gact + chv];
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < BURST; ++r) {
+              const int xx = x0b + r;
+              if (xx < vx) {
+                float val = R[u][xx] * (1.f / 4096.f);
+                const unsigned pix = pix0 + (unsigned)(sgn * xx);
+                if (!POST) {
+                  val += bias;
+                  val = TANH ? tanhf(val) : (val > 0.f ? val : val * p.alpha);
+                  if (aimg) aimg[pix * (unsigned)p.ld_act + chv] = val;
+                  val = val * sc + sh;
+                }
+                if (RES) val += rv[r];
+                if (POST) {
+                  if (y2img) y2img[pix * (unsigned)p.ld_y2 + chv] = val;
+                  const float gq = gv[r];
+                  val *= p.gmode == PCNN_ACT_TANH ? 1.f - gq * gq : (gq > 0.f ? 1.f : p.galpha);
+                  bsum += val;
+                }
+                yimg[pix * (unsigned)p.ldy + chv] = val;
+                ymax = fmaxf(ymax, fabsf(val));
+              }
+            }
+          }
+        }
+      }
+    }
+    if (next >= nvirt) break;
+    v = __builtin_amdgcn_readfirstlane(next);
+  }
+  if (POST && p.bsum) p.bsum[(blockIdx.x * 8 + wave) * 64 + lane] += bsum;    // own slot; a workgroup keeps ONE 16-channel half (the grid is a multiple of 16)
+  if (p.absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (lane == 0) {
+      const unsigned bits = __float_as_uint(ymax <= 3.0e38f ? ymax : 3.0e38f);
+      if (bits > __atomic_load_n(p.absmax, __ATOMIC_RELAXED)) atomicMax(p.absmax, bits);
+    }
+  }
+}
+
+// POST at 64 points: dbias[ch] from the lanes' partial sums, in a fixed order.  Channel ch = 16 hf + c16 lives in the workgroups with (block >> 3) & 1 == hf,
+// lanes with lane & 15 == c16 (four lane groups = four rows).  One workgroup per channel.
+__global__ __launch_bounds__(256) void fft64_post_bias_kernel(const float* __restrict__ bsum, int nblocks, float* __restrict__ dbias) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, t = threadIdx.x, hf = ch >> 4, c16 = ch & 15;
+  float a = 0.f;
+  for (int sl = t; sl < nblocks * 8 * 4; sl += 256) {                 // (block, wave, lane group)
+    const int lgq = sl & 3, bw = sl >> 2, block = bw >> 3;
+    if (((block >> 3) & 1) == hf) a += bsum[(size_t)bw * 64 + lgq * 16 + c16];
+  }
+  red[t] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
+  if (t == 0) dbias[ch] = red[0];
+}
+
 constexpr size_t LDS64_BYTES = LDS_BYTES + 128 * sizeof(float);       // + the twiddle table of the radix-4 step
 template <typename K>
 void set_lds(K kernel, size_t bytes = LDS_BYTES) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
@@ -662,6 +897,35 @@ void launch_fwd_fft64(pcnn_handle h, FwdParams p, int ntile) {
     set_lds(fft64_fwd_kernel<false>, LDS64_BYTES);
     hipLaunchKernelGGL((fft64_fwd_kernel<false>), grid, dim3(512), LDS64_BYTES, h->stream, p, nvirt);
   }
+}
+
+template <bool TANH, bool RES, bool POST>
+static void launch_inv64_t(pcnn_handle h, const InvParams& p, const dim3& grid, int nvirt) {
+  set_lds(fft64_inv_kernel<TANH, RES, POST>, LDS64I_BYTES);
+  hipLaunchKernelGGL((fft64_inv_kernel<TANH, RES, POST>), grid, dim3(512), LDS64I_BYTES, h->stream, p, nvirt);
+}
+
+void launch_inv_fft64(pcnn_handle h, InvParams p, int ntile) {
+  p.ntile = ntile;
+  const int ntg = ntile * p.groups;
+  const int nvirt = 2 * ((ntg + 7) & ~7);
+  const dim3 grid((unsigned)std::min((nvirt + 15) & ~15, 256));
+  if (p.gact) {
+    p.alpha = 1.f;
+    p.galpha = p.gmode == PCNN_ACT_LINEAR ? 1.f : (p.gmode == PCNN_ACT_RELU ? 0.f : p.galpha);
+    if (p.res) launch_inv64_t<false, true, true>(h, p, grid, nvirt); else launch_inv64_t<false, false, true>(h, p, grid, nvirt);
+    return;
+  }
+  if (p.act == PCNN_ACT_TANH) {
+    if (p.res) launch_inv64_t<true, true, false>(h, p, grid, nvirt); else launch_inv64_t<true, false, false>(h, p, grid, nvirt);
+  } else {
+    p.alpha = p.act == PCNN_ACT_LINEAR ? 1.f : (p.act == PCNN_ACT_RELU ? 0.f : p.alpha);
+    if (p.res) launch_inv64_t<false, true, false>(h, p, grid, nvirt); else launch_inv64_t<false, false, false>(h, p, grid, nvirt);
+  }
+}
+
+void launch_post_bias_fft64(pcnn_handle h, const float* bsum, int nblocks, int C, float* dbias) {
+  hipLaunchKernelGGL(fft64_post_bias_kernel, dim3((unsigned)C), dim3(256), 0, h->stream, bsum, nblocks, dbias);
 }
 
 void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile) {

@@ -10,15 +10,19 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def tile64_forced():
+@pytest.fixture(autouse=True, params=['mfma', 'fft'])
+def tile64_forced(request):
+    """Every test of this file runs through BOTH transform kernel families on 64-point tiles: the streamed DFT-as-GEMM kernels of csrc/spectral64.hip and
+    the in-register FFTs of csrc/spectral_fft.hip (fft64_fwd_kernel / fft64_inv_kernel, round 5)."""
     from poisson_cnn_amd import ops
-    prev = ops.get_spectral_mode(), ops.get_spectral_tile()
+    prev = ops.get_spectral_mode(), ops.get_spectral_tile(), ops.get_spectral_transform()
     ops.set_spectral_mode('force')
     ops.set_spectral_tile(64)
+    ops.set_spectral_transform(request.param)
     yield
     ops.set_spectral_mode(prev[0])
     ops.set_spectral_tile(prev[1])
+    ops.set_spectral_transform(prev[2])
 
 
 def rel(a, b):
