@@ -94,7 +94,8 @@ int pcnn_get_spectral_tile(pcnn_handle h);
  *   PCNN_XFORM_MFMA: the DFT as a GEMM on the matrix cores (v_mfma_f32_32x32x2_f32; csrc/spectral_conv.hip, spectral64.hip);
  *   PCNN_XFORM_FFT:  in-register FFTs on the vector ALUs, lane = channel (csrc/spectral_fft.hip, fft_regs.h): fp32 MFMA has no rate advantage
  *                    over the vector ALUs on gfx950, so the FFT needs ~9x fewer issue cycles, half the registers and twice the waves per CU.
- * Environment PCNN_SPEC_XFORM=fft|mfma sets the default of new handles. */
+ * Default: PCNN_XFORM_FFT (measured 20-30 % faster per layer at 8 x 1024^2, profiles/r05_probe_xform*.txt); environment PCNN_SPEC_XFORM=fft|mfma sets the
+ * default of new handles. */
 enum { PCNN_XFORM_MFMA = 0, PCNN_XFORM_FFT = 1 };
 int pcnn_set_spectral_transform(pcnn_handle h, int xform);
 int pcnn_get_spectral_transform(pcnn_handle h);

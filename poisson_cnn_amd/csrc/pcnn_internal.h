@@ -22,7 +22,7 @@ struct pcnn_handle_s {
   size_t aux_ws_bytes = 0;
   int spectral_mode = -1;         // PCNN_SPECTRAL_AUTO (cost model) / _OFF / _FORCE, see pcnn_set_spectral_mode
   int spectral_tile = 0;          // 0: per layer (pick_tile), 32 / 64: that tile size wherever the layer allows it, see pcnn_set_spectral_tile
-  int spectral_xform = 0;         // transform kernels of the spectral route: 0 = DFT as a GEMM on the matrix cores, 1 = in-register FFT on the vector ALUs (pcnn_set_spectral_transform)
+  int spectral_xform = 1;         // transform kernels of the spectral route: 1 = in-register FFT on the vector ALUs (default since round 5), 0 = DFT as a GEMM on the matrix cores (pcnn_set_spectral_transform)
   int retain = 0;                 // pcnn_set_workspace_retain: outgrown handle-owned buffers are kept (a captured hipGraph may still replay into them)
   std::vector<void*> retired;     // ... here, until pcnn_destroy
   void* comm = nullptr;           // RCCL communicator (ncclComm_t) of pcnn_comm_init, see collective.hip

@@ -918,8 +918,10 @@ int pick_tile(pcnn_handle h, const pcnn_conv_desc* d) {
   if (forced == 64) return 64;
   const int Vy = 65 - d->kh, Vx = 65 - d->kw;
   const int tiles = pcnn_cdiv(d->Ho, Vy) * pcnn_cdiv(d->Wo, Vx);
-  // 11 and 12 taps: ahead only on large images (1024^2, 16->32: 2.77 -> 2.66 ms forward, 4.48 -> 4.30 fused backward; 512^2: 0.80 -> 0.93)
-  if (d->kh >= 11 && d->kw >= 11 && d->kh < 13 && d->kw < 13) return tiles >= 256 ? 64 : 32;
+  // 11 and 12 taps: ahead only on large images (1024^2, 16->32: 2.77 -> 2.66 ms forward, 4.48 -> 4.30 fused backward; 512^2: 0.80 -> 0.93) - with the
+  // matrix-core transforms.  With the FFT transforms (round 5) the 32-point kernels gained more than the 64-point ones: 11 taps 2.16 vs 2.19 ms forward,
+  // 3.44 vs 3.47 fused backward at 8 x 1024^2 (profiles/r05_probe_xform32.txt / _xform64.txt) - 32-point tiles; 13 / 15 taps stay at 64 (2.70 -> 2.45, 3.22 -> 2.72).
+  if (d->kh >= 11 && d->kw >= 11 && d->kh < 13 && d->kw < 13) return (h->spectral_xform != PCNN_XFORM_FFT && tiles >= 256) ? 64 : 32;
   return (d->kh >= 13 && d->kw >= 13 && tiles >= 36) ? 64 : 32;
 }
 

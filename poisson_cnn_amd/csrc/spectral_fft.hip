@@ -279,7 +279,7 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
       const bool cok = cc < p.cvalid && chan < p.C;
       if (2 * wave < vy) {                                            // uniform: at least the even row of this wave is an output row
         const int yy = 2 * wave + half;
-        const bool rowok = cok && yy < vy;
+        const bool rowok = cok && yy < vy && vx > 0;                  // (vx <= 0: this lane's packed tile lies beyond the image - its first pixel does not exist)
         float X[32];
         {
           // u = E +- O in batches of eight entries: left alone, the scheduler requests all 64 operands first (64 registers beside the 32 of the

@@ -64,7 +64,7 @@ def get_spectral_tile():
 
 
 XFORMS = {'mfma': 0, 'fft': 1}
-_spectral_xform = XFORMS[{'f': 'fft', '1': 'fft'}.get(__import__('os').environ.get('PCNN_SPEC_XFORM', 'mfma')[:1], 'mfma')]
+_spectral_xform = XFORMS[{'m': 'mfma', '0': 'mfma'}.get(__import__('os').environ.get('PCNN_SPEC_XFORM', 'fft')[:1], 'fft')]      # default: the FFT kernels (round 5)
 
 
 def set_spectral_transform(xform):
