@@ -21,12 +21,23 @@
 #include "spectral_common.h"
 #include "fft_regs.h"
 #include <algorithm>
+#include <stdlib.h>
 
 #ifndef PCNN_NT
 #define PCNN_NT 17
 #endif
 #define NT_LOAD(bit, p) ((PCNN_NT & (bit)) ? __builtin_nontemporal_load(p) : *(p))
 #define NT_STORE(bit, v, p) do { if (PCNN_NT & (bit)) __builtin_nontemporal_store(v, p); else *(p) = (v); } while (0)
+
+// Removal studies (what a kernel costs without its loads / stores / arithmetic / LDS traffic) exist only in a diagnostic build: -DPCNN_FFT_STUDY, bits
+// from the environment variable PCNN_FFT_STUDY (1 no spectrum / pixel stores, 2 no global loads, 4 no FFT arithmetic, 8 no LDS reads, 16 no LDS
+// writes).  The shipped library compiles every test out.
+#ifdef PCNN_FFT_STUDY
+__constant__ int g_fft_study;
+#define FFT_STUDY(bit) (g_fft_study & (bit))
+#else
+#define FFT_STUDY(bit) 0
+#endif
 
 namespace pcnn_spec {
 
@@ -78,7 +89,7 @@ __device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int wa
   it.cl = 0; it.cr = T;
   const int wx_first = txg * p.pack * p.Vx - p.ox, wx_last = wx_first + (p.pack - 1) * p.Vx;
   it.fast = wx_first >= 0 && wx_last + T <= p.W;                               // uniform
-  if (2 * wave >= ylim) return;                                                // uniform: both rows of this wave are zero rows - nothing to fetch
+  if (2 * wave >= ylim || FFT_STUDY(2)) return;                                // uniform: both rows of this wave are zero rows - nothing to fetch
   const int sy = pad_sel(gy, p.H, p.pad_mode);
   const unsigned ch = (unsigned)(cok ? chan : 0);
   if (it.fast) {
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   // ---- x axis: this lane's window row, real -> half-complex, into LDS
   auto x_phase = [&]() {
     fwd_consume<MASKED>(p, cur, R);
-    rfft_fwd<32>(R);
+    if (!FFT_STUDY(4)) rfft_fwd<32>(R);
     float* u = U + (y * 32) * 32 + c;
 #pragma unroll
     for (int s = 0; s < T; ++s) u[s * 32] = hc_get(R, s);
@@ -160,11 +171,11 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
       const float* u = U + (half ? 16 : 0) * 32 + c;
 #pragma unroll
       for (int yy = 0; yy < T; ++yy) V[yy] = u[yy * 1024];
-      rfft_fwd<32>(V);
+      if (!FFT_STUDY(4)) rfft_fwd<32>(V);
       // (stores: uniform base + 32-bit lane offset + immediate - no 64-bit address per 4 KB window in vector registers)
       const unsigned lo = (unsigned)((half ? 32 : 0) * RS + c);
 #pragma unroll
-      for (int s = 0; s < T; ++s) NT_STORE(1, hc_get(V, s), &(out + (s * RS))[lo]);
+      for (int s = 0; s < T; ++s) if (!FFT_STUDY(1)) NT_STORE(1, hc_get(V, s), &(out + (s * RS))[lo]);
     } else {
       // complex column fx = wave; lane half = parity of the output frequencies: Z[2m + par] = FFT16( (u[y] +- u[y + 16]) W32^(par y) )[m]
       const float* ur = U + wave * 32 + c, *ui = U + (16 + wave) * 32 + c;
@@ -184,12 +195,13 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
           vi[yy] = fma_(ar, wi, ai * wr);
         }
       }
-      cfft_dif<16, -1>(vr, vi);
+      if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
       // register q holds Z[2 bitrev(q) + par]: spectrum rows 64 + 64 (fx - 1) + fy (real part), + 32 (imaginary part)
       float* o = out + (64 + 64 * (wave - 1)) * RS;                   // uniform
       const unsigned lo = (unsigned)(half * RS + c);
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
+        if (FFT_STUDY(1)) continue;
         NT_STORE(1, vr[bitrev(m, 16)], &(o + ((2 * m) * RS))[lo]);
         NT_STORE(1, vi[bitrev(m, 16)], &(o + ((32 + 2 * m) * RS))[lo]);
       }
@@ -202,6 +214,76 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ inverse transform + epilogue
+// The fused convolution epilogue of one output row held in registers (lane = channel: per-channel constants are per-lane scalars), NPIX pixels,
+// the first vx of them real.  bias -> activation -> act_out -> BN affine -> residual -> y, or - POST, the data-gradient launches - residual -> y2 ->
+// times act'(producer's activation) -> y, with the bias-gradient partial sum.
+// Written for the memory counter (vmcnt is in order, and a store's data register may not be rewritten before the store has read it):
+//   * per burst of BURST pixels: every input load first, then every value into a register OF ITS OWN, then the stores back to back;
+//   * NO store sits behind a branch: a pixel beyond vx re-stores the row's first pixel (same address, same value) - with a static number of memory
+//     operations per burst the compiler's waits name exactly what they need.  (First version: `if (x < vx) store` - every store in a basic block of
+//     its own, re-using one data register: an s_waitcnt vmcnt(0) per pixel, i.e. every store COMPLETED before the next pixel was formed; the
+//     64-point inverse spent half its time there - tools/study_fft.sh.)
+template <bool TANH, bool RES, bool POST, int NPIX, int BURST, bool NT>
+__device__ __forceinline__ void epilogue_row(const InvParams& p, const float* X, float scale, int vx, unsigned pix0, int sgn, unsigned chv, float bias, float sc, float sh,
+                                             float* yimg, float* aimg, const float* rimg, const float* gimg, float* y2img, float& ymax, float& bsum) {
+  auto st = [](float v, float* q) { if (NT) __builtin_nontemporal_store(v, q); else *q = v; };
+  float first_y = 0.f, first_a = 0.f, first_y2 = 0.f;              // what the row's first pixel stores (pixels beyond vx repeat it)
+#pragma unroll
+  for (int x0b = 0; x0b < NPIX; x0b += BURST) {
+    float rv[BURST], gv[BURST], oy[BURST], oa[BURST], oy2[BURST];
+    if (RES) {
+#pragma unroll
+      for (int r = 0; r < BURST; ++r) rv[r] = rimg[(pix0 + (unsigned)(x0b + r < vx ? sgn * (x0b + r) : 0)) * (unsigned)p.ld_res + chv];
+    }
+    if (POST) {
+#pragma unroll
+      for (int r = 0; r < BURST; ++r) gv[r] = gimg[(pix0 + (unsigned)(x0b + r < vx ? sgn * (x0b + r) : 0)) * (unsigned)p.ld_gact + chv];
+    }
+#pragma unroll
+    for (int r = 0; r < BURST; ++r) {
+      const bool ok = x0b + r < vx;
+      float v = X[x0b + r] * scale;
+      if (!POST) {                                                   // (a data-gradient launch has no bias, activation, BN or act_out)
+        v += bias;
+        v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
+        oa[r] = v;
+        v = v * sc + sh;
+      }
+      if (RES) v += rv[r];
+      if (POST) {
+        oy2[r] = v;
+        const float gq = gv[r];
+        v *= p.gmode == PCNN_ACT_TANH ? 1.f - gq * gq : (gq > 0.f ? 1.f : p.galpha);
+        bsum += ok ? v : 0.f;
+      }
+      oy[r] = v;
+      ymax = fmaxf(ymax, ok ? fabsf(v) : 0.f);
+      if (x0b + r == 0) { first_y = v; if (!POST) first_a = oa[0]; if (POST) first_y2 = oy2[0]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);                               // the values first, then the stores: nothing of the next burst in between
+    // (the optional second output is tested once per burst, not per pixel: a branch between two stores makes their number unknown to the waits)
+    float* const second = POST ? y2img : aimg;
+    const unsigned ld2 = (unsigned)(POST ? p.ld_y2 : p.ld_act);
+    if (second) {
+#pragma unroll
+      for (int r = 0; r < BURST; ++r) {
+        const bool ok = x0b + r < vx;
+        const unsigned pix = pix0 + (unsigned)(ok ? sgn * (x0b + r) : 0);
+        st(ok ? (POST ? oy2[r] : oa[r]) : (POST ? first_y2 : first_a), &second[pix * ld2 + chv]);
+        st(ok ? oy[r] : first_y, &yimg[pix * (unsigned)p.ldy + chv]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < BURST; ++r) {
+        const bool ok = x0b + r < vx;
+        const unsigned pix = pix0 + (unsigned)(ok ? sgn * (x0b + r) : 0);
+        st(ok ? oy[r] : first_y, &yimg[pix * (unsigned)p.ldy + chv]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // requests this wave's column of an item (`in`: its spectrum): wave 0 - lane half = real column 0 / 16, its 32 half-complex entries in row order;
 // wave fx - lane half = parity, B[m] = Re Z[2m + par], B[16 + m] = Im Z[2m + par] (spectrum rows 2j + par of the column's 64, j = 0..31).
 // ONE code path for both (a uniform row step on the scalar ALU): the prefetch registers then have a single definition point in the item loop.
@@ -210,8 +292,15 @@ __device__ __forceinline__ void inv_request(const float* in, int wave, int half,
   const int step = wave == 0 ? RS : 2 * RS;
   const unsigned lo = (unsigned)((wave == 0 ? 32 * RS : RS) * half + c);
 #pragma unroll
-  for (int j = 0; j < T; ++j) { B[j] = NT_LOAD(8, &sp[lo]); sp += step; }
+  for (int j = 0; j < T; ++j) { B[j] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &sp[lo]); sp += step; }
 }
+
+// Prefetch of the next item's spectrum column (32 registers that stay live through the x axis and the epilogue): with it the epilogue variants spill
+// 20-26 registers, and a spill costs more than the prefetch hides (scratch traffic shares the memory pipe) - off; measured both ways, DESIGN.md 4.8.
+#ifndef PCNN_INV32_PREFETCH
+#define PCNN_INV32_PREFETCH 0
+#endif
+constexpr bool INV32_PREFETCH = PCNN_INV32_PREFETCH;
 
 // TANH = false: linear / relu / leaky-relu as one select with the negative-side slope in p.alpha (1 / 0 / alpha)
 template <bool TANH, bool RES, bool POST>
@@ -223,22 +312,23 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
   int item = blockIdx.x;
   if (item >= total) return;
   float B[32];
-  inv_request(p.sp + sp_item32(item), wave, half, c, B);
+  if (INV32_PREFETCH) inv_request(p.sp + sp_item32(item), wave, half, c, B);
   float ymax = 0.f, bsum = 0.f;
-  constexpr int BURST = (POST && RES) ? 4 : ((POST || RES) ? 8 : 16); // pixels whose epilogue inputs are requested together, before any of their stores (registers: 128 per lane)
+  constexpr int BURST = (POST && RES) ? 4 : 8;                       // pixels per epilogue burst (registers: 128 per lane; epilogue_row keeps up to 5 values per pixel)
   for (;;) {
     const int next = item + gridDim.x;
     // ---- y axis inverse (unnormalised: the 1 / 1024 of both axes is applied once, after the x axis)
     {
       float V[32];
+      if (!INV32_PREFETCH) inv_request(p.sp + sp_item32(item), wave, half, c, B);
 #pragma unroll
       for (int i = 0; i < 32; ++i) V[i] = B[i];
-      if (next < total) inv_request(p.sp + sp_item32(next), wave, half, c, B);      // lands under the rest of this item
+      if (INV32_PREFETCH && next < total) inv_request(p.sp + sp_item32(next), wave, half, c, B);      // lands under the rest of this item
       if (wave == 0) {
         float W[32];
 #pragma unroll
         for (int s = 0; s < T; ++s) hc_put(W, s, V[s]);
-        rfft_inv<32>(W);                                             // W[y] = 32 u[y]
+        if (!FFT_STUDY(4)) rfft_inv<32>(W);                                             // W[y] = 32 u[y]
         float* e = U + (half ? 16 : 0) * 32 + c;
 #pragma unroll
         for (int yy = 0; yy < 16; ++yy) {
@@ -247,7 +337,7 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
         }
       } else {
         float* vr = V, *vi = V + 16;
-        cfft_dif<16, +1>(vr, vi);                                    // register q: E (par = 0) or O-before-twiddle (par = 1) at y = bitrev(q)
+        if (!FFT_STUDY(4)) cfft_dif<16, +1>(vr, vi);                                    // register q: E (par = 0) or O-before-twiddle (par = 1) at y = bitrev(q)
         float* er = U + (half ? EO : 0) + wave * 32 + c, *ei = er + 16 * 32;
         int par = half;
         asm volatile("" : "+v"(par));                                // opaque: the per-lane twiddle selects are formed here, not hoisted out of the item loop
@@ -293,7 +383,7 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        rfft_inv<32>(X);                                             // X[x] = 1024 * pixel (yy, x)
+        if (!FFT_STUDY(4)) rfft_inv<32>(X);                                             // X[x] = 1024 * pixel (yy, x)
         const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
         const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
         // addresses: a uniform IMAGE base per tensor plus an unsigned 32-bit lane offset (scalar base + vector offset form: no 64-bit address
@@ -309,51 +399,8 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
         const float* gimg = POST ? p.gact + ipix * p.ld_gact : nullptr;
         float* y2img = (POST && p.y2) ? p.y2 + ipix * p.ld_y2 : nullptr;
         const unsigned chv = (unsigned)chan;
-        if (rowok) {
-#pragma unroll
-          for (int x0b = 0; x0b < T; x0b += BURST) {
-            float rv[BURST], gv[BURST];
-            // the burst's inputs first, as unconditional loads (pixels beyond vx read the lane's first pixel): a load placed between stores is
-            // waited for together with the stores in front of it (in-order memory counter)
-            if (RES) {
-#pragma unroll
-              for (int r = 0; r < BURST; ++r) {
-                const int xx = x0b + r;
-                rv[r] = rimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_res + chv];
-              }
-            }
-            if (POST) {
-#pragma unroll
-              for (int r = 0; r < BURST; ++r) {
-                const int xx = x0b + r;
-                gv[r] = gimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_gact + chv];
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < BURST; ++r) {
-              const int xx = x0b + r;
-              if (xx < vx) {
-                float v = X[xx] * (1.f / 1024.f);
-                const unsigned pix = pix0 + (unsigned)(sgn * xx);
-                if (!POST) {                                           // (a data-gradient launch has no bias, activation, BN or act_out)
-                  v += bias;
-                  v = TANH ? tanhf(v) : (v > 0.f ? v : v * p.alpha);
-                  if (aimg) aimg[pix * (unsigned)p.ld_act + chv] = v;
-                  v = v * sc + sh;
-                }
-                if (RES) v += rv[r];
-                if (POST) {
-                  if (y2img) y2img[pix * (unsigned)p.ld_y2 + chv] = v;
-                  const float gq = gv[r];
-                  v *= p.gmode == PCNN_ACT_TANH ? 1.f - gq * gq : (gq > 0.f ? 1.f : p.galpha);
-                  bsum += v;
-                }
-                yimg[pix * (unsigned)p.ldy + chv] = v;
-                ymax = fmaxf(ymax, fabsf(v));
-              }
-            }
-          }
-        }
+        if (rowok && !FFT_STUDY(1))
+          epilogue_row<TANH, RES, POST, T, BURST, false>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
       }
     }
     if (next >= total) break;
@@ -403,7 +450,8 @@ struct FwdRow64 {
 };
 
 // describes virtual item v (window, column map) and the unit's row y (lane: y = 4 unit + lane group)
-__device__ __forceinline__ void fwd64_describe(const FwdParams& p, int v, int lane, int c16, FwdItem64& it, FwdRow64 (&row)[2], int unit0) {
+template <int NU>
+__device__ __forceinline__ void fwd64_describe_t(const FwdParams& p, int v, int lane, int c16, FwdItem64& it, FwdRow64 (&row)[2], int unit0) {
   int tg, hf;
   item64(v, tg, hf);
   const int g = tg % p.groups;
@@ -424,7 +472,7 @@ __device__ __forceinline__ void fwd64_describe(const FwdParams& p, int v, int la
   // instructions per pixel, and no index arithmetic per load
   it.voff = (unsigned)(pad_sel(wx0 + lane, p.W, p.pad_mode) * p.ld);
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int y = 4 * (unit0 + u) + (lane >> 4);
     const int gy = wy0 + y;
     const bool rowconst = p.pad_mode == PCNN_PAD_CONSTANT && (unsigned)gy >= (unsigned)p.H;
@@ -436,13 +484,13 @@ __device__ __forceinline__ void fwd64_describe(const FwdParams& p, int v, int la
   }
 }
 
-// requests the two window rows of this wave's units: always-valid addresses; padding and masks are applied on consumption
+// requests the window row of unit Un: always-valid addresses; padding and masks are applied on consumption
+template <int Un>
 __device__ __forceinline__ void fwd64_request(const FwdItem64& it, const FwdRow64 (&row)[2], float (&R)[2][64]) {
 #pragma unroll
   for (int x = 0; x < T64; ++x) {
     const float* rp = it.img + (unsigned)__builtin_amdgcn_readlane((int)it.voff, x);
-    R[0][x] = row[0].fetch ? rp[row[0].lo] : 0.f;                      // (defined on every path: otherwise R is carried around the item loop)
-    R[1][x] = row[1].fetch ? rp[row[1].lo] : 0.f;
+    R[Un][x] = (row[Un].fetch && !FFT_STUDY(2)) ? rp[row[Un].lo] : 0.f;                   // (defined on every path: otherwise R is carried around the item loop)
   }
 }
 
@@ -460,7 +508,9 @@ __device__ __forceinline__ void fwd64_consume(const FwdParams& p, const FwdItem6
 
 // tw: this lane's row of the twiddle table in LDS, tw[2 y] + i tw[2 y + 1] = W64^(cl y) (gfx950 VOP3 selects take no literal operands: as a select
 // chain over compile-time constants the 90 twiddles sit in 90 registers)
-__device__ __forceinline__ void y64_gather(const float* ur, const float* ui, int cl, float isign, const float* tw, float* vr, float* vi) {
+__device__ __forceinline__ void y64_gather(const float* U, int offr, int offi, int cl, float isign, const float* tw, float* vr, float* vi) {
+  asm volatile("" : "+v"(offr), "+v"(offi));                          // opaque: LDS addresses are lane constants - left alone they are hoisted out of the
+  const float* ur = U + offr, *ui = U + offi;                         // item loop, one register per 64 KB window and use
   const bool odd = cl & 1;
   const float sg2 = odd ? -1.f : 1.f;                                // a = u0 + sg2 u2, w = u1 + sg2 u3
   const float s = (cl & 2) ? -1.f : 1.f;                             // v = a + s b,  b = w (cl even) | -i w (cl odd; with s: cl = 1: -i w, cl = 3: +i w)
@@ -485,8 +535,16 @@ __device__ __forceinline__ void y64_gather(const float* ur, const float* ui, int
 // 8 waves of up to 256 registers, two units per wave and phase (unit u of wave w: window rows 4 (2w + u) + lane group, column 2w + u): the
 // whole next item (two rows of 64 values per lane) is requested while the second y phase runs.  (A 16-wave build of the same phases - 128
 // registers - cannot hold a row of 64 beside the y-axis state: it spilled 50-110 registers in every arrangement tried.)
-template <bool MASKED>
-__global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) {
+#ifndef PCNN_PF64_ONE
+#define PCNN_PF64_ONE 0
+#endif
+#ifndef PCNN_PF64_FULL
+#define PCNN_PF64_FULL 0
+#endif
+constexpr bool PF64_FULL = PCNN_PF64_FULL; // 8-wave form: request BOTH rows of the next item under the even y phase (128 registers in flight: spills ~60)
+constexpr bool PF64_ONE = PCNN_PF64_ONE;   // 16-wave form: request the next item's row under the even y phase (64 registers in flight)
+template <bool MASKED, int NU>
+__global__ __launch_bounds__(1024 / NU) void fft64_fwd_kernel(FwdParams p, int nvirt) {
   extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*16 + c16], y < 64, s < 32: one x-parity phase
   const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -501,28 +559,29 @@ __global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) 
   FwdRow64 row[2];
   // the padded tail of the virtual item list (tg >= ntg) runs as a copy of a real item that stores nothing: the workgroup keeps its barriers
   auto safe = [&](int vv) { int tg, hf; item64(vv, tg, hf); return tg < ntg ? vv : (vv & 8); };
-  auto request = [&](int vv) {
-    fwd64_describe(p, safe(vv), lane, c16, cur, row, 2 * wave);
-    fwd64_request(cur, row, R);
-  };
-  static_assert(true, "");
+  fwd64_describe_t<NU>(p, safe(v), lane, c16, cur, row, NU * wave);
+  if (NU == 2 || PF64_ONE) fwd64_request<0>(cur, row, R);
+  if (NU == 2 && PF64_FULL) fwd64_request<1>(cur, row, R);
   for (;;) {
     const int next = v + gridDim.x;
     const bool more = next < nvirt;
-    // No register prefetch of the next item (128 values per lane beside the y-axis state: 60-110 spilled registers in every arrangement tried).  While
-    // this workgroup waits for its burst of loads, its own spectrum stores are still draining and the other CUs keep HBM busy.
-    request(v);
+    // (unit 0's row was requested a phase ahead - below; unit 1's here: the registers cannot hold both beside the y-axis state)
+    if (NU == 2 && !PF64_FULL) fwd64_request<1>(cur, row, R);
+    else if (NU == 1 && !PF64_ONE) fwd64_request<0>(cur, row, R);
     // ---- x axis: the whole real FFT of this lane's two rows.  The ODD bins go through LDS first (16 complex columns, every unit the same path)
     // while the even bins wait in R[u][0..32).
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       __builtin_amdgcn_sched_barrier(0);                                 // one unit after the other: interleaved, the two transforms need twice the registers
       fwd64_consume<MASKED>(p, cur, row[u], R[u]);
-      rfft_fwd<64>(R[u]);
+      if (!FFT_STUDY(4)) rfft_fwd<64>(R[u]);
       pin<32>(R[u]);
-      float* urow = U + ((4 * (2 * wave + u) + lg) * 32) * 16 + c16;
+      int uoff = ((4 * (NU * wave + u) + lg) * 32) * 16 + c16;
+      asm volatile("" : "+v"(uoff));
+      float* urow = U + uoff;
 #pragma unroll
       for (int m = 0; m < 16; ++m) {                                     // C[m] = X[4m + 1]: Re at s = m, Im at s = 16 + m
+        if (FFT_STUDY(16)) continue;
         urow[m * 16] = R[u][32 + bitrev(m, 16)];
         urow[(16 + m) * 16] = R[u][48 + bitrev(m, 16)];
       }
@@ -530,20 +589,20 @@ __global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) 
     lds_barrier();
     int tg, hf;
     item64(v, tg, hf);
-    const bool store = tg < ntg;
+    const bool store = tg < ntg && !FFT_STUDY(1);
     float* out = p.sp + sp_item64(store ? tg : 0) + 16 * hf;              // uniform; the lane adds (class row) * RS + c16
     int cl = lg;
     asm volatile("" : "+v"(cl));                                     // opaque: the per-lane constants of a phase are formed in the phase, not hoisted
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       // ---- y axis, odd fx.  column index q = 2 wave + u: fx = 2q + 1; q even: fx = 4j + 1 = C[j] (j = q / 2); q odd: fx = 4j + 3 = conj C[15 - j]
       __builtin_amdgcn_sched_barrier(0);
-      const int q = 2 * wave + u;
+      const int q = NU * wave + u;
       const int mcol = (q & 1) ? 15 - (q >> 1) : (q >> 1);
       float V[32];
       float* vr = V, *vi = V + 16;
-      y64_gather(U + mcol * 16 + c16, U + (16 + mcol) * 16 + c16, cl, (q & 1) ? -1.f : 1.f, tw, vr, vi);
-      cfft_dif<16, -1>(vr, vi);
+      if (FFT_STUDY(8)) { for (int i = 0; i < 32; ++i) V[i] = 1.f; } else y64_gather(U, mcol * 16 + c16, (16 + mcol) * 16 + c16, cl, (q & 1) ? -1.f : 1.f, tw, vr, vi);
+      if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
       if (store) {
         float* o = out + (128 + 128 * (2 * q)) * RS;
         const unsigned lo = (unsigned)(cl * RS + c16);
@@ -556,24 +615,33 @@ __global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) 
     }
     lds_barrier();                                                       // the odd phase has been read: U is free
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float* urow = U + ((4 * (2 * wave + u) + lg) * 32) * 16 + c16;
+    for (int u = 0; u < NU; ++u) {
+      int uoff = ((4 * (NU * wave + u) + lg) * 32) * 16 + c16;
+      asm volatile("" : "+v"(uoff));
+      float* urow = U + uoff;
       float (&E)[32] = *reinterpret_cast<float (*)[32]>(&R[u][0]);
 #pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) urow[s2 * 16] = hc_get(E, s2);     // s <= 16: Re X[2s], s > 16: Im X[2 (s - 16)]
+      for (int s2 = 0; s2 < 32; ++s2) if (!FFT_STUDY(16)) urow[s2 * 16] = hc_get(E, s2);     // s <= 16: Re X[2s], s > 16: Im X[2 (s - 16)]
+    }
+    // R is free: unit 0's row of the next item is requested here and lands under the even y phase (both rows - 128 registers - beside the y-axis
+    // state spill 66 registers; during the odd phase the even bins still occupy 64)
+    if (more) {
+      fwd64_describe_t<NU>(p, safe(next), lane, c16, cur, row, NU * wave);
+      if (NU == 2 || PF64_ONE) fwd64_request<0>(cur, row, R);
+      if (NU == 2 && PF64_FULL) fwd64_request<1>(cur, row, R);
     }
     lds_barrier();
     asm volatile("" : "+v"(cl));
     // ---- y axis, even fx.  q = 0..14: complex column fx = 2 (q + 1) (Re at s = q + 1, Im at s = 17 + q); q = 15: the two real columns
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       __builtin_amdgcn_sched_barrier(0);
-      const int q = 2 * wave + u;
+      const int q = NU * wave + u;
       float V[32];
       float* vr = V, *vi = V + 16;
       if (q < 15) {
-        y64_gather(U + (q + 1) * 16 + c16, U + (17 + q) * 16 + c16, cl, 1.f, tw, vr, vi);
-        cfft_dif<16, -1>(vr, vi);
+        if (FFT_STUDY(8)) { for (int i = 0; i < 32; ++i) V[i] = 1.f; } else y64_gather(U, (q + 1) * 16 + c16, (17 + q) * 16 + c16, cl, 1.f, tw, vr, vi);
+        if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
         if (store) {
           float* o = out + (128 + 128 * (2 * (q + 1) - 1)) * RS;
           const unsigned lo = (unsigned)(cl * RS + c16);
@@ -585,13 +653,15 @@ __global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) 
         }
       } else {
         // lane groups: (column fx = 0, E), (0, D), (32, E), (32, D).  E: even fy = real FFT of u[y] + u[y + 32]; D: odd fy by the real split
-        const float* uu = U + ((cl & 2) ? 16 : 0) * 16 + c16;
+        int uuoff = ((cl & 2) ? 16 : 0) * 16 + c16;
+        asm volatile("" : "+v"(uuoff));
+        const float* uu = U + uuoff;
         float* o = out;
         const unsigned lo = (unsigned)(((cl & 2) ? 64 : 0) * RS + c16);
         if ((cl & 1) == 0) {
 #pragma unroll
           for (int yy = 0; yy < 32; ++yy) V[yy] = uu[yy * 512] + uu[(yy + 32) * 512];
-          rfft_fwd<32>(V);
+          if (!FFT_STUDY(4)) rfft_fwd<32>(V);
           if (store) {
 #pragma unroll
             for (int k = 0; k <= 16; ++k) NT_STORE(1, hc_get(V, k), &(o + ((2 * k) * RS))[lo]);                 // Re Z[2k] -> row 2k
@@ -605,7 +675,7 @@ __global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) 
             const float dr = uu[n2 * 512] - uu[(n2 + 32) * 512], di = uu[(n2 + 48) * 512] - uu[(n2 + 16) * 512];
             mul_tw<64, -1>(n2, dr, di, vr[n2], vi[n2]);
           }
-          cfft_dif<16, -1>(vr, vi);
+          if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
           if (store) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -634,6 +704,10 @@ __global__ __launch_bounds__(512) void fft64_fwd_kernel(FwdParams p, int nvirt) 
 constexpr int G_YS = 528, G_CS = 16 * G_YS + 16;                     // floats between rows / class planes of the LDS image (odd multiples of 16: no bank conflicts)
 constexpr size_t LDS64I_BYTES = (4 * G_CS + 128) * sizeof(float);
 
+#ifndef PCNN_ST64_NT
+#define PCNN_ST64_NT 1
+#endif
+#define ST64(v, p) do { if (PCNN_ST64_NT) __builtin_nontemporal_store(v, p); else *(p) = (v); } while (0)
 template <bool TANH, bool RES, bool POST>
 __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) {
   extern __shared__ __attribute__((aligned(16))) float G[];          // G[cl * G_CS + y * G_YS + s * 16 + c16], y < 16, s < 32
@@ -646,7 +720,7 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
   if (tid < 64) { TW[2 * tid] = cos64(((tid >> 4) * (tid & 15)) & 63); TW[2 * tid + 1] = -sin64(((tid >> 4) * (tid & 15)) & 63); }
   const float* const tw = TW + lg * 32;
   float ymax = 0.f, bsum = 0.f;
-  constexpr int BURST = (POST && RES) ? 8 : 16;
+  constexpr int BURST = 8;
   for (;;) {
     const int next = v + gridDim.x;
     int tg, hf;
@@ -677,8 +751,8 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
             const float sg = fy <= 32 ? 1.f : -1.f;
             const bool hasim = fp != 0 && fp != 32;
             const unsigned rr = (unsigned)(fp * RS), ri = (unsigned)((32 + (hasim ? fp : 1)) * RS);
-            const float ar = NT_LOAD(8, &in[lo + rr]), br = NT_LOAD(8, &(in + 64 * RS)[lo + rr]);
-            float ai = NT_LOAD(8, &in[lo + ri]), bi = NT_LOAD(8, &(in + 64 * RS)[lo + ri]);
+            const float ar = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &in[lo + rr]), br = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + 64 * RS)[lo + rr]);
+            float ai = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &in[lo + ri]), bi = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + 64 * RS)[lo + ri]);
             ai = hasim ? sg * ai : 0.f; bi = hasim ? sg * bi : 0.f;
             vr[m] = ar - bi; vi[m] = ai + br;
           }
@@ -692,11 +766,11 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
           const unsigned lo = (unsigned)(cl * RS + c16);
 #pragma unroll
           for (int m = 0; m < 16; ++m) {
-            vr[m] = NT_LOAD(8, &(src + (4 * m) * RS)[lo]);
-            vi[m] = NT_LOAD(8, &(src + (64 + 4 * m) * RS)[lo]);
+            vr[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(src + (4 * m) * RS)[lo]);
+            vi[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(src + (64 + 4 * m) * RS)[lo]);
           }
         }
-        cfft_dif<16, +1>(vr, vi);                                      // register j: y = bitrev(j)
+        if (!FFT_STUDY(4)) cfft_dif<16, +1>(vr, vi);                                      // register j: y = bitrev(j)
         int goff = cl * G_CS + sre * 16 + c16;
         asm volatile("" : "+v"(goff));                                 // opaque: LDS addresses are lane constants - left alone, ~100 of them are hoisted
         float* g = G + goff;                                           // out of the item loop into registers of their own (everything else then spills)
@@ -780,53 +854,12 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
         const int unit = 2 * wave + u;
         if (4 * unit >= vy) continue;                                  // uniform: none of the unit's four rows is an output row
         const int yy = 4 * unit + lg;
-        rfft_inv<64>(R[u]);                                            // R[u][x] = 4096 * pixel (yy, x)
+        if (!FFT_STUDY(4)) rfft_inv<64>(R[u]);                                            // R[u][x] = 4096 * pixel (yy, x)
         const int prow = p.flip ? p.Ho - 1 - y0 - yy : y0 + yy, pcol = p.flip ? p.Wo - 1 - x0 : x0;
         unsigned pix0 = (unsigned)(prow * p.Wo + pcol);
         asm volatile("" : "+v"(pix0));                               // opaque: per-pixel offsets are recomputed, not hoisted into registers per tensor
-        if (cok && yy < vy) {
-#pragma unroll
-          for (int x0b = 0; x0b < T64; x0b += BURST) {
-            float rv[BURST], gv[BURST];
-            if (RES) {
-#pragma unroll
-              for (int r = 0; r < BURST; ++r) {
-                const int xx = x0b + r;
-                rv[r] = rimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_res + chv];
-              }
-            }
-            if (POST) {
-#pragma unroll
-              for (int r = 0; r < BURST; ++r) {
-                const int xx = x0b + r;
-                gv[r] = gimg[(pix0 + (unsigned)(xx < vx ? sgn * xx : 0)) * (unsigned)p.ld_gact + chv];
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < BURST; ++r) {
-              const int xx = x0b + r;
-              if (xx < vx) {
-                float val = R[u][xx] * (1.f / 4096.f);
-                const unsigned pix = pix0 + (unsigned)(sgn * xx);
-                if (!POST) {
-                  val += bias;
-                  val = TANH ? tanhf(val) : (val > 0.f ? val : val * p.alpha);
-                  if (aimg) aimg[pix * (unsigned)p.ld_act + chv] = val;
-                  val = val * sc + sh;
-                }
-                if (RES) val += rv[r];
-                if (POST) {
-                  if (y2img) y2img[pix * (unsigned)p.ld_y2 + chv] = val;
-                  const float gq = gv[r];
-                  val *= p.gmode == PCNN_ACT_TANH ? 1.f - gq * gq : (gq > 0.f ? 1.f : p.galpha);
-                  bsum += val;
-                }
-                yimg[pix * (unsigned)p.ldy + chv] = val;
-                ymax = fmaxf(ymax, fabsf(val));
-              }
-            }
-          }
-        }
+        if (cok && yy < vy && !FFT_STUDY(1))
+          epilogue_row<TANH, RES, POST, T64, BURST, PCNN_ST64_NT != 0>(p, R[u], 1.f / 4096.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
       }
     }
     if (next >= nvirt) break;
@@ -872,7 +905,14 @@ void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
 }  // namespace
 
 // persistent kernels: one 16-wave workgroup per CU (128 KB of LDS) walking the (tile, channel group) items
+#ifdef PCNN_FFT_STUDY
+static void study_init() { static int once = 0; if (!once) { once = 1; const int v = getenv("PCNN_FFT_STUDY") ? atoi(getenv("PCNN_FFT_STUDY")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_study), &v, sizeof(int)); } }
+#else
+static void study_init() {}
+#endif
+
 void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
+  study_init();
   p.ntile = ntile;
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.ylim < T || p.xlim < T) {
@@ -886,16 +926,23 @@ void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
 
 void launch_fwd_fft64(pcnn_handle h, FwdParams p, int ntile) {
   p.ntile = ntile;
+  study_init();
   const int ntg = ntile * p.groups;
   const int nvirt = 2 * ((ntg + 7) & ~7);                            // (tile-and-group) x two 16-channel halves, in blocks of 8 + 8 (item64)
   const dim3 grid((unsigned)std::min((nvirt + 15) & ~15, 256));
   const bool masked = p.ylim < T64 || p.xlim < T64 || p.ext_y < (1 << 29) || p.ext_x < (1 << 29);
+  static const int nu = getenv("PCNN_FFT64_UNITS") ? atoi(getenv("PCNN_FFT64_UNITS")) : 2;    // developer switch (A/B): 1 = 16 waves x 1 unit, 2 = 8 waves x 2 units
+  if (nu == 1) {
+    if (masked) { set_lds(fft64_fwd_kernel<true, 1>, LDS64_BYTES); hipLaunchKernelGGL((fft64_fwd_kernel<true, 1>), grid, dim3(1024), LDS64_BYTES, h->stream, p, nvirt); }
+    else { set_lds(fft64_fwd_kernel<false, 1>, LDS64_BYTES); hipLaunchKernelGGL((fft64_fwd_kernel<false, 1>), grid, dim3(1024), LDS64_BYTES, h->stream, p, nvirt); }
+    return;
+  }
   if (masked) {
-    set_lds(fft64_fwd_kernel<true>, LDS64_BYTES);
-    hipLaunchKernelGGL((fft64_fwd_kernel<true>), grid, dim3(512), LDS64_BYTES, h->stream, p, nvirt);
+    set_lds(fft64_fwd_kernel<true, 2>, LDS64_BYTES);
+    hipLaunchKernelGGL((fft64_fwd_kernel<true, 2>), grid, dim3(512), LDS64_BYTES, h->stream, p, nvirt);
   } else {
-    set_lds(fft64_fwd_kernel<false>, LDS64_BYTES);
-    hipLaunchKernelGGL((fft64_fwd_kernel<false>), grid, dim3(512), LDS64_BYTES, h->stream, p, nvirt);
+    set_lds(fft64_fwd_kernel<false, 2>, LDS64_BYTES);
+    hipLaunchKernelGGL((fft64_fwd_kernel<false, 2>), grid, dim3(512), LDS64_BYTES, h->stream, p, nvirt);
   }
 }
 
@@ -906,6 +953,7 @@ static void launch_inv64_t(pcnn_handle h, const InvParams& p, const dim3& grid, 
 }
 
 void launch_inv_fft64(pcnn_handle h, InvParams p, int ntile) {
+  study_init();
   p.ntile = ntile;
   const int ntg = ntile * p.groups;
   const int nvirt = 2 * ((ntg + 7) & ~7);
@@ -929,6 +977,7 @@ void launch_post_bias_fft64(pcnn_handle h, const float* bsum, int nblocks, int C
 }
 
 void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile) {
+  study_init();
   p.ntile = ntile;
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)

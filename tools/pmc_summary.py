@@ -22,9 +22,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KERNELS = (r'(conv_fwd_split_kernel<\d, \d>|conv_fwd_kernel<\d>|wgrad_split_kernel|wgrad_kernel|spec_fwd_kernel<\w+, \w+>|spec_inv_kernel|spec_mix_kernel<\d>|spec_mix_lds_kernel<\d>|spec_wmix_kernel|spec_mixw_kernel|'
-           r'spec64_fwd4?_kernel<\w+>|spec64_inv_kernel|'
+           r'spec64_fwd4?_kernel<\w+>|spec64_inv_kernel|fft32_fwd_kernel<\w+>|fft32_inv_kernel|fft64_fwd_kernel<\w+>|fft64_inv_kernel|'
            r'conv_small_fwd_kernel|conv_small_wgrad_kernel|resnet3_stage_kernel|split_convert_kernel|split_absmax_kernel|epilogue_bwd\w*|deconv_fwd_mfma_kernel|resize_fwd_kernel)')
-CONV = ('conv_fwd', 'wgrad', 'spec', 'conv_small', 'resnet3_stage')      # what bench.py's `roofline` covers: every convolution launch
+CONV = ('conv_fwd', 'wgrad', 'spec', 'fft', 'conv_small', 'resnet3_stage')      # what bench.py's `roofline` covers: every convolution launch
 
 
 def per_kernel(path, counter, scale=1024.0):
