@@ -73,6 +73,18 @@ class DataParallel:
         import ctypes
         from . import ops
         h = ops.handle()
+        ident = self.exchange_unique_id(h)
+        raw = (ctypes.c_ubyte * 128)(*ident)
+        h.call('pcnn_comm_init', raw, ctypes.c_int(self.rank), ctypes.c_int(self.world_size))
+        self._c_abi = h
+        return self
+
+    def exchange_unique_id(self, h=None):
+        """The rendezvous of the C-ABI collective: rank 0 asks the library for RCCL's 128-byte unique id (pcnn_comm_unique_id) and ships it to every
+        rank over the process group that already exists (gloo or nccl); returns the 128 bytes every rank then hands to pcnn_comm_init."""
+        import ctypes
+        from . import ops
+        h = h or ops.handle()
         ident = torch.zeros(128, dtype=torch.uint8)
         if self.rank == 0:
             buf = (ctypes.c_ubyte * 128)()
@@ -83,10 +95,7 @@ class DataParallel:
             ident = ident.to(dev)
             dist.broadcast(ident, src=0)
             ident = ident.cpu()
-        raw = (ctypes.c_ubyte * 128)(*ident.tolist())
-        h.call('pcnn_comm_init', raw, ctypes.c_int(self.rank), ctypes.c_int(self.world_size))
-        self._c_abi = h
-        return self
+        return ident.tolist()
 
     def broadcast(self, flat, src=0):
         if self.world_size > 1:

@@ -233,3 +233,67 @@ def test_train_main_two_ranks_share_the_grid_shape_and_the_weights(tmp_path):
     assert len({a[0] for a in s0}) > 1                              # and the shape does change from step to step
     assert all(a[1] != b[1] for a, b in zip(s0, s1))                # different samples per rank
     assert np.array_equal(w0, w1) and np.isfinite(w0).all()
+
+
+_CABI2_SNIPPET = """
+import json, os, sys, torch
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+from poisson_cnn_amd import parallel
+dp = parallel.DataParallel.from_env(backend='gloo')               # rendezvous over gloo: RANK / WORLD_SIZE / MASTER_* from the environment
+ident = dp.exchange_unique_id()                                    # rank 0: pcnn_comm_unique_id; everybody: the broadcast 128 bytes
+out = {'rank': dp.rank, 'ranks_seen': dp.ranks_seen(), 'ident': ident, 'init': None, 'sum': None}
+try:
+    import ctypes
+    from poisson_cnn_amd import ops
+    h = ops.handle()
+    h.call('pcnn_comm_init', (ctypes.c_ubyte * 128)(*ident), dp.rank, dp.world_size)
+    out['init'] = 'ok'
+    buf = torch.full((1 << 20,), float(dp.rank + 1), device='cuda')
+    h.call('pcnn_allreduce', ctypes.c_void_p(buf.data_ptr()), buf.numel())
+    torch.cuda.synchronize()
+    out['sum'] = [float(buf.min()), float(buf.max())]
+    h.call('pcnn_comm_destroy')
+except RuntimeError as e:
+    out['init'] = str(e)
+print('CABI2 ' + json.dumps(out), flush=True)
+dp.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_c_abi_collective_rendezvous_with_two_processes():
+    """the C-ABI collective's rendezvous at world size 2 - two bare processes, gloo between them, both on this box's one GPU.
+    Rank 0's RCCL unique id (pcnn_comm_unique_id) must reach rank 1 unchanged (DataParallel.exchange_unique_id), and both ranks must come out of
+    pcnn_comm_init TOGETHER: either with a communicator - then pcnn_allreduce of (1, 2) gives 3 everywhere - or, because RCCL refuses two ranks on
+    one device, each with the library's ordinary error return (no hang, no crash).  The first real 2-GPU all-reduce happens on the driver's node."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK='0', WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   PCNN_DIST_TIMEOUT_S='120', NCCL_DEBUG='WARN')
+        procs.append(subprocess.Popen([sys.executable, '-c', _CABI2_SNIPPET % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            assert p.returncode == 0, (o[-1000:], e[-3000:])
+            line = [ln for ln in o.splitlines() if ln.startswith('CABI2 ')]
+            assert len(line) == 1, (o[-1000:], e[-2000:])
+            outs.append(json.loads(line[0][6:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs.sort(key=lambda d: d['rank'])
+    assert [d['rank'] for d in outs] == [0, 1] and all(d['ranks_seen'] == 2 for d in outs)
+    assert outs[0]['ident'] == outs[1]['ident'] and any(outs[0]['ident'])            # the id crossed the process boundary intact
+    if outs[0]['init'] == 'ok':
+        assert outs[1]['init'] == 'ok' and outs[0]['sum'] == [3.0, 3.0] and outs[1]['sum'] == [3.0, 3.0]
+    else:                                                                              # RCCL's refusal of a duplicate device: an error return on both ranks
+        assert all('pcnn_comm_init' in d['init'] for d in outs), outs
+        print('two ranks on one device: %s' % outs[0]['init'][:200])
