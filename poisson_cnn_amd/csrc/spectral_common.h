@@ -86,6 +86,7 @@ void launch_post_bias64(pcnn_handle h, const float* bsum, int nblocks, int C, fl
 constexpr int FFT_WAVES = 16;
 void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile);
 void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile);
+void launch_post_bias_fft32(pcnn_handle h, const float* bsum, int pack, int cpt, int C, float* dbias);     // POST partial sums of the FFT inverse in use -> dbias
 void launch_fwd_fft64(pcnn_handle h, FwdParams p, int ntile);       // 64-point tiles, item = (tile, 16 channels), 8 waves x 2 units
 void launch_inv_fft64(pcnn_handle h, InvParams p, int ntile);
 void launch_post_bias_fft64(pcnn_handle h, const float* bsum, int nblocks, int C, float* dbias);   // POST at 64 points: one float per (block, wave, lane)

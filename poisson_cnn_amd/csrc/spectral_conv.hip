@@ -1293,7 +1293,8 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
   if (post && post->dbias) {
     if (Tg == 64 && h->spectral_xform == PCNN_XFORM_FFT) launch_post_bias_fft64(h, bsum, 256, dg->Cout, post->dbias);
     else if (Tg == 64) launch_post_bias64(h, bsum, 256, dg->Cout, post->dbias);
-    else hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * (h->spectral_xform == PCNN_XFORM_FFT ? FFT_WAVES : 8), pack, cpt, post->dbias);
+    else if (h->spectral_xform == PCNN_XFORM_FFT) launch_post_bias_fft32(h, bsum, pack, cpt, dg->Cout, post->dbias);
+    else hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * 8, pack, cpt, post->dbias);
   }
   float* csp = wsp;                                      // the filter spectrum is no longer needed: every mixing launch above has read it (same stream)
   hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gx), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);

@@ -66,8 +66,9 @@ struct FwdRow {
   bool fast;             // uniform: every window of the item lies inside the image in x
 };
 
-// requests window row y (lane: y = 2 wave + half) of `item`: 32 loads with always-valid addresses; padding and masks are applied on consumption
-__device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int wave, int y, int c, FwdRow& it, float (&R)[32]) {
+// requests window row y of `item` for the lane at position c of its 32-channel group: 32 loads with always-valid addresses; padding and masks are
+// applied on consumption
+__device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int row0, int y, int c, FwdRow& it, float (&R)[32]) {
   const int g = item % p.groups;
   int t = p.tile0 + item / p.groups;
   const int txg = t % p.tgx; t /= p.tgx;
@@ -89,7 +90,11 @@ __device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int wa
   it.cl = 0; it.cr = T;
   const int wx_first = txg * p.pack * p.Vx - p.ox, wx_last = wx_first + (p.pack - 1) * p.Vx;
   it.fast = wx_first >= 0 && wx_last + T <= p.W;                               // uniform
-  if (2 * wave >= ylim || FFT_STUDY(2)) return;                                // uniform: both rows of this wave are zero rows - nothing to fetch
+  if (row0 >= ylim || FFT_STUDY(2)) {                                          // uniform (row0: the wave's first row): all rows of this wave are zero rows
+#pragma unroll
+    for (int x = 0; x < T; ++x) R[x] = 0.f;                                    // (defined on every path: otherwise R is carried around the item loop)
+    return;
+  }
   const int sy = pad_sel(gy, p.H, p.pad_mode);
   const unsigned ch = (unsigned)(cok ? chan : 0);
   if (it.fast) {
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   const int y = 2 * wave + half;
   float R[32];
   FwdRow cur;
-  fwd_request(p, item, wave, y, c, cur, R);
+  fwd_request(p, item, 2 * wave, y, c, cur, R);
   // ---- x axis: this lane's window row, real -> half-complex, into LDS
   auto x_phase = [&]() {
     fwd_consume<MASKED>(p, cur, R);
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   x_phase();
   for (;;) {
     const int next = item + gridDim.x;
-    if (next < total) fwd_request(p, next, wave, y, c, cur, R);      // lands under the y phase below
+    if (next < total) fwd_request(p, next, 2 * wave, y, c, cur, R);  // lands under the y phase below
     lds_barrier();
     float* out = p.sp + sp_item32(item);
     float V[32];
@@ -418,6 +423,269 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
   }
 }
 
+// virtual work item v of the persistent grid -> (tile-and-group index, 16-channel half): v and v + 8 are the two halves of one 32-channel group
+__device__ __forceinline__ void item64(int v, int& tg, int& hf) { tg = (v >> 4) * 8 + (v & 7); hf = (v >> 3) & 1; }
+
+// =================================================================================================================== 32-point tiles, two workgroups per CU
+// The removal study of the kernels above (tools/study_fft.sh, 7 taps at 8 x 1024^2): 538 us as shipped, 215 us without any global memory access, ~320 us
+// of memory time - and the two ADD UP: all 16 waves of the one workgroup a CU holds (128 KB of LDS) sit in the same phase, so nothing computes while the
+// burst of loads is awaited.  These kernels take 16-CHANNEL items instead - lane = (row or lane group, channel of 16), every global access a 64-byte half
+// of a channel vector, as the 64-point kernels have it - so that a workgroup is 8 waves and 64 KB of LDS and TWO of them share a CU: while one waits
+// for its window rows or drains its stores, the other one computes.  The two halves of a 32-channel group are the virtual items v and v + 8 (item64),
+// i.e. they run at the same time on one XCD and the second half of every 128-byte line comes from its L2.
+//   x axis   wave w, lane group r: row 4w + r.   y axis / columns: 32 lane groups G = 4w + r: G = 0 / 1 the real columns fx = 0 / 16 (rfft_fwd<32>),
+//   G >= 2 the complex column fx = G / 2 with output parity G & 1.
+constexpr size_t LDS_H_BYTES = (size_t)T * T * 16 * sizeof(float);    // 64 KB
+
+template <bool MASKED>
+__global__ __launch_bounds__(512, 4) void fft32h_fwd_kernel(FwdParams p, int nvirt) {
+  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*16 + c16]
+  const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntg = p.ntile * p.groups;
+  int v = blockIdx.x;
+  if (v >= nvirt) return;
+  const int y = 4 * wave + lg;
+  float R[32];
+  FwdRow cur;
+  // the padded tail of the virtual item list (tg >= ntg) runs as a copy of a real item that stores nothing: the workgroup keeps its barriers
+  auto safe = [&](int vv) { int tg, hf; item64(vv, tg, hf); return tg < ntg ? vv : (vv & 8); };
+  auto request = [&](int vv) { int tg, hf; item64(safe(vv), tg, hf); fwd_request(p, tg, 4 * wave, y, 16 * hf + c16, cur, R); };
+  request(v);
+  for (;;) {
+    const int next = v + gridDim.x;
+    const bool more = next < nvirt;
+    // ---- x axis: this lane's window row, real -> half-complex, into LDS
+    fwd_consume<MASKED>(p, cur, R);
+    if (!FFT_STUDY(4)) rfft_fwd<32>(R);
+    {
+      int uoff = (y * 32) * 16 + c16;
+      asm volatile("" : "+v"(uoff));                                   // opaque: LDS addresses are lane constants (hoisted out of the item loop otherwise)
+      float* u = U + uoff;
+#pragma unroll
+      for (int s = 0; s < T; ++s) u[s * 16] = hc_get(R, s);
+    }
+    if (more) request(next);                                           // lands under the y phase below
+    lds_barrier();
+    int tg, hf;
+    item64(v, tg, hf);
+    const bool store = tg < ntg && !FFT_STUDY(1);
+    float* out = p.sp + sp_item32(store ? tg : 0) + 16 * hf;             // uniform
+    float V[32];
+    int G = 4 * wave + lg;
+    asm volatile("" : "+v"(G));                                          // opaque: the per-lane constants of the phase are formed in the phase
+    if (G < 2) {
+      // the two real columns fx = 0 (G = 0) and fx = 16 (G = 1): half-complex along y as well
+      int uoff = (G ? 16 : 0) * 16 + c16;
+      asm volatile("" : "+v"(uoff));
+      const float* u = U + uoff;
+#pragma unroll
+      for (int yy = 0; yy < T; ++yy) V[yy] = u[yy * 512];
+      if (!FFT_STUDY(4)) rfft_fwd<32>(V);
+      if (store) {
+        const unsigned lo = (unsigned)((G ? 32 : 0) * RS + c16);
+#pragma unroll
+        for (int s = 0; s < T; ++s) NT_STORE(1, hc_get(V, s), &(out + (s * RS))[lo]);
+      }
+    } else {
+      // complex column fx = G / 2 (1..15), parity par = G & 1 of the output frequencies: Z[2m + par] = FFT16( (u[y] +- u[y + 16]) W32^(par y) )[m]
+      const int fx = G >> 1, par = G & 1;
+      int uoff = fx * 16 + c16;
+      asm volatile("" : "+v"(uoff));
+      const float* ur = U + uoff, *ui = ur + 256;
+      float* vr = V, *vi = V + 16;
+      const float osign = par ? -1.f : 1.f;
+#pragma unroll
+      for (int yy = 0; yy < 16; ++yy) {
+        const float lr = ur[yy * 512], hr = ur[(yy + 16) * 512], li = ui[yy * 512], hi = ui[(yy + 16) * 512];
+        const float ar = fma_(osign, hr, lr), ai = fma_(osign, hi, li);
+        if (yy == 0) { vr[yy] = ar; vi[yy] = ai; }
+        else {
+          const float wr = par ? tw_re<32>(yy) : 1.f, wi = par ? tw_im<32>(yy) : 0.f;
+          vr[yy] = fma_(ar, wr, -(ai * wi));
+          vi[yy] = fma_(ar, wi, ai * wr);
+        }
+      }
+      if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
+      if (store) {
+        const unsigned lo = (unsigned)((64 + 64 * (fx - 1) + par) * RS + c16);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          NT_STORE(1, vr[bitrev(m, 16)], &(out + ((2 * m) * RS))[lo]);
+          NT_STORE(1, vi[bitrev(m, 16)], &(out + ((32 + 2 * m) * RS))[lo]);
+        }
+      }
+    }
+    if (!more) break;
+    v = __builtin_amdgcn_readfirstlane(next);
+    lds_barrier();                                                       // U is free for the next item
+  }
+}
+
+template <bool TANH, bool RES, bool POST>
+__global__ __launch_bounds__(512, 4) void fft32h_inv_kernel(InvParams p, int nvirt) {
+  extern __shared__ __attribute__((aligned(16))) float U[];          // E[(y*32 + s)*16 + c16], y < 16, then O
+  constexpr int EOH = 16 * 32 * 16;
+  const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntg = p.ntile * p.groups;
+  int v = blockIdx.x;
+  if (v >= nvirt) return;
+  float ymax = 0.f, bsum = 0.f;
+  constexpr int BURST = (POST && RES) ? 4 : 8;
+  for (;;) {
+    const int next = v + gridDim.x;
+    int tg, hf;
+    item64(v, tg, hf);
+    const bool live = tg < ntg;
+    const float* in = p.sp + sp_item32(live ? tg : 0) + 16 * hf;         // uniform
+    // ---- y axis inverse (unnormalised: the 1 / 1024 of both axes is applied once, after the x axis)
+    {
+      int G = 4 * wave + lg;
+      asm volatile("" : "+v"(G));
+      float V[32];
+      if (G < 2) {
+        const unsigned lo = (unsigned)((G ? 32 : 0) * RS + c16);
+        float W[32];
+#pragma unroll
+        for (int s = 0; s < T; ++s) hc_put(W, s, FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + (s * RS))[lo]));
+        if (!FFT_STUDY(4)) rfft_inv<32>(W);                            // W[y] = 32 u[y]
+        int eoff = (G ? 16 : 0) * 16 + c16;
+        asm volatile("" : "+v"(eoff));
+        float* e = U + eoff;
+#pragma unroll
+        for (int yy = 0; yy < 16; ++yy) {
+          e[yy * 512] = 0.5f * (W[yy] + W[yy + 16]);
+          e[EOH + yy * 512] = 0.5f * (W[yy] - W[yy + 16]);
+        }
+      } else {
+        const int fx = G >> 1, par = G & 1;
+        const unsigned lo = (unsigned)((64 + 64 * (fx - 1) + par) * RS + c16);
+        float* vr = V, *vi = V + 16;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          vr[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + ((2 * m) * RS))[lo]);
+          vi[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + ((32 + 2 * m) * RS))[lo]);
+        }
+        if (!FFT_STUDY(4)) cfft_dif<16, +1>(vr, vi);                   // register q: E (par = 0) or O-before-twiddle (par = 1) at y = bitrev(q)
+        int eoff = (par ? EOH : 0) + fx * 16 + c16;
+        asm volatile("" : "+v"(eoff));
+        float* er = U + eoff, *ei = er + 256;
+#pragma unroll
+        for (int yy = 0; yy < 16; ++yy) {
+          const float ar = vr[bitrev(yy, 16)], ai = vi[bitrev(yy, 16)];
+          if (yy == 0) { er[0] = ar; ei[0] = ai; }
+          else {
+            const float wr = par ? tw_re<32>(yy) : 1.f, wi = par ? -tw_im<32>(yy) : 0.f;        // conj(W32^y) for the odd half
+            er[yy * 512] = fma_(ar, wr, -(ai * wi));
+            ei[yy * 512] = fma_(ar, wi, ai * wr);
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- x axis inverse of this lane's output row + the fused epilogue
+    {
+      const int c = 16 * hf + c16;                                     // the lane's place in its 32-channel group
+      const int g = tg % p.groups;
+      int t = p.tile0 + (live ? tg : 0) / p.groups;
+      const int txg = t % p.tgx; t /= p.tgx;
+      const int ty = t % p.tiles_y;
+      const int n = t / p.tiles_y;
+      const int sub = p.pack > 1 ? c / p.cpt : 0, cc = c - sub * p.cpt;
+      const int subx = sub * p.Vx;
+      const int y0 = ty * p.Vy, x0 = txg * p.pack * p.Vx;
+      const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0 - subx);
+      const int chan = g * p.cstride + cc;
+      const bool cok = live && cc < p.cvalid && chan < p.C;
+      if (4 * wave < vy) {                                            // uniform: at least the first row of this wave is an output row
+        const int yy = 4 * wave + lg;
+        const bool rowok = cok && yy < vy && vx > 0;
+        float X[32];
+        {
+          int eoff = ((yy & 15) * 32) * 16 + c16;
+          asm volatile("" : "+v"(eoff));
+          const float* e = U + eoff;
+          const float osign = yy < 16 ? 1.f : -1.f;
+#pragma unroll
+          for (int s0 = 0; s0 < T; s0 += 8) {
+#pragma unroll
+            for (int s = s0; s < s0 + 8; ++s) {
+              float val = fma_(osign, e[EOH + s * 16], e[s * 16]);
+              asm volatile("" : "+v"(val));                              // needed now (not sunk into the transform with its two operands kept)
+              hc_put(X, s, val);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (!FFT_STUDY(4)) rfft_inv<32>(X);                            // X[x] = 1024 * pixel (yy, x)
+        const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
+        const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
+        const int sgn = p.flip ? -1 : 1;
+        const int prow = p.flip ? p.Ho - 1 - y0 - yy : y0 + yy, pcol = p.flip ? p.Wo - 1 - x0 - subx : x0 + subx;
+        unsigned pix0 = (unsigned)(prow * p.Wo + pcol);
+        asm volatile("" : "+v"(pix0));
+        const int64_t ipix = (int64_t)n * p.Ho * p.Wo;
+        float* yimg = p.y + ipix * p.ldy;
+        float* aimg = (!POST && p.act_out) ? p.act_out + ipix * p.ld_act : nullptr;
+        const float* rimg = RES ? p.res + ipix * p.ld_res : nullptr;
+        const float* gimg = POST ? p.gact + ipix * p.ld_gact : nullptr;
+        float* y2img = (POST && p.y2) ? p.y2 + ipix * p.ld_y2 : nullptr;
+        if (rowok && !FFT_STUDY(1))
+          epilogue_row<TANH, RES, POST, T, BURST, false>(p, X, 1.f / 1024.f, vx, pix0, sgn, (unsigned)chan, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
+      }
+    }
+    if (next >= nvirt) break;
+    v = __builtin_amdgcn_readfirstlane(next);
+    lds_barrier();                                                       // the LDS image is free for the next item
+  }
+  if (POST && p.bsum) p.bsum[(blockIdx.x * 8 + wave) * 64 + lane] += bsum;    // own slot; a workgroup keeps ONE 16-channel half (the grid is a multiple of 16)
+  if (p.absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    if (lane == 0) {
+      const unsigned bits = __float_as_uint(ymax <= 3.0e38f ? ymax : 3.0e38f);
+      if (bits > __atomic_load_n(p.absmax, __ATOMIC_RELAXED)) atomicMax(p.absmax, bits);
+    }
+  }
+}
+
+// POST with 32-channel items (fft32_inv_kernel): thread t sums the slots (block, wave) = t, t + 256, ... of the lanes that carry the channel
+__global__ __launch_bounds__(256) void fft32_post_bias_kernel(const float* __restrict__ bsum, int nslots, int pack, int cpt, float* __restrict__ dbias) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int sl = t; sl < nslots; sl += 256)
+    for (int sub = 0; sub < pack; ++sub) {
+      const int c = sub * cpt + ch;
+      a += bsum[sl * 64 + c];
+      a += bsum[sl * 64 + 32 + c];
+    }
+  red[t] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
+  if (t == 0) dbias[ch] = red[0];
+}
+
+// POST with 16-channel items: dbias[ch] from the lanes' partial sums, in a fixed order.  The lane at place L = sub cpt + ch of its 32-channel group
+// (sub: packed tile) lives in the workgroups with (block >> 3) & 1 == L >> 4, lanes with lane & 15 == L & 15 (four lane groups = four rows).
+__global__ __launch_bounds__(256) void fft32h_post_bias_kernel(const float* __restrict__ bsum, int nblocks, int pack, int cpt, float* __restrict__ dbias) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int sl = t; sl < nblocks * 8 * 4; sl += 256) {                 // (block, wave, lane group)
+    const int lgq = sl & 3, bw = sl >> 2, block = bw >> 3;
+    for (int sub = 0; sub < pack; ++sub) {
+      const int L = sub * cpt + ch;
+      if (((block >> 3) & 1) == (L >> 4)) a += bsum[(size_t)bw * 64 + lgq * 16 + (L & 15)];
+    }
+  }
+  red[t] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
+  if (t == 0) dbias[ch] = red[0];
+}
+
 // =================================================================================================================== 64-point tiles
 // A 64 x 64 x 32-channel tile is 512 KB - the whole register file of a CU.  item = (tile, 16 channels): the lanes of a wave are 4 x 16 channels
 // (every global access a 64-byte half of a pixel's / spectrum row's channel vector; the two halves of a 32-channel group run at the same time on
@@ -432,8 +700,6 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
 constexpr int T64 = 64, ROWS64 = 4096;
 __host__ __device__ __forceinline__ int64_t sp_item64(int64_t item) { return pcnn_spec::sp_item(item, ROWS64); }
 
-// virtual work item v of the persistent grid -> (tile-and-group index, 16-channel half): v and v + 8 are the two halves of one 32-channel group
-__device__ __forceinline__ void item64(int v, int& tg, int& hf) { tg = (v >> 4) * 8 + (v & 7); hf = (v >> 3) & 1; }
 
 // what a wave keeps of an item between requesting its window rows and consuming them
 struct FwdItem64 {
@@ -905,6 +1171,10 @@ void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
 }  // namespace
 
 // persistent kernels: one 16-wave workgroup per CU (128 KB of LDS) walking the (tile, channel group) items
+int fft32_item_channels();
+static void launch_fwd_fft32h(pcnn_handle h, FwdParams p, int ntile);
+static void launch_inv_fft32h(pcnn_handle h, InvParams p, int ntile);
+
 #ifdef PCNN_FFT_STUDY
 static void study_init() { static int once = 0; if (!once) { once = 1; const int v = getenv("PCNN_FFT_STUDY") ? atoi(getenv("PCNN_FFT_STUDY")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_study), &v, sizeof(int)); } }
 #else
@@ -913,6 +1183,7 @@ static void study_init() {}
 
 void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
   study_init();
+  if (fft32_item_channels() == 16) { launch_fwd_fft32h(h, p, ntile); return; }
   p.ntile = ntile;
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.ylim < T || p.xlim < T) {
@@ -922,6 +1193,58 @@ void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
     set_lds(fft32_fwd_kernel<false>);
     hipLaunchKernelGGL((fft32_fwd_kernel<false>), grid, dim3(1024), LDS_BYTES, h->stream, p);
   }
+}
+
+// which 32-point FFT kernels run: 16-channel items, two workgroups per CU (default), or 32-channel items, one 16-wave workgroup per CU
+// (PCNN_FFT32_ITEM=32: developer switch for A/B timing and tests)
+int fft32_item_channels() {
+  static const int v = getenv("PCNN_FFT32_ITEM") ? atoi(getenv("PCNN_FFT32_ITEM")) : 16;
+  return v == 32 ? 32 : 16;
+}
+
+static void launch_fwd_fft32h(pcnn_handle h, FwdParams p, int ntile) {
+  p.ntile = ntile;
+  const int ntg = ntile * p.groups;
+  const int nvirt = 2 * ((ntg + 7) & ~7);                            // (tile-and-group) x two 16-channel halves, in blocks of 8 + 8 (item64)
+  const dim3 grid((unsigned)std::min((nvirt + 15) & ~15, 512));      // two workgroups per CU
+  if (p.ylim < T || p.xlim < T) {
+    set_lds(fft32h_fwd_kernel<true>, LDS_H_BYTES);
+    hipLaunchKernelGGL((fft32h_fwd_kernel<true>), grid, dim3(512), LDS_H_BYTES, h->stream, p, nvirt);
+  } else {
+    set_lds(fft32h_fwd_kernel<false>, LDS_H_BYTES);
+    hipLaunchKernelGGL((fft32h_fwd_kernel<false>), grid, dim3(512), LDS_H_BYTES, h->stream, p, nvirt);
+  }
+}
+
+template <bool TANH, bool RES, bool POST>
+static void launch_inv32h_t(pcnn_handle h, const InvParams& p, const dim3& grid, int nvirt) {
+  set_lds(fft32h_inv_kernel<TANH, RES, POST>, LDS_H_BYTES);
+  hipLaunchKernelGGL((fft32h_inv_kernel<TANH, RES, POST>), grid, dim3(512), LDS_H_BYTES, h->stream, p, nvirt);
+}
+
+static void launch_inv_fft32h(pcnn_handle h, InvParams p, int ntile) {
+  p.ntile = ntile;
+  const int ntg = ntile * p.groups;
+  const int nvirt = 2 * ((ntg + 7) & ~7);
+  const dim3 grid((unsigned)std::min((nvirt + 15) & ~15, 512));
+  if (p.gact) {
+    p.alpha = 1.f;
+    p.galpha = p.gmode == PCNN_ACT_LINEAR ? 1.f : (p.gmode == PCNN_ACT_RELU ? 0.f : p.galpha);
+    if (p.res) launch_inv32h_t<false, true, true>(h, p, grid, nvirt); else launch_inv32h_t<false, false, true>(h, p, grid, nvirt);
+    return;
+  }
+  if (p.act == PCNN_ACT_TANH) {
+    if (p.res) launch_inv32h_t<true, true, false>(h, p, grid, nvirt); else launch_inv32h_t<true, false, false>(h, p, grid, nvirt);
+  } else {
+    p.alpha = p.act == PCNN_ACT_LINEAR ? 1.f : (p.act == PCNN_ACT_RELU ? 0.f : p.alpha);
+    if (p.res) launch_inv32h_t<false, true, false>(h, p, grid, nvirt); else launch_inv32h_t<false, false, false>(h, p, grid, nvirt);
+  }
+}
+
+// POST partial sums of the 32-point FFT inverse -> dbias (the layout depends on the kernel family in use)
+void launch_post_bias_fft32(pcnn_handle h, const float* bsum, int pack, int cpt, int C, float* dbias) {
+  if (fft32_item_channels() == 16) hipLaunchKernelGGL(fft32h_post_bias_kernel, dim3((unsigned)C), dim3(256), 0, h->stream, bsum, 512, pack, cpt, dbias);
+  else hipLaunchKernelGGL(fft32_post_bias_kernel, dim3((unsigned)C), dim3(256), 0, h->stream, bsum, 256 * FFT_WAVES, pack, cpt, dbias);
 }
 
 void launch_fwd_fft64(pcnn_handle h, FwdParams p, int ntile) {
@@ -978,6 +1301,7 @@ void launch_post_bias_fft64(pcnn_handle h, const float* bsum, int nblocks, int C
 
 void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile) {
   study_init();
+  if (fft32_item_channels() == 16) { launch_inv_fft32h(h, p, ntile); return; }
   p.ntile = ntile;
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)
