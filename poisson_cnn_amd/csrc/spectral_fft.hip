@@ -57,6 +57,35 @@ __device__ __forceinline__ int pad_sel(int i, int n, int mode) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ forward transform
+// ---- hand-managed memory counter -----------------------------------------------------------------------------------------------------------------
+// s_waitcnt vmcnt(n) counts loads AND stores, in issue order.  A persistent transform kernel wants, per item: [next item's 32 loads] ... [this item's
+// 32 spectrum stores] ... consume the loads while the stores are still draining, i.e. s_waitcnt vmcnt(32).  The compiler's own waits do not get
+// there: its pending-operation model is merged conservatively over the kernel's paths (boundary / interior loaders, masked rows, the two y-axis
+// branches) and it ended up waiting for the stores, one more per consumed value - the whole x phase ran behind the store drain (removal study,
+// tools/study_fft.sh: 538 us as shipped = 215 us compute + 323 us memory, added up).  So the window loads are issued from inline assembly - the
+// compiler does not know their results are in flight - and the kernel waits for them itself, once, with the count it knows to be right
+// (vm_wait_loads).  The compiler's waits for ITS operations (the stores) stay correct: untracked younger operations only make them wait longer.
+__device__ __forceinline__ float vm_load(const float* sbase, unsigned voff_bytes) {     // sbase: uniform; address = sbase + voff_bytes
+  float v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff_bytes), "s"(sbase) : "memory");
+  return v;
+}
+__device__ __forceinline__ float vm_load_v(const float* vaddr) {                          // per-lane 64-bit address
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(vaddr) : "memory");
+  return v;
+}
+// every value of R[0..32) has landed; at most KEEP younger operations (the stores issued after the loads) stay in flight.  The values are operands
+// of the statement, so nothing that uses them is scheduled in front of the wait.
+template <int KEEP> __device__ __forceinline__ void vm_wait_loads(float (&R)[32]) {
+  static_assert(KEEP == 0 || KEEP == 32, "spelled-out immediates");
+  if (KEEP == 32) asm volatile("s_waitcnt vmcnt(32)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]) :: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]) :: "memory");
+  asm volatile("" : "+v"(R[8]), "+v"(R[9]), "+v"(R[10]), "+v"(R[11]), "+v"(R[12]), "+v"(R[13]), "+v"(R[14]), "+v"(R[15]) :: "memory");
+  asm volatile("" : "+v"(R[16]), "+v"(R[17]), "+v"(R[18]), "+v"(R[19]), "+v"(R[20]), "+v"(R[21]), "+v"(R[22]), "+v"(R[23]) :: "memory");
+  asm volatile("" : "+v"(R[24]), "+v"(R[25]), "+v"(R[26]), "+v"(R[27]), "+v"(R[28]), "+v"(R[29]), "+v"(R[30]), "+v"(R[31]) :: "memory");
+}
+
 // what a lane keeps of an item between requesting its window row and consuming it
 struct FwdRow {
   float fill;            // lane: value of a row that is not read from memory (0: beyond ylim / no such channel; the padding constant)
@@ -90,24 +119,29 @@ __device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int ro
   it.cl = 0; it.cr = T;
   const int wx_first = txg * p.pack * p.Vx - p.ox, wx_last = wx_first + (p.pack - 1) * p.Vx;
   it.fast = wx_first >= 0 && wx_last + T <= p.W;                               // uniform
-  if (row0 >= ylim || FFT_STUDY(2)) {                                          // uniform (row0: the wave's first row): all rows of this wave are zero rows
-#pragma unroll
-    for (int x = 0; x < T; ++x) R[x] = 0.f;                                    // (defined on every path: otherwise R is carried around the item loop)
-    return;
-  }
   const int sy = pad_sel(gy, p.H, p.pad_mode);
   const unsigned ch = (unsigned)(cok ? chan : 0);
+  if (row0 >= ylim || FFT_STUDY(2)) {
+    // uniform (row0: the wave's first row): all rows of this wave are zero rows.  Nothing needs fetching - but the NUMBER of memory operations per
+    // item must not depend on the path: s_waitcnt vmcnt counts loads and stores in issue order, and where the count differs between paths the
+    // compiler's waits in the x phase assume the fewest, i.e. they also wait for the previous item's spectrum stores, one more per value (that
+    // serialised the whole x phase behind the store drain: tools/study_fft.sh).  32 loads of one resident line cost next to nothing.
+    // (Since the loads come from inline assembly - vm_load - and the kernel counts for itself, the count must be exact on every path.)
+#pragma unroll
+    for (int x = 0; x < T; ++x) R[x] = vm_load(img, 4u * ch);
+    return;
+  }
   if (it.fast) {
     // one lane offset for all 32 loads; the uniform pointer steps from pixel to pixel on the scalar ALU
-    const unsigned lo = (unsigned)((sy * p.W + wx0) * p.ld) + ch;
+    const unsigned lo = 4u * ((unsigned)((sy * p.W + wx0) * p.ld) + ch);
     const float* rp = img;
 #pragma unroll
-    for (int x = 0; x < T; ++x) { R[x] = rp[lo]; rp += p.ld; }
+    for (int x = 0; x < T; ++x) { R[x] = vm_load(rp, lo); rp += p.ld; }
   } else {
     const unsigned rowoff = (unsigned)(sy * p.W * p.ld) + ch;
     if (p.pad_mode == PCNN_PAD_CONSTANT) { it.cl = -wx0; it.cr = p.W - wx0; }
 #pragma unroll
-    for (int x = 0; x < T; ++x) R[x] = img[rowoff + (unsigned)(pad_sel(wx0 + x, p.W, p.pad_mode) * p.ld)];
+    for (int x = 0; x < T; ++x) R[x] = vm_load(img, 4u * (rowoff + (unsigned)(pad_sel(wx0 + x, p.W, p.pad_mode) * p.ld)));
   }
 }
 
@@ -155,7 +189,10 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   FwdRow cur;
   fwd_request(p, item, 2 * wave, y, c, cur, R);
   // ---- x axis: this lane's window row, real -> half-complex, into LDS
-  auto x_phase = [&]() {
+  auto x_phase = [&](bool stores_behind) {
+    // the loads were issued by vm_load: this is the one wait for them.  Inside the loop exactly 32 stores were issued after them (both y-axis
+    // branches store 32 values per lane) and may stay in flight; in front of the loop nothing follows the loads.
+    if (stores_behind && !FFT_STUDY(1)) vm_wait_loads<32>(R); else vm_wait_loads<0>(R);
     fwd_consume<MASKED>(p, cur, R);
     if (!FFT_STUDY(4)) rfft_fwd<32>(R);
     float* u = U + (y * 32) * 32 + c;
@@ -164,10 +201,12 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   };
   // (first x phase outside the loop: every x phase inside it then meets the same memory-counter state - the next item's loads, then this item's
   // stores - as in spec_fwd_kernel)
-  x_phase();
+  x_phase(false);
   for (;;) {
     const int next = item + gridDim.x;
-    if (next < total) fwd_request(p, next, 2 * wave, y, c, cur, R);  // lands under the y phase below
+    // the next item's window row lands under the y phase below; the last item re-requests itself instead of branching around the loads (a static
+    // number of memory operations per pass: 32 loads, then 32 stores - the x phase's waits then leave exactly the stores in flight)
+    fwd_request(p, next < total ? next : item, 2 * wave, y, c, cur, R);
     lds_barrier();
     float* out = p.sp + sp_item32(item);
     float V[32];
@@ -214,7 +253,7 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
     if (next >= total) break;
     item = __builtin_amdgcn_readfirstlane(next);
     lds_barrier();                                                       // U is free for the next item
-    x_phase();
+    x_phase(true);
   }
 }
 
@@ -423,234 +462,17 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
   }
 }
 
-// virtual work item v of the persistent grid -> (tile-and-group index, 16-channel half): v and v + 8 are the two halves of one 32-channel group
-__device__ __forceinline__ void item64(int v, int& tg, int& hf) { tg = (v >> 4) * 8 + (v & 7); hf = (v >> 3) & 1; }
+// (Measured and rejected, round 5: a software pipeline over the items - request(i + 1), x axis (i), barrier, y axis (i + 1), epilogue (i) - so that no load
+// is issued behind the epilogue's stores (vmcnt is one in-order counter) and nothing is held through the epilogue.  Correct, but the 32 pixel values
+// carried across the next item's y axis pushed every variant to 13-24 spilled registers, and scratch traffic shares the memory pipe: 7 taps forward
+// 2.04 vs 1.86 ms at 8 x 1024^2.  The plain order - loads at the top of an item - stays.)
+// (Measured and rejected, round 5 - commit "Experiment: 32-point FFT kernels on 16-channel items": the same kernels on 16-CHANNEL items, 8 waves and
+// 64 KB of LDS per workgroup, TWO workgroups per CU, so that one computes while the other waits for its loads.  Correct - all 79 spectral tests - and
+// 6 % slower: 7 taps forward 1.96 vs 1.84 ms, 11 taps 2.47 vs 2.16 ms at 8 x 1024^2 (profiles/r05_probe_xform_16ch_items_rejected.txt).  The 64-byte
+// half-vector accesses cost more than the overlap brings; the 32-channel form below stays.)
 
-// =================================================================================================================== 32-point tiles, two workgroups per CU
-// The removal study of the kernels above (tools/study_fft.sh, 7 taps at 8 x 1024^2): 538 us as shipped, 215 us without any global memory access, ~320 us
-// of memory time - and the two ADD UP: all 16 waves of the one workgroup a CU holds (128 KB of LDS) sit in the same phase, so nothing computes while the
-// burst of loads is awaited.  These kernels take 16-CHANNEL items instead - lane = (row or lane group, channel of 16), every global access a 64-byte half
-// of a channel vector, as the 64-point kernels have it - so that a workgroup is 8 waves and 64 KB of LDS and TWO of them share a CU: while one waits
-// for its window rows or drains its stores, the other one computes.  The two halves of a 32-channel group are the virtual items v and v + 8 (item64),
-// i.e. they run at the same time on one XCD and the second half of every 128-byte line comes from its L2.
-//   x axis   wave w, lane group r: row 4w + r.   y axis / columns: 32 lane groups G = 4w + r: G = 0 / 1 the real columns fx = 0 / 16 (rfft_fwd<32>),
-//   G >= 2 the complex column fx = G / 2 with output parity G & 1.
-constexpr size_t LDS_H_BYTES = (size_t)T * T * 16 * sizeof(float);    // 64 KB
-
-template <bool MASKED>
-__global__ __launch_bounds__(512, 4) void fft32h_fwd_kernel(FwdParams p, int nvirt) {
-  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*16 + c16]
-  const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntg = p.ntile * p.groups;
-  int v = blockIdx.x;
-  if (v >= nvirt) return;
-  const int y = 4 * wave + lg;
-  float R[32];
-  FwdRow cur;
-  // the padded tail of the virtual item list (tg >= ntg) runs as a copy of a real item that stores nothing: the workgroup keeps its barriers
-  auto safe = [&](int vv) { int tg, hf; item64(vv, tg, hf); return tg < ntg ? vv : (vv & 8); };
-  auto request = [&](int vv) { int tg, hf; item64(safe(vv), tg, hf); fwd_request(p, tg, 4 * wave, y, 16 * hf + c16, cur, R); };
-  request(v);
-  for (;;) {
-    const int next = v + gridDim.x;
-    const bool more = next < nvirt;
-    // ---- x axis: this lane's window row, real -> half-complex, into LDS
-    fwd_consume<MASKED>(p, cur, R);
-    if (!FFT_STUDY(4)) rfft_fwd<32>(R);
-    {
-      int uoff = (y * 32) * 16 + c16;
-      asm volatile("" : "+v"(uoff));                                   // opaque: LDS addresses are lane constants (hoisted out of the item loop otherwise)
-      float* u = U + uoff;
-#pragma unroll
-      for (int s = 0; s < T; ++s) u[s * 16] = hc_get(R, s);
-    }
-    if (more) request(next);                                           // lands under the y phase below
-    lds_barrier();
-    int tg, hf;
-    item64(v, tg, hf);
-    const bool store = tg < ntg && !FFT_STUDY(1);
-    float* out = p.sp + sp_item32(store ? tg : 0) + 16 * hf;             // uniform
-    float V[32];
-    int G = 4 * wave + lg;
-    asm volatile("" : "+v"(G));                                          // opaque: the per-lane constants of the phase are formed in the phase
-    if (G < 2) {
-      // the two real columns fx = 0 (G = 0) and fx = 16 (G = 1): half-complex along y as well
-      int uoff = (G ? 16 : 0) * 16 + c16;
-      asm volatile("" : "+v"(uoff));
-      const float* u = U + uoff;
-#pragma unroll
-      for (int yy = 0; yy < T; ++yy) V[yy] = u[yy * 512];
-      if (!FFT_STUDY(4)) rfft_fwd<32>(V);
-      if (store) {
-        const unsigned lo = (unsigned)((G ? 32 : 0) * RS + c16);
-#pragma unroll
-        for (int s = 0; s < T; ++s) NT_STORE(1, hc_get(V, s), &(out + (s * RS))[lo]);
-      }
-    } else {
-      // complex column fx = G / 2 (1..15), parity par = G & 1 of the output frequencies: Z[2m + par] = FFT16( (u[y] +- u[y + 16]) W32^(par y) )[m]
-      const int fx = G >> 1, par = G & 1;
-      int uoff = fx * 16 + c16;
-      asm volatile("" : "+v"(uoff));
-      const float* ur = U + uoff, *ui = ur + 256;
-      float* vr = V, *vi = V + 16;
-      const float osign = par ? -1.f : 1.f;
-#pragma unroll
-      for (int yy = 0; yy < 16; ++yy) {
-        const float lr = ur[yy * 512], hr = ur[(yy + 16) * 512], li = ui[yy * 512], hi = ui[(yy + 16) * 512];
-        const float ar = fma_(osign, hr, lr), ai = fma_(osign, hi, li);
-        if (yy == 0) { vr[yy] = ar; vi[yy] = ai; }
-        else {
-          const float wr = par ? tw_re<32>(yy) : 1.f, wi = par ? tw_im<32>(yy) : 0.f;
-          vr[yy] = fma_(ar, wr, -(ai * wi));
-          vi[yy] = fma_(ar, wi, ai * wr);
-        }
-      }
-      if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
-      if (store) {
-        const unsigned lo = (unsigned)((64 + 64 * (fx - 1) + par) * RS + c16);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-          NT_STORE(1, vr[bitrev(m, 16)], &(out + ((2 * m) * RS))[lo]);
-          NT_STORE(1, vi[bitrev(m, 16)], &(out + ((32 + 2 * m) * RS))[lo]);
-        }
-      }
-    }
-    if (!more) break;
-    v = __builtin_amdgcn_readfirstlane(next);
-    lds_barrier();                                                       // U is free for the next item
-  }
-}
-
-template <bool TANH, bool RES, bool POST>
-__global__ __launch_bounds__(512, 4) void fft32h_inv_kernel(InvParams p, int nvirt) {
-  extern __shared__ __attribute__((aligned(16))) float U[];          // E[(y*32 + s)*16 + c16], y < 16, then O
-  constexpr int EOH = 16 * 32 * 16;
-  const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntg = p.ntile * p.groups;
-  int v = blockIdx.x;
-  if (v >= nvirt) return;
-  float ymax = 0.f, bsum = 0.f;
-  constexpr int BURST = (POST && RES) ? 4 : 8;
-  for (;;) {
-    const int next = v + gridDim.x;
-    int tg, hf;
-    item64(v, tg, hf);
-    const bool live = tg < ntg;
-    const float* in = p.sp + sp_item32(live ? tg : 0) + 16 * hf;         // uniform
-    // ---- y axis inverse (unnormalised: the 1 / 1024 of both axes is applied once, after the x axis)
-    {
-      int G = 4 * wave + lg;
-      asm volatile("" : "+v"(G));
-      float V[32];
-      if (G < 2) {
-        const unsigned lo = (unsigned)((G ? 32 : 0) * RS + c16);
-        float W[32];
-#pragma unroll
-        for (int s = 0; s < T; ++s) hc_put(W, s, FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + (s * RS))[lo]));
-        if (!FFT_STUDY(4)) rfft_inv<32>(W);                            // W[y] = 32 u[y]
-        int eoff = (G ? 16 : 0) * 16 + c16;
-        asm volatile("" : "+v"(eoff));
-        float* e = U + eoff;
-#pragma unroll
-        for (int yy = 0; yy < 16; ++yy) {
-          e[yy * 512] = 0.5f * (W[yy] + W[yy + 16]);
-          e[EOH + yy * 512] = 0.5f * (W[yy] - W[yy + 16]);
-        }
-      } else {
-        const int fx = G >> 1, par = G & 1;
-        const unsigned lo = (unsigned)((64 + 64 * (fx - 1) + par) * RS + c16);
-        float* vr = V, *vi = V + 16;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-          vr[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + ((2 * m) * RS))[lo]);
-          vi[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + ((32 + 2 * m) * RS))[lo]);
-        }
-        if (!FFT_STUDY(4)) cfft_dif<16, +1>(vr, vi);                   // register q: E (par = 0) or O-before-twiddle (par = 1) at y = bitrev(q)
-        int eoff = (par ? EOH : 0) + fx * 16 + c16;
-        asm volatile("" : "+v"(eoff));
-        float* er = U + eoff, *ei = er + 256;
-#pragma unroll
-        for (int yy = 0; yy < 16; ++yy) {
-          const float ar = vr[bitrev(yy, 16)], ai = vi[bitrev(yy, 16)];
-          if (yy == 0) { er[0] = ar; ei[0] = ai; }
-          else {
-            const float wr = par ? tw_re<32>(yy) : 1.f, wi = par ? -tw_im<32>(yy) : 0.f;        // conj(W32^y) for the odd half
-            er[yy * 512] = fma_(ar, wr, -(ai * wi));
-            ei[yy * 512] = fma_(ar, wi, ai * wr);
-          }
-        }
-      }
-    }
-    lds_barrier();
-    // ---- x axis inverse of this lane's output row + the fused epilogue
-    {
-      const int c = 16 * hf + c16;                                     // the lane's place in its 32-channel group
-      const int g = tg % p.groups;
-      int t = p.tile0 + (live ? tg : 0) / p.groups;
-      const int txg = t % p.tgx; t /= p.tgx;
-      const int ty = t % p.tiles_y;
-      const int n = t / p.tiles_y;
-      const int sub = p.pack > 1 ? c / p.cpt : 0, cc = c - sub * p.cpt;
-      const int subx = sub * p.Vx;
-      const int y0 = ty * p.Vy, x0 = txg * p.pack * p.Vx;
-      const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0 - subx);
-      const int chan = g * p.cstride + cc;
-      const bool cok = live && cc < p.cvalid && chan < p.C;
-      if (4 * wave < vy) {                                            // uniform: at least the first row of this wave is an output row
-        const int yy = 4 * wave + lg;
-        const bool rowok = cok && yy < vy && vx > 0;
-        float X[32];
-        {
-          int eoff = ((yy & 15) * 32) * 16 + c16;
-          asm volatile("" : "+v"(eoff));
-          const float* e = U + eoff;
-          const float osign = yy < 16 ? 1.f : -1.f;
-#pragma unroll
-          for (int s0 = 0; s0 < T; s0 += 8) {
-#pragma unroll
-            for (int s = s0; s < s0 + 8; ++s) {
-              float val = fma_(osign, e[EOH + s * 16], e[s * 16]);
-              asm volatile("" : "+v"(val));                              // needed now (not sunk into the transform with its two operands kept)
-              hc_put(X, s, val);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        if (!FFT_STUDY(4)) rfft_inv<32>(X);                            // X[x] = 1024 * pixel (yy, x)
-        const float bias = (p.bias && cok) ? p.bias[chan] : 0.f;
-        const float sc = (p.bn_scale && cok) ? p.bn_scale[chan] : 1.f, sh = (p.bn_scale && cok) ? p.bn_shift[chan] : 0.f;
-        const int sgn = p.flip ? -1 : 1;
-        const int prow = p.flip ? p.Ho - 1 - y0 - yy : y0 + yy, pcol = p.flip ? p.Wo - 1 - x0 - subx : x0 + subx;
-        unsigned pix0 = (unsigned)(prow * p.Wo + pcol);
-        asm volatile("" : "+v"(pix0));
-        const int64_t ipix = (int64_t)n * p.Ho * p.Wo;
-        float* yimg = p.y + ipix * p.ldy;
-        float* aimg = (!POST && p.act_out) ? p.act_out + ipix * p.ld_act : nullptr;
-        const float* rimg = RES ? p.res + ipix * p.ld_res : nullptr;
-        const float* gimg = POST ? p.gact + ipix * p.ld_gact : nullptr;
-        float* y2img = (POST && p.y2) ? p.y2 + ipix * p.ld_y2 : nullptr;
-        if (rowok && !FFT_STUDY(1))
-          epilogue_row<TANH, RES, POST, T, BURST, false>(p, X, 1.f / 1024.f, vx, pix0, sgn, (unsigned)chan, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
-      }
-    }
-    if (next >= nvirt) break;
-    v = __builtin_amdgcn_readfirstlane(next);
-    lds_barrier();                                                       // the LDS image is free for the next item
-  }
-  if (POST && p.bsum) p.bsum[(blockIdx.x * 8 + wave) * 64 + lane] += bsum;    // own slot; a workgroup keeps ONE 16-channel half (the grid is a multiple of 16)
-  if (p.absmax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-    if (lane == 0) {
-      const unsigned bits = __float_as_uint(ymax <= 3.0e38f ? ymax : 3.0e38f);
-      if (bits > __atomic_load_n(p.absmax, __ATOMIC_RELAXED)) atomicMax(p.absmax, bits);
-    }
-  }
-}
-
-// POST with 32-channel items (fft32_inv_kernel): thread t sums the slots (block, wave) = t, t + 256, ... of the lanes that carry the channel
+// POST (fft32_inv_kernel): dbias[ch] from the lanes' partial sums, in a fixed order - thread t sums the slots (block, wave) = t, t + 256, ... of the
+// lanes that carry the channel (lane & 31 = sub cpt + channel for each packed tile, both halves).  One workgroup per channel.
 __global__ __launch_bounds__(256) void fft32_post_bias_kernel(const float* __restrict__ bsum, int nslots, int pack, int cpt, float* __restrict__ dbias) {
   __shared__ float red[256];
   const int ch = blockIdx.x, t = threadIdx.x;
@@ -661,25 +483,6 @@ __global__ __launch_bounds__(256) void fft32_post_bias_kernel(const float* __res
       a += bsum[sl * 64 + c];
       a += bsum[sl * 64 + 32 + c];
     }
-  red[t] = a;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
-  if (t == 0) dbias[ch] = red[0];
-}
-
-// POST with 16-channel items: dbias[ch] from the lanes' partial sums, in a fixed order.  The lane at place L = sub cpt + ch of its 32-channel group
-// (sub: packed tile) lives in the workgroups with (block >> 3) & 1 == L >> 4, lanes with lane & 15 == L & 15 (four lane groups = four rows).
-__global__ __launch_bounds__(256) void fft32h_post_bias_kernel(const float* __restrict__ bsum, int nblocks, int pack, int cpt, float* __restrict__ dbias) {
-  __shared__ float red[256];
-  const int ch = blockIdx.x, t = threadIdx.x;
-  float a = 0.f;
-  for (int sl = t; sl < nblocks * 8 * 4; sl += 256) {                 // (block, wave, lane group)
-    const int lgq = sl & 3, bw = sl >> 2, block = bw >> 3;
-    for (int sub = 0; sub < pack; ++sub) {
-      const int L = sub * cpt + ch;
-      if (((block >> 3) & 1) == (L >> 4)) a += bsum[(size_t)bw * 64 + lgq * 16 + (L & 15)];
-    }
-  }
   red[t] = a;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
@@ -698,6 +501,9 @@ __global__ __launch_bounds__(256) void fft32h_post_bias_kernel(const float* __re
 //            LDS, then cfft_dif<16> in 32 registers.  The two real columns (fx = 0, 32: phase 0) take one wave: lane groups (column, half) with
 //            half E: the even fy as rfft_fwd<32>(u[y] + u[y + 32]), half D: the odd fy as the complex 16-point FFT of the real split.
 constexpr int T64 = 64, ROWS64 = 4096;
+// virtual work item v of the persistent grid -> (tile-and-group index, 16-channel half): v and v + 8 are the two halves of one 32-channel group
+__device__ __forceinline__ void item64(int v, int& tg, int& hf) { tg = (v >> 4) * 8 + (v & 7); hf = (v >> 3) & 1; }
+
 __host__ __device__ __forceinline__ int64_t sp_item64(int64_t item) { return pcnn_spec::sp_item(item, ROWS64); }
 
 
@@ -1171,10 +977,6 @@ void launch_inv_t(pcnn_handle h, const InvParams& p, const dim3& grid) {
 }  // namespace
 
 // persistent kernels: one 16-wave workgroup per CU (128 KB of LDS) walking the (tile, channel group) items
-int fft32_item_channels();
-static void launch_fwd_fft32h(pcnn_handle h, FwdParams p, int ntile);
-static void launch_inv_fft32h(pcnn_handle h, InvParams p, int ntile);
-
 #ifdef PCNN_FFT_STUDY
 static void study_init() { static int once = 0; if (!once) { once = 1; const int v = getenv("PCNN_FFT_STUDY") ? atoi(getenv("PCNN_FFT_STUDY")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fft_study), &v, sizeof(int)); } }
 #else
@@ -1183,7 +985,6 @@ static void study_init() {}
 
 void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
   study_init();
-  if (fft32_item_channels() == 16) { launch_fwd_fft32h(h, p, ntile); return; }
   p.ntile = ntile;
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.ylim < T || p.xlim < T) {
@@ -1195,56 +996,9 @@ void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
   }
 }
 
-// which 32-point FFT kernels run: 16-channel items, two workgroups per CU (default), or 32-channel items, one 16-wave workgroup per CU
-// (PCNN_FFT32_ITEM=32: developer switch for A/B timing and tests)
-int fft32_item_channels() {
-  static const int v = getenv("PCNN_FFT32_ITEM") ? atoi(getenv("PCNN_FFT32_ITEM")) : 16;
-  return v == 32 ? 32 : 16;
-}
-
-static void launch_fwd_fft32h(pcnn_handle h, FwdParams p, int ntile) {
-  p.ntile = ntile;
-  const int ntg = ntile * p.groups;
-  const int nvirt = 2 * ((ntg + 7) & ~7);                            // (tile-and-group) x two 16-channel halves, in blocks of 8 + 8 (item64)
-  const dim3 grid((unsigned)std::min((nvirt + 15) & ~15, 512));      // two workgroups per CU
-  if (p.ylim < T || p.xlim < T) {
-    set_lds(fft32h_fwd_kernel<true>, LDS_H_BYTES);
-    hipLaunchKernelGGL((fft32h_fwd_kernel<true>), grid, dim3(512), LDS_H_BYTES, h->stream, p, nvirt);
-  } else {
-    set_lds(fft32h_fwd_kernel<false>, LDS_H_BYTES);
-    hipLaunchKernelGGL((fft32h_fwd_kernel<false>), grid, dim3(512), LDS_H_BYTES, h->stream, p, nvirt);
-  }
-}
-
-template <bool TANH, bool RES, bool POST>
-static void launch_inv32h_t(pcnn_handle h, const InvParams& p, const dim3& grid, int nvirt) {
-  set_lds(fft32h_inv_kernel<TANH, RES, POST>, LDS_H_BYTES);
-  hipLaunchKernelGGL((fft32h_inv_kernel<TANH, RES, POST>), grid, dim3(512), LDS_H_BYTES, h->stream, p, nvirt);
-}
-
-static void launch_inv_fft32h(pcnn_handle h, InvParams p, int ntile) {
-  p.ntile = ntile;
-  const int ntg = ntile * p.groups;
-  const int nvirt = 2 * ((ntg + 7) & ~7);
-  const dim3 grid((unsigned)std::min((nvirt + 15) & ~15, 512));
-  if (p.gact) {
-    p.alpha = 1.f;
-    p.galpha = p.gmode == PCNN_ACT_LINEAR ? 1.f : (p.gmode == PCNN_ACT_RELU ? 0.f : p.galpha);
-    if (p.res) launch_inv32h_t<false, true, true>(h, p, grid, nvirt); else launch_inv32h_t<false, false, true>(h, p, grid, nvirt);
-    return;
-  }
-  if (p.act == PCNN_ACT_TANH) {
-    if (p.res) launch_inv32h_t<true, true, false>(h, p, grid, nvirt); else launch_inv32h_t<true, false, false>(h, p, grid, nvirt);
-  } else {
-    p.alpha = p.act == PCNN_ACT_LINEAR ? 1.f : (p.act == PCNN_ACT_RELU ? 0.f : p.alpha);
-    if (p.res) launch_inv32h_t<false, true, false>(h, p, grid, nvirt); else launch_inv32h_t<false, false, false>(h, p, grid, nvirt);
-  }
-}
-
-// POST partial sums of the 32-point FFT inverse -> dbias (the layout depends on the kernel family in use)
+// POST partial sums of the 32-point FFT inverse -> dbias
 void launch_post_bias_fft32(pcnn_handle h, const float* bsum, int pack, int cpt, int C, float* dbias) {
-  if (fft32_item_channels() == 16) hipLaunchKernelGGL(fft32h_post_bias_kernel, dim3((unsigned)C), dim3(256), 0, h->stream, bsum, 512, pack, cpt, dbias);
-  else hipLaunchKernelGGL(fft32_post_bias_kernel, dim3((unsigned)C), dim3(256), 0, h->stream, bsum, 256 * FFT_WAVES, pack, cpt, dbias);
+  hipLaunchKernelGGL(fft32_post_bias_kernel, dim3((unsigned)C), dim3(256), 0, h->stream, bsum, 256 * FFT_WAVES, pack, cpt, dbias);
 }
 
 void launch_fwd_fft64(pcnn_handle h, FwdParams p, int ntile) {
@@ -1301,7 +1055,6 @@ void launch_post_bias_fft64(pcnn_handle h, const float* bsum, int nblocks, int C
 
 void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile) {
   study_init();
-  if (fft32_item_channels() == 16) { launch_inv_fft32h(h, p, ntile); return; }
   p.ntile = ntile;
   const dim3 grid((unsigned)std::min(ntile * p.groups, 256));
   if (p.gact) {                                                      // data gradient + the producer's activation backward (linear conv epilogue)
