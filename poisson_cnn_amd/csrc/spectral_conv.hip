@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ per-frequency channel mixing
-struct MixParams { const float* xs; float* ys; const float* wsp; const int4* slots; int ntile, gin, gout, rows, Cin, cpt; };   // wsp: filter spectrum; Cin: its input channels; cpt: lanes per packed tile      // rows: spectrum rows per item (T*T)
+struct MixParams { const float* xs; float* ys; const float* wsp; const int4* slots; int ntile, gin, gout, rows, Cin, cpt, study; };   // wsp: filter spectrum; Cin: its input channels; cpt: lanes per packed tile      // rows: spectrum rows per item (T*T)
 
 // K order inside one 64-row block of M_f (one input channel group): step ks = 16 p + j pairs channel j (lanes 0-31) with channel 16 + j
 // (lanes 32-63) of part p (0: real row, 1: imaginary row) - so a lane's A operands are 16 CONSECUTIVE channels of its tile's row.
@@ -423,7 +423,11 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
   const int slot = blockIdx.x, go = blockIdx.z;
   const int4 sl = p.slots[slot];
+#ifdef PCNN_FFT_STUDY                                                     // diagnostic build (make study): 64 = the imaginary row next to the real one
+  const int rr = (p.study & 64) ? (sl.x & ~1) : sl.x, ri = (p.study & 64) ? (sl.x | 1) : sl.y;
+#else
   const int rr = sl.x, ri = sl.y;
+#endif
   // M_f = [[Hr, Hi], [-Hi, Hr]], H = conj(W^), straight from the filter spectrum Wsp[ci * gout + go][row][co] (conj: correlation): this lane's
   // 16 input channels j + 16 half of its output channel c - 32 loads of L2-resident rows.  A slot that packs two real frequencies (sl.z == 1)
   // is block diagonal in (real row, imaginary row).  cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and M_f is block
@@ -473,6 +477,9 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) {
         const float av = a[ks >> 4][(ks & 15) >> 2][ks & 3];
+#ifdef PCNN_MIX_KEEP                                                      // diagnostic builds only: keep PCNN_MIX_KEEP of every 4 k-steps on the matrix pipe (0: none) - what would
+        if ((ks & 3) >= PCNN_MIX_KEEP) { acc[0][ks & 15] += av * breg[gi][ks][0]; acc[1][ks & 15] += av * breg[gi][ks][1]; continue; }   // fewer MFMAs buy?
+#endif
         acc[0] = mfma(av, breg[gi][ks][0], acc[0]);
         acc[1] = mfma(av, breg[gi][ks][1], acc[1]);
       }
@@ -620,7 +627,11 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
       accp[0] = mfma(a0, t[2][j], accp[0]);
       accp[1] = mfma(a1, t[2][j], accp[1]);
       accp[2] = mfma(a0, t[3][j], accp[2]);
+#if defined(PCNN_MIX_KEEP) && PCNN_MIX_KEEP < 4
+      accp[3][j] += a1 * t[3][j];
+#else
       accp[3] = mfma(a1, t[3][j], accp[3]);
+#endif
     }
   };
   // One M-tile = 8 phases of 16 MFMAs, weight-gradient batches and mixing quarters interleaved (W0 M0 W1 M1 W2 M2 W3 M3) so that every operand
@@ -649,6 +660,9 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
       for (int e = 0; e < 8; ++e) {
         const int j = 8 * (qu & 1) + e;
         const float av = aq[qu & 1][e >> 2][e & 3];
+#ifdef PCNN_MIX_KEEP
+        if ((e & 3) >= PCNN_MIX_KEEP) { acc[0][e] += av * hr[j]; acc[1][e] += av * hi[j]; continue; }
+#endif
         if (qu < 2) {
           acc[0] = mfma(av, hr[j], acc[0]);
           acc[1] = mfma(av * s_neg, hi[j], acc[1]);
@@ -891,6 +905,8 @@ void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
 
 void launch_mix(pcnn_handle h, const Geom& gm, MixParams mx, int gin, int gout, int nt) {
   mx.slots = gm.slots; mx.rows = gm.rows; mx.ntile = nt;
+  static const int study = getenv("PCNN_FFT_STUDY") ? atoi(getenv("PCNN_FFT_STUDY")) : 0;
+  mx.study = study;
   const int nMt = pcnn_cdiv(nt, 32);
   const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
   if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);

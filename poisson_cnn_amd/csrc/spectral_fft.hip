@@ -57,35 +57,11 @@ __device__ __forceinline__ int pad_sel(int i, int n, int mode) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ forward transform
-// ---- hand-managed memory counter -----------------------------------------------------------------------------------------------------------------
-// s_waitcnt vmcnt(n) counts loads AND stores, in issue order.  A persistent transform kernel wants, per item: [next item's 32 loads] ... [this item's
-// 32 spectrum stores] ... consume the loads while the stores are still draining, i.e. s_waitcnt vmcnt(32).  The compiler's own waits do not get
-// there: its pending-operation model is merged conservatively over the kernel's paths (boundary / interior loaders, masked rows, the two y-axis
-// branches) and it ended up waiting for the stores, one more per consumed value - the whole x phase ran behind the store drain (removal study,
-// tools/study_fft.sh: 538 us as shipped = 215 us compute + 323 us memory, added up).  So the window loads are issued from inline assembly - the
-// compiler does not know their results are in flight - and the kernel waits for them itself, once, with the count it knows to be right
-// (vm_wait_loads).  The compiler's waits for ITS operations (the stores) stay correct: untracked younger operations only make them wait longer.
-__device__ __forceinline__ float vm_load(const float* sbase, unsigned voff_bytes) {     // sbase: uniform; address = sbase + voff_bytes
-  float v;
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff_bytes), "s"(sbase) : "memory");
-  return v;
-}
-__device__ __forceinline__ float vm_load_v(const float* vaddr) {                          // per-lane 64-bit address
-  float v;
-  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(vaddr) : "memory");
-  return v;
-}
-// every value of R[0..32) has landed; at most KEEP younger operations (the stores issued after the loads) stay in flight.  The values are operands
-// of the statement, so nothing that uses them is scheduled in front of the wait.
-template <int KEEP> __device__ __forceinline__ void vm_wait_loads(float (&R)[32]) {
-  static_assert(KEEP == 0 || KEEP == 32, "spelled-out immediates");
-  if (KEEP == 32) asm volatile("s_waitcnt vmcnt(32)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]) :: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]) :: "memory");
-  asm volatile("" : "+v"(R[8]), "+v"(R[9]), "+v"(R[10]), "+v"(R[11]), "+v"(R[12]), "+v"(R[13]), "+v"(R[14]), "+v"(R[15]) :: "memory");
-  asm volatile("" : "+v"(R[16]), "+v"(R[17]), "+v"(R[18]), "+v"(R[19]), "+v"(R[20]), "+v"(R[21]), "+v"(R[22]), "+v"(R[23]) :: "memory");
-  asm volatile("" : "+v"(R[24]), "+v"(R[25]), "+v"(R[26]), "+v"(R[27]), "+v"(R[28]), "+v"(R[29]), "+v"(R[30]), "+v"(R[31]) :: "memory");
-}
-
+// (Measured and removed, round 5 - commit "Forward transform loads through hand-managed vmcnt": the window loads issued from inline assembly and waited for
+// by hand with s_waitcnt vmcnt(32), so that the x phase starts while the previous item's 32 spectrum stores are still draining - the compiler's own
+// waits are merged conservatively over the kernel's paths.  Correct in the shipped build (all spectral tests) and not faster: 7 taps forward 1.86 vs
+// 1.84 ms - the kernel sits at the copy ceiling either way.  Removed because it is fragile: the compiler does not know the
+// destination registers are in flight and may copy or reuse them; the diagnostic build of the very same source (-DPCNN_FFT_STUDY) faulted.)
 // what a lane keeps of an item between requesting its window row and consuming it
 struct FwdRow {
   float fill;            // lane: value of a row that is not read from memory (0: beyond ylim / no such channel; the padding constant)
@@ -95,9 +71,8 @@ struct FwdRow {
   bool fast;             // uniform: every window of the item lies inside the image in x
 };
 
-// requests window row y of `item` for the lane at position c of its 32-channel group: 32 loads with always-valid addresses; padding and masks are
-// applied on consumption
-__device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int row0, int y, int c, FwdRow& it, float (&R)[32]) {
+// requests window row y (lane: y = 2 wave + half) of `item`: 32 loads with always-valid addresses; padding and masks are applied on consumption
+__device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int wave, int y, int c, FwdRow& it, float (&R)[32]) {
   const int g = item % p.groups;
   int t = p.tile0 + item / p.groups;
   const int txg = t % p.tgx; t /= p.tgx;
@@ -119,29 +94,20 @@ __device__ __forceinline__ void fwd_request(const FwdParams& p, int item, int ro
   it.cl = 0; it.cr = T;
   const int wx_first = txg * p.pack * p.Vx - p.ox, wx_last = wx_first + (p.pack - 1) * p.Vx;
   it.fast = wx_first >= 0 && wx_last + T <= p.W;                               // uniform
+  if (2 * wave >= ylim || FFT_STUDY(2)) return;                                // uniform: both rows of this wave are zero rows - nothing to fetch
   const int sy = pad_sel(gy, p.H, p.pad_mode);
   const unsigned ch = (unsigned)(cok ? chan : 0);
-  if (row0 >= ylim || FFT_STUDY(2)) {
-    // uniform (row0: the wave's first row): all rows of this wave are zero rows.  Nothing needs fetching - but the NUMBER of memory operations per
-    // item must not depend on the path: s_waitcnt vmcnt counts loads and stores in issue order, and where the count differs between paths the
-    // compiler's waits in the x phase assume the fewest, i.e. they also wait for the previous item's spectrum stores, one more per value (that
-    // serialised the whole x phase behind the store drain: tools/study_fft.sh).  32 loads of one resident line cost next to nothing.
-    // (Since the loads come from inline assembly - vm_load - and the kernel counts for itself, the count must be exact on every path.)
-#pragma unroll
-    for (int x = 0; x < T; ++x) R[x] = vm_load(img, 4u * ch);
-    return;
-  }
   if (it.fast) {
     // one lane offset for all 32 loads; the uniform pointer steps from pixel to pixel on the scalar ALU
-    const unsigned lo = 4u * ((unsigned)((sy * p.W + wx0) * p.ld) + ch);
+    const unsigned lo = (unsigned)((sy * p.W + wx0) * p.ld) + ch;
     const float* rp = img;
 #pragma unroll
-    for (int x = 0; x < T; ++x) { R[x] = vm_load(rp, lo); rp += p.ld; }
+    for (int x = 0; x < T; ++x) { R[x] = rp[lo]; rp += p.ld; }
   } else {
     const unsigned rowoff = (unsigned)(sy * p.W * p.ld) + ch;
     if (p.pad_mode == PCNN_PAD_CONSTANT) { it.cl = -wx0; it.cr = p.W - wx0; }
 #pragma unroll
-    for (int x = 0; x < T; ++x) R[x] = vm_load(img, 4u * (rowoff + (unsigned)(pad_sel(wx0 + x, p.W, p.pad_mode) * p.ld)));
+    for (int x = 0; x < T; ++x) R[x] = img[rowoff + (unsigned)(pad_sel(wx0 + x, p.W, p.pad_mode) * p.ld)];
   }
 }
 
@@ -187,12 +153,9 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   const int y = 2 * wave + half;
   float R[32];
   FwdRow cur;
-  fwd_request(p, item, 2 * wave, y, c, cur, R);
+  fwd_request(p, item, wave, y, c, cur, R);
   // ---- x axis: this lane's window row, real -> half-complex, into LDS
-  auto x_phase = [&](bool stores_behind) {
-    // the loads were issued by vm_load: this is the one wait for them.  Inside the loop exactly 32 stores were issued after them (both y-axis
-    // branches store 32 values per lane) and may stay in flight; in front of the loop nothing follows the loads.
-    if (stores_behind && !FFT_STUDY(1)) vm_wait_loads<32>(R); else vm_wait_loads<0>(R);
+  auto x_phase = [&]() {
     fwd_consume<MASKED>(p, cur, R);
     if (!FFT_STUDY(4)) rfft_fwd<32>(R);
     float* u = U + (y * 32) * 32 + c;
@@ -201,12 +164,10 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   };
   // (first x phase outside the loop: every x phase inside it then meets the same memory-counter state - the next item's loads, then this item's
   // stores - as in spec_fwd_kernel)
-  x_phase(false);
+  x_phase();
   for (;;) {
     const int next = item + gridDim.x;
-    // the next item's window row lands under the y phase below; the last item re-requests itself instead of branching around the loads (a static
-    // number of memory operations per pass: 32 loads, then 32 stores - the x phase's waits then leave exactly the stores in flight)
-    fwd_request(p, next < total ? next : item, 2 * wave, y, c, cur, R);
+    if (next < total) fwd_request(p, next, wave, y, c, cur, R);      // lands under the y phase below
     lds_barrier();
     float* out = p.sp + sp_item32(item);
     float V[32];
@@ -253,7 +214,7 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
     if (next >= total) break;
     item = __builtin_amdgcn_readfirstlane(next);
     lds_barrier();                                                       // U is free for the next item
-    x_phase(true);
+    x_phase();
   }
 }
 
