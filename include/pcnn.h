@@ -99,7 +99,21 @@ int pcnn_get_spectral_tile(pcnn_handle h);
 enum { PCNN_XFORM_MFMA = 0, PCNN_XFORM_FFT = 1 };
 int pcnn_set_spectral_transform(pcnn_handle h, int xform);
 int pcnn_get_spectral_transform(pcnn_handle h);
-/* The ONE buffer a handle owns besides small scratch: the spectral workspace (tile spectra of the layer in flight, mixing matrices,
+/* Filter spectra across calls (round 5).  A filter's spectrum depends on the weights alone; by default (version 0) every spectral convolution call
+ * recomputes it into the workspace - correct for any caller, ~10 us + a launch gap per call.  A caller that knows WHEN its weights change tells the
+ * handle: pcnn_set_filter_version(h, v) with v != 0 promises that every filter pointer passed to pcnn_conv2d_fwd / pcnn_conv2d_bwd_spectral(_post)
+ * while the version is v holds the same values as at the first call under v.  The handle then keeps each filter's spectrum (key: pointer, shape, tile
+ * size, transform family) in a buffer of its own; a call under the same version reuses it, and the first call under a NEW version refreshes every
+ * filter the handle knows in ONE launch per tile size.  Inference: set a version once - no filter work after the first call.  Training: bump the
+ * version after each optimizer step - one or two launches per step instead of one per layer and direction.  The setting is per call sequence: set 0
+ * again before passing filters whose contents the version does not describe (poisson_cnn_amd.ops does that for every call without `w_version`).
+ * Contract: a cached filter pointer must stay readable until pcnn_filter_cache_clear / pcnn_destroy (the refresh reads every known filter); memory:
+ * Cin x ceil(Cout/32) x T^2 x 128 B per filter (4 MB at 32 -> 32 channels and 32-point tiles, 16 MB at 64-point tiles), pcnn_filter_cache_stats.
+ * Under stream capture nothing is allocated: a filter first seen there is transformed into the workspace as with version 0. */
+int pcnn_set_filter_version(pcnn_handle h, uint64_t version);
+int pcnn_filter_cache_clear(pcnn_handle h);
+int pcnn_filter_cache_stats(pcnn_handle h, long long* entries, long long* bytes, long long* hits, long long* fills, long long* refreshes);
+/* The one LARGE buffer a handle owns (besides small scratch and, when a filter version is set, the kept filter spectra above): the spectral workspace (tile spectra of the layer in flight, mixing matrices,
  * constant tables).  By default it grows to a whole layer per launch - 8 x 1024^2 x 32 channels at 15 taps: ~11 GB, sized for 288 GB of
  * HBM.  pcnn_set_workspace_limit caps it (bytes; 0 = no cap): the launches then cover fewer tiles each (never fewer than 32; a layer that
  * cannot run inside the cap fails with an ordinary error), so a host program that budgets device memory itself decides what the
@@ -140,6 +154,10 @@ int pcnn_conv2d_fwd_absmax(pcnn_handle h, const pcnn_conv_desc* d, const float* 
 
 /* w (kh,kw,Cin,Cout) -> wt (kh,kw,Cout,Cin) with both taps reversed: the filter of the data-gradient convolution. */
 int pcnn_conv2d_flip_transpose_weights(pcnn_handle h, const float* w, float* wt, int kh, int kw, int Cin, int Cout);
+/* The same for n filters in ONE launch (a model's ~100 flipped filters are all re-formed when the weights change): `table_dev` is an array of n items in
+ * DEVICE memory, ordered by `start` = the running sum of the previous items' element counts (start of item 0 = 0), total = the sum over all items. */
+typedef struct pcnn_flip_item { const float* w; float* wt; int kh, kw, Cin, Cout; int64_t start; } pcnn_flip_item;
+int pcnn_conv2d_flip_transpose_table(pcnn_handle h, const pcnn_flip_item* table_dev, int n, int64_t total);
 
 /* Filter gradient of the convolution above (tf.nn.conv2d backprop-filter):
  *   dw[i,j,ci,co] = sum_{n,y,x} xpad[n, y - pad_top + i, x - pad_left + j, ci] * dz[n,y,x,co]

@@ -208,6 +208,19 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
   }
 }
 
+// the same for a whole table of filters in one launch (pcnn_conv2d_flip_transpose_table): element i of the concatenated outputs belongs to the
+// last entry whose `start` is <= i
+__global__ void flip_transpose_table_kernel(const pcnn_flip_item* __restrict__ tab, int n, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= i) lo = mid; else hi = mid - 1; }
+    const pcnn_flip_item it = tab[lo];
+    const int64_t e = i - it.start;
+    int ci = e % it.Cin; int64_t r = e / it.Cin; int co = r % it.Cout; r /= it.Cout; int j = r % it.kw; int ii = r / it.kw;
+    it.wt[e] = it.w[(((int64_t)(it.kh - 1 - ii) * it.kw + (it.kw - 1 - j)) * it.Cin + ci) * it.Cout + co];
+  }
+}
+
 }  // namespace
 
 extern "C" int pcnn_conv2d_fwd_absmax(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -291,6 +304,14 @@ extern "C" int pcnn_conv2d_fwd(pcnn_handle h, const pcnn_conv_desc* d, const flo
     hipLaunchKernelGGL(conv_fwd_kernel<2>, grid, block, lds, h->stream, p);
   }
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_fwd");
+  return 0;
+}
+
+extern "C" int pcnn_conv2d_flip_transpose_table(pcnn_handle h, const pcnn_flip_item* table_dev, int n, int64_t total) {
+  PCNN_REQUIRE(h, h && table_dev && n > 0 && total > 0, "pcnn_conv2d_flip_transpose_table: bad argument");
+  const int blocks = (int)std::min<int64_t>(pcnn_cdiv64(total, 256), 4096);
+  hipLaunchKernelGGL(flip_transpose_table_kernel, dim3(blocks), dim3(256), 0, h->stream, table_dev, n, total);
+  PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_flip_transpose_table");
   return 0;
 }
 

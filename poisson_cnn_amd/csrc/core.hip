@@ -25,6 +25,7 @@ extern "C" int pcnn_destroy(pcnn_handle h) {
   if (h && h->aux_ws) (void)hipFree(h->aux_ws);
   if (h) for (void* p : h->retired) (void)hipFree(p);
   if (h && h->comm) pcnn_comm_release(h);
+  if (h) pcnn_filter_cache_free(h);
   delete h;
   return 0;
 }

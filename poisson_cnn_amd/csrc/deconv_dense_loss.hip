@@ -163,14 +163,23 @@ __global__ __launch_bounds__(256) void spp_max_fwd_kernel(int H, int W, int C, i
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[n * nb + b] = bv[0]; argmax[n * nb + b] = bi[0]; }
+  // a bin that holds nothing but NaN never passes `v > best`: its maximum is NaN (tf.reduce_max propagates it) and its argmax must still be an
+  // index INSIDE the tensor - the backward kernel writes through it
+  if (threadIdx.x == 0) {
+    const bool none = bi[0] == 0x7fffffff;
+    out[n * nb + b] = none ? __builtin_nanf("") : bv[0];
+    argmax[n * nb + b] = none ? (y0 * W + x0) * C : bi[0];
+  }
 }
 
 __global__ void spp_max_bwd_kernel(int N, int64_t per, int nb, const int32_t* __restrict__ argmax, const float* __restrict__ dout, float* __restrict__ dx) {
   // one thread per sample: bins of different pyramid levels overlap, so accumulate serially (nb <= a few dozen)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  for (int b = 0; b < nb; ++b) dx[(int64_t)n * per + argmax[n * nb + b]] += dout[n * nb + b];
+  for (int b = 0; b < nb; ++b) {
+    const int a = argmax[n * nb + b];
+    if ((unsigned)a < (uint64_t)per) dx[(int64_t)n * per + a] += dout[n * nb + b];          // (an index outside the sample is never written through)
+  }
 }
 
 // ---------------------------------------------------------------- loss

@@ -25,11 +25,14 @@ struct pcnn_handle_s {
   int spectral_xform = 1;         // transform kernels of the spectral route: 1 = in-register FFT on the vector ALUs (default since round 5), 0 = DFT as a GEMM on the matrix cores (pcnn_set_spectral_transform)
   int retain = 0;                 // pcnn_set_workspace_retain: outgrown handle-owned buffers are kept (a captured hipGraph may still replay into them)
   std::vector<void*> retired;     // ... here, until pcnn_destroy
+  unsigned long long filter_version = 0;   // pcnn_set_filter_version: 0 = filter spectra are recomputed by every call; else the caller's weights version
+  void* filter_cache = nullptr;   // ... and the spectra kept per (filter pointer, shape, tile size), spectral_conv.hip
   void* comm = nullptr;           // RCCL communicator (ncclComm_t) of pcnn_comm_init, see collective.hip
   int comm_rank = 0, comm_size = 0;
 };
 
 void pcnn_comm_release(pcnn_handle_s* h);   // collective.hip
+void pcnn_filter_cache_free(pcnn_handle_s* h);   // spectral_conv.hip
 
 // A handle-owned buffer is being outgrown (or capped): free it once the stream has drained - unless the caller declared that recorded work
 // (a hipGraph captured on this handle's stream) may still use it; then it is parked until pcnn_destroy.

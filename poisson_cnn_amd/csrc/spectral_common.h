@@ -85,6 +85,8 @@ void launch_post_bias64(pcnn_handle h, const float* bsum, int nblocks, int C, fl
 // the POST partial sums hold one float per (block, wave, lane) with FFT_WAVES waves per block
 constexpr int FFT_WAVES = 16;
 void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile);
+void launch_fwd_fft32_multi(pcnn_handle h, const FwdParams* tab, int count, int max_items);   // `count` one-tile transforms (filters) from a device table of parameter blocks
+void launch_fwd_fft64_multi(pcnn_handle h, const FwdParams* tab, int count, int max_items);
 void launch_inv_fft32(pcnn_handle h, InvParams p, int ntile);
 void launch_post_bias_fft32(pcnn_handle h, const float* bsum, int pack, int cpt, int C, float* dbias);     // POST partial sums of the FFT inverse in use -> dbias
 void launch_fwd_fft64(pcnn_handle h, FwdParams p, int ntile);       // 64-point tiles, item = (tile, 16 channels), 8 waves x 2 units

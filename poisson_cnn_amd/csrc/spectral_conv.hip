@@ -1037,6 +1037,121 @@ InvParams taps_params(const Geom& gm, const float* csp, float* dw, int kh, int k
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------ filter-spectrum cache
+// A filter's spectrum depends on the weights alone, yet every convolution call recomputed it: ~140 launches of ~10 us (+ the gaps around them) per
+// training step of hpnn.json, on the stream's critical path, and again on every inference call although the weights never change.
+// With pcnn_set_filter_version(h, v != 0) the handle keeps the spectrum of every filter it has seen - key: pointer, shape, tile size, transform family -
+// in buffers of its own, stamped with v.  A call that finds its filter stamped with the current version uses it as it is; the first call that finds a
+// stale stamp refreshes EVERY filter of the handle in one launch per tile size (fft32 / fft64_fwd_multi_kernel: the table of parameter blocks lives in
+// device memory and changes only when a filter is added), so a training step pays one or two launches instead of one per layer and direction.
+// Nothing is allocated or uploaded while the stream is being captured: a filter first seen under capture is transformed into the workspace as before.
+namespace {
+struct FilterEntry { const float* w; int kh, kw, Cin, Cout, gout, T, xform; float* buf; unsigned long long version; FwdParams fp; };
+struct FilterCache {
+  std::vector<FilterEntry> e;
+  std::vector<FwdParams> host[2];                                   // [0]: 32-point entries, [1]: 64-point entries (FFT family), in the order of the device table
+  FwdParams* dev[2] = {nullptr, nullptr};
+  size_t cap[2] = {0, 0};
+  long long hits = 0, fills = 0, refreshes = 0;
+  size_t bytes = 0;
+};
+FilterCache* cache_of(pcnn_handle h) {
+  if (!h->filter_cache) h->filter_cache = new FilterCache();
+  return static_cast<FilterCache*>(h->filter_cache);
+}
+// every entry of the handle gets the current version: one table launch per tile size (FFT family), one launch per entry otherwise
+void refresh_filters(pcnn_handle h, FilterCache* fc) {
+  for (int ti = 0; ti < 2; ++ti) {
+    if (fc->host[ti].empty()) continue;
+    int max_items = 1;
+    for (const FwdParams& f : fc->host[ti]) max_items = std::max(max_items, f.groups);
+    if (ti == 0) launch_fwd_fft32_multi(h, fc->dev[0], (int)fc->host[0].size(), max_items);
+    else launch_fwd_fft64_multi(h, fc->dev[1], (int)fc->host[1].size(), max_items);
+  }
+  for (FilterEntry& en : fc->e) {
+    if (en.xform != PCNN_XFORM_FFT && en.version != h->filter_version) {
+      const Geom gm = geom_of(h, en.T);
+      en.fp.tab = gm.tab;                                           // the tables move when the workspace grows
+      launch_fwd(h, gm, en.fp, 1);
+    }
+    en.version = h->filter_version;
+  }
+  ++fc->refreshes;
+}
+// the spectrum of filter `w` ((kh, kw, Cin, Cout), output channel groups gout) for this call: a cached buffer, or `ws_slot` freshly filled
+const float* filter_spectrum(pcnn_handle h, const Geom& gm, const float* w, float* ws_slot, int kh, int kw, int Cin, int Cout, int gout) {
+  auto uncached = [&]() { launch_fwd(h, gm, filter_params(gm, w, ws_slot, kh, kw, Cin, Cout, gout), 1); return ws_slot; };
+  if (h->filter_version == 0) return uncached();
+  FilterCache* fc = cache_of(h);
+  for (FilterEntry& en : fc->e)
+    if (en.w == w && en.kh == kh && en.kw == kw && en.Cin == Cin && en.Cout == Cout && en.gout == gout && en.T == gm.T && en.xform == h->spectral_xform) {
+      if (en.version != h->filter_version) refresh_filters(h, fc); else ++fc->hits;
+      return en.buf;
+    }
+  // first sight of this filter: a buffer of its own - unless the stream is being captured (no allocation, no upload inside a capture)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return uncached(); }
+  const size_t bytes = align256(sp_bytes((size_t)Cin * gout, gm.rows));
+  void* buf = nullptr;
+  if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return uncached(); }
+  FilterEntry en{w, kh, kw, Cin, Cout, gout, gm.T, h->spectral_xform, static_cast<float*>(buf), h->filter_version,
+                 filter_params(gm, w, static_cast<float*>(buf), kh, kw, Cin, Cout, gout)};
+  en.fp.ntile = 1;
+  if (en.xform == PCNN_XFORM_FFT) {
+    const int ti = gm.T == 64 ? 1 : 0;
+    const size_t n = fc->host[ti].size() + 1;
+    if (n > fc->cap[ti]) {
+      const size_t cap = std::max<size_t>(64, 2 * n);
+      void* t = nullptr;
+      if (hipMalloc(&t, cap * sizeof(FwdParams)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return uncached(); }   // no table: the filter stays uncached
+      if (fc->dev[ti]) pcnn_release(h, fc->dev[ti]);
+      fc->dev[ti] = static_cast<FwdParams*>(t); fc->cap[ti] = cap;
+    }
+    fc->host[ti].push_back(en.fp);
+    // (synchronous copy of the whole table: once per filter, in the first step that sees it; the stream may still be reading the old contents)
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipMemcpy(fc->dev[ti], fc->host[ti].data(), n * sizeof(FwdParams), hipMemcpyHostToDevice);
+  }
+  launch_fwd(h, gm, en.fp, 1);
+  fc->e.push_back(en);
+  fc->bytes += bytes;
+  ++fc->fills;
+  return en.buf;
+}
+}  // namespace
+
+void pcnn_filter_cache_free(pcnn_handle_s* h) {
+  if (!h || !h->filter_cache) return;
+  FilterCache* fc = static_cast<FilterCache*>(h->filter_cache);
+  for (FilterEntry& en : fc->e) pcnn_release(h, en.buf);
+  for (int ti = 0; ti < 2; ++ti) if (fc->dev[ti]) pcnn_release(h, fc->dev[ti]);
+  delete fc;
+  h->filter_cache = nullptr;
+}
+
+extern "C" int pcnn_set_filter_version(pcnn_handle h, uint64_t version) {
+  if (!h) return 1;
+  h->filter_version = version;
+  return 0;
+}
+
+extern "C" int pcnn_filter_cache_clear(pcnn_handle h) {
+  if (!h) return 1;
+  pcnn_filter_cache_free(h);
+  return 0;
+}
+
+extern "C" int pcnn_filter_cache_stats(pcnn_handle h, long long* entries, long long* bytes, long long* hits, long long* fills, long long* refreshes) {
+  if (!h) return 1;
+  const FilterCache* fc = static_cast<const FilterCache*>(h->filter_cache);
+  if (entries) *entries = fc ? (long long)fc->e.size() : 0;
+  if (bytes) *bytes = fc ? (long long)fc->bytes : 0;
+  if (hits) *hits = fc ? fc->hits : 0;
+  if (fills) *fills = fc ? fc->fills : 0;
+  if (refreshes) *refreshes = fc ? fc->refreshes : 0;
+  return 0;
+}
+
 int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                            const float* bn_shift, const float* residual, float* y, float* act_out) {
   const int Tg = pick_tile(h, d);
@@ -1059,7 +1174,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   float* wsp = reinterpret_cast<float*>(r); r += wsp_b;
   float* xs = reinterpret_cast<float*>(r); r += xs_b;
   float* ys = reinterpret_cast<float*>(r);
-  launch_fwd(h, gm, filter_params(gm, w, wsp, d->kh, d->kw, d->Cin, d->Cout, gout), 1);
+  const float* fsp = filter_spectrum(h, gm, w, wsp, d->kh, d->kw, d->Cin, d->Cout, gout);
   PCNN_CHECK_LAUNCH(h, "spectral convolution (filter spectrum)");
   FwdParams fx;
   fx.x = x; fx.sp = xs; fx.tab = gm.tab; fx.H = d->H; fx.W = d->W; fx.C = d->Cin; fx.ld = d->ldx; fx.groups = gin; fx.cstride = 32; fx.cvalid = 32;
@@ -1075,7 +1190,7 @@ int pcnn_spectral_conv_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* 
   iv.pack = pack; iv.cpt = cpt; iv.tgx = tgx;
   if (pack > 1) { iv.cstride = cpt; iv.cvalid = cpt; }
   MixParams mx;
-  mx.xs = xs; mx.ys = ys; mx.wsp = wsp; mx.gin = gin; mx.gout = gout; mx.Cin = d->Cin; mx.cpt = cpt;
+  mx.xs = xs; mx.ys = ys; mx.wsp = fsp; mx.gin = gin; mx.gout = gout; mx.Cin = d->Cin; mx.cpt = cpt;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
     fx.tile0 = (int)t0; iv.tile0 = (int)t0;
@@ -1258,7 +1373,7 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
   float* bsum = post ? reinterpret_cast<float*>(r) : nullptr;
   // flipped filter spectrum -> mixing matrices of the data gradient (input groups: dz's, output groups: dx's)
   PCNN_REQUIRE(h, gx == 1 || dg->Cout == 64, "pcnn_conv2d_bwd_spectral: %d input channels unsupported (<= 32 or 64)", d->Cin);
-  launch_fwd(h, gm, filter_params(gm, w_flipped, wsp, d->kh, d->kw, dg->Cin, dg->Cout, gx), 1);
+  const float* fsp = filter_spectrum(h, gm, w_flipped, wsp, d->kh, d->kw, dg->Cin, dg->Cout, gx);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral (filter spectrum)");
   FwdParams fz;                                          // dz windows with halo: the data gradient's input transform
   fz.x = dz; fz.sp = zs; fz.tab = gm.tab; fz.H = dg->H; fz.W = dg->W; fz.C = dg->Cin; fz.ld = dg->ldx; fz.groups = gz; fz.cstride = 32; fz.cvalid = 32;
@@ -1283,12 +1398,12 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
     if (iv.bsum && hipMemsetAsync(bsum, 0, bs_b, h->stream) != hipSuccess) PCNN_FAIL(h, "pcnn_conv2d_bwd_spectral_post: memset failed");
   }
   MixParams mx;
-  mx.xs = zs; mx.ys = ys; mx.wsp = wsp; mx.gin = gz; mx.gout = gx; mx.Cin = dg->Cin; mx.cpt = cpt;
+  mx.xs = zs; mx.ys = ys; mx.wsp = fsp; mx.gin = gz; mx.gout = gx; mx.Cin = dg->Cin; mx.cpt = cpt;
   WMixParams wm;
   wm.xs = xs; wm.ds = zs; wm.part = part; wm.slots = gm.slots; wm.gin = gx; wm.S = S / 4; wm.rows = rows; wm.nslot = nslot;
   static const int fused_mix = getenv("PCNN_SPEC_MIXW") ? atoi(getenv("PCNN_SPEC_MIXW")) : 1;   // developer switch (A/B timing): 0 = two kernels
   MixWParams mw;
-  mw.zs = zs; mw.xs = xs; mw.ys = ys; mw.part = part; mw.wsp = wsp; mw.slots = gm.slots; mw.gx = gx; mw.rows = rows; mw.nslot = nslot;
+  mw.zs = zs; mw.xs = xs; mw.ys = ys; mw.part = part; mw.wsp = fsp; mw.slots = gm.slots; mw.gx = gx; mw.rows = rows; mw.nslot = nslot;
   mw.Cz = dg->Cin; mw.cpt = cpt;
   for (int64_t t0 = 0; t0 < ntile; t0 += chunk) {
     const int nt = (int)std::min<int64_t>(chunk, ntile - t0);
@@ -1312,7 +1427,7 @@ static int bwd_spectral_impl(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_
     else if (h->spectral_xform == PCNN_XFORM_FFT) launch_post_bias_fft32(h, bsum, pack, cpt, dg->Cout, post->dbias);
     else hipLaunchKernelGGL(spec_post_bias_kernel, dim3((unsigned)dg->Cout), dim3(256), 0, h->stream, bsum, 256 * 8, pack, cpt, post->dbias);
   }
-  float* csp = wsp;                                      // the filter spectrum is no longer needed: every mixing launch above has read it (same stream)
+  float* csp = wsp;                                      // the workspace's filter-spectrum slot: every mixing launch above has read it (same stream), or the spectrum came from the cache
   hipLaunchKernelGGL(spec_wcombine_kernel, dim3(nslot, gx), dim3(256), 0, h->stream, part, gm.slots, csp, S, gx, d->Cin, -1.0f, cpt, rows);
   launch_inv(h, gm, taps_params(gm, csp, dw, d->kh, d->kw, d->Cin, d->Cout, 1), 1);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_bwd_spectral");

@@ -142,13 +142,14 @@ __device__ __forceinline__ void hc_put(float (&R)[32], int s, float v) {
   R[pos] = neg ? -v : v;
 }
 
+// (the kernel body as a function of (parameter block, first item, item stride): fft32_fwd_kernel walks one layer, fft32_fwd_multi_kernel one entry
+// of a table of layers per blockIdx.y - the filter spectra of a whole model in one launch, pcnn_set_filter_version)
 template <bool MASKED>
-__global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*32 + c]
+__device__ __forceinline__ void fft32_fwd_body(const FwdParams& p, float* U, const int bid, const int gdim) {          // U[(y*32 + s)*32 + c]
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int total = p.ntile * p.groups;
-  int item = blockIdx.x;
+  int item = bid;
   if (item >= total) return;
   const int y = 2 * wave + half;
   float R[32];
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
   // stores - as in spec_fwd_kernel)
   x_phase();
   for (;;) {
-    const int next = item + gridDim.x;
+    const int next = item + gdim;
     if (next < total) fwd_request(p, next, wave, y, c, cur, R);      // lands under the y phase below
     lds_barrier();
     float* out = p.sp + sp_item32(item);
@@ -216,6 +217,30 @@ __global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
     lds_barrier();                                                       // U is free for the next item
     x_phase();
   }
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(1024) void fft32_fwd_kernel(FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float U[];
+  fft32_fwd_body<MASKED>(p, U, blockIdx.x, gridDim.x);
+}
+
+// a parameter block from a device table into scalar registers (the table index is uniform; readfirstlane says so to the compiler)
+__device__ __forceinline__ FwdParams load_fwd_params(const FwdParams* q) {
+  static_assert(sizeof(FwdParams) % 4 == 0, "FwdParams is copied word by word");
+  FwdParams p;
+  const int* s = reinterpret_cast<const int*>(q);
+  int* d = reinterpret_cast<int*>(&p);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(FwdParams) / 4); ++i) d[i] = __builtin_amdgcn_readfirstlane(s[i]);
+  return p;
+}
+
+// blockIdx.y = table entry (one filter: a one-tile "image" with Cin x Cout channels), blockIdx.x walks its items
+__global__ __launch_bounds__(1024) void fft32_fwd_multi_kernel(const FwdParams* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) float U[];
+  const FwdParams p = load_fwd_params(tab + blockIdx.y);
+  fft32_fwd_body<true>(p, U, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ inverse transform + epilogue
@@ -577,12 +602,11 @@ __device__ __forceinline__ void y64_gather(const float* U, int offr, int offi, i
 constexpr bool PF64_FULL = PCNN_PF64_FULL; // 8-wave form: request BOTH rows of the next item under the even y phase (128 registers in flight: spills ~60)
 constexpr bool PF64_ONE = PCNN_PF64_ONE;   // 16-wave form: request the next item's row under the even y phase (64 registers in flight)
 template <bool MASKED, int NU>
-__global__ __launch_bounds__(1024 / NU) void fft64_fwd_kernel(FwdParams p, int nvirt) {
-  extern __shared__ __attribute__((aligned(16))) float U[];          // U[(y*32 + s)*16 + c16], y < 64, s < 32: one x-parity phase
+__device__ __forceinline__ void fft64_fwd_body(const FwdParams& p, const int nvirt, float* U, const int bid, const int gdim) {   // U[(y*32 + s)*16 + c16], y < 64, s < 32: one x-parity phase
   const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, c16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntg = p.ntile * p.groups;
-  int v = blockIdx.x;
+  int v = bid;
   if (v >= nvirt) return;
   float* const TW = U + 64 * 32 * 16;                                // W64^(cl y), cl < 4, y < 16: 128 floats behind the phase image
   if (tid < 64) { TW[2 * tid] = cos64(((tid >> 4) * (tid & 15)) & 63); TW[2 * tid + 1] = -sin64(((tid >> 4) * (tid & 15)) & 63); }
@@ -596,7 +620,7 @@ __global__ __launch_bounds__(1024 / NU) void fft64_fwd_kernel(FwdParams p, int n
   if (NU == 2 || PF64_ONE) fwd64_request<0>(cur, row, R);
   if (NU == 2 && PF64_FULL) fwd64_request<1>(cur, row, R);
   for (;;) {
-    const int next = v + gridDim.x;
+    const int next = v + gdim;
     const bool more = next < nvirt;
     // (unit 0's row was requested a phase ahead - below; unit 1's here: the registers cannot hold both beside the y-axis state)
     if (NU == 2 && !PF64_FULL) fwd64_request<1>(cur, row, R);
@@ -725,6 +749,20 @@ __global__ __launch_bounds__(1024 / NU) void fft64_fwd_kernel(FwdParams p, int n
     v = __builtin_amdgcn_readfirstlane(next);
     lds_barrier();                                                       // U is free for the next item
   }
+}
+
+template <bool MASKED, int NU>
+__global__ __launch_bounds__(1024 / NU) void fft64_fwd_kernel(FwdParams p, int nvirt) {
+  extern __shared__ __attribute__((aligned(16))) float U[];
+  fft64_fwd_body<MASKED, NU>(p, nvirt, U, blockIdx.x, gridDim.x);
+}
+
+// the table form (fft32_fwd_multi_kernel): blockIdx.y = entry; gridDim.x is a multiple of 16 (a workgroup keeps one 16-channel half)
+__global__ __launch_bounds__(512) void fft64_fwd_multi_kernel(const FwdParams* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) float U[];
+  const FwdParams p = load_fwd_params(tab + blockIdx.y);
+  const int ntg = p.ntile * p.groups;
+  fft64_fwd_body<true, 2>(p, 2 * ((ntg + 7) & ~7), U, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ 64-point inverse + epilogue
@@ -955,6 +993,17 @@ void launch_fwd_fft32(pcnn_handle h, FwdParams p, int ntile) {
     set_lds(fft32_fwd_kernel<false>);
     hipLaunchKernelGGL((fft32_fwd_kernel<false>), grid, dim3(1024), LDS_BYTES, h->stream, p);
   }
+}
+
+// `count` filters (table entries in device memory, ntile = 1 each) in one launch; max_items: the largest groups value among them
+void launch_fwd_fft32_multi(pcnn_handle h, const FwdParams* tab, int count, int max_items) {
+  set_lds(fft32_fwd_multi_kernel);
+  hipLaunchKernelGGL(fft32_fwd_multi_kernel, dim3((unsigned)std::min(max_items, 64), (unsigned)count), dim3(1024), LDS_BYTES, h->stream, tab);
+}
+void launch_fwd_fft64_multi(pcnn_handle h, const FwdParams* tab, int count, int max_items) {
+  set_lds(fft64_fwd_multi_kernel, LDS64_BYTES);
+  const int nvirt = 2 * ((max_items + 7) & ~7);
+  hipLaunchKernelGGL(fft64_fwd_multi_kernel, dim3((unsigned)std::min((nvirt + 15) & ~15, 64), (unsigned)count), dim3(512), LDS64_BYTES, h->stream, tab);
 }
 
 // POST partial sums of the 32-point FFT inverse -> dbias

@@ -69,7 +69,8 @@ class _Captured:
                 ops.handle().call('pcnn_set_workspace_retain', c_int(1))
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            ops.weights_changed()                                     # a replay must refresh the cached filter spectra (the weights move between replays,
+            with torch.cuda.graph(self.graph, stream=self.stream):    # no host code runs): the refresh launch is recorded only if the version is new here
                 out = fn()
             torch.cuda.synchronize()
         finally:

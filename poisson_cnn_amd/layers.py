@@ -89,6 +89,22 @@ class ParamStore:
     def trainable_names(self):
         return [s[0] for s in self.specs if s[3] in ('w', 'bn_gamma', 'bn_beta')]
 
+    def filter_version(self):
+        """The weights version a convolution of this bucket passes to libpcnn (ops.filter_version).  torch-side writes to the bucket - copy_, an
+        optimizer of torch.optim through autograd.Differentiable, a user's in-place op - move Tensor._version and are noticed here; the library's own
+        writers (train.Adam / SGD, parallel's broadcast) call ops.weights_changed() themselves."""
+        v = self.flat_w._version
+        if v != getattr(self, '_seen_version', None):
+            self._seen_version = v
+            ops.weights_changed()
+        return ops.filter_version()
+
+    def __del__(self):
+        try:
+            ops.weights_released()
+        except Exception:
+            pass
+
     def initialize(self, seed=0):
         """Keras defaults: Glorot-uniform kernels (and deconv bias, layers/deconvupscale.py:37-38,60-62), zero biases,
         BN gamma=1 beta=0 mean=0 var=1."""
@@ -241,6 +257,7 @@ class ConvUnit:
 
     def _forward(self, x, residual=None, out=None, training=True, x_absmax=None):
         self.out_absmax = None
+        ops.sync_flipped_filters(self.store.filter_version())
         w = self.store.w[self.name + '/kernel']
         b = self.store.w[self.name + '/bias'] if self.use_bias else None
         sc, sh = self._bn()
@@ -250,7 +267,8 @@ class ConvUnit:
         if self.bn_name is not None and training and getattr(self.store, 'bn_training', False):
             # training-mode BatchNormalization: batch statistics need the whole activation first (two passes)
             a = ops.empty((N, H, W, self.cout), x.device)
-            ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act, out=a)
+            ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act, out=a,
+                           w_version=self.store.filter_version())
             sw = self.store.w
             _, stats = ops.bn_train_forward(a, sw[self.bn_name + '/gamma'], sw[self.bn_name + '/beta'], sw[self.bn_name + '/moving_mean'],
                                             sw[self.bn_name + '/moving_variance'], residual=residual, out=out, ws=self.ctx.ws)
@@ -261,10 +279,28 @@ class ConvUnit:
         if training and ops.get_math_mode() == 'split_f16':       # only the split-mode weight gradient scales by max|x| / max|dz|
             self.out_absmax = ops.empty((1,), x.device)          # a fresh buffer per call: a layer may run several times per step
         ops.conv2d_fwd(x, w, b, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value, act=self.act,
-                       bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a, y_absmax=self.out_absmax)
+                       bn_scale=sc, bn_shift=sh, residual=residual, out=out, act_out=a, y_absmax=self.out_absmax, w_version=self.store.filter_version())
         if training:
             self.saved = (x, a if a is not None else out, None, x_absmax)   # without BN/residual the output itself is the activation
         return out
+
+    def _flipped(self, w):
+        """(flipped / transposed filter (kh, kw, Cout, Cin), weights version): a buffer of the layer's own - a stable address, which is what lets libpcnn
+        keep ITS spectrum across calls - rewritten when the weights version moves: by ops.sync_flipped_filters for all layers at once (before the first
+        convolution under the new version), here only for a layer's first backward pass or with the cache switched off."""
+        ver = self.store.filter_version()
+        wf = getattr(self, '_wf', None)
+        if wf is None or wf.device != w.device:
+            self._wf = torch.empty((self.kh, self.kw, self.cout, self.cin), dtype=torch.float32, device=w.device)
+            self._wf_ver = None
+            ops.register_flipped(self)
+        if not ver or self._wf_ver != ver:
+            self._reflip(ver)
+        return self._wf, ver
+
+    def _reflip(self, ver):
+        ops.flip_transpose_weights(self.store.w[self.name + '/kernel'], out=self._wf)
+        self._wf_ver = ver
 
     def post_spec(self, want_raw=False):
         """This layer's activation backward (dz = dy act'(a), dbias = sum dz) as an offer to the data-gradient kernel of the layer that CONSUMES
@@ -309,13 +345,13 @@ class ConvUnit:
                 dz = dy
         w = s.w[self.name + '/kernel']
         kh, kw = self.kh, self.kw
-        wf = None
+        wf, wver = None, 0
         if need_dx:
             # wide filters: both gradients in one call on the spectral route (the spectrum of dz is shared); None = not eligible
-            wf = ops.flip_transpose_weights(w, out=self.ctx.wflip((kh, kw, self.cout, self.cin), w.device))
+            wf, wver = self._flipped(w)
             res = add_to if (self.mode == 'CONSTANT') else None
             out = ops.conv2d_bwd_fused(x, dz, w.shape, wf, pad_top=self.pads_y[0], pad_left=self.pads_x[0], pad_mode=self.mode, pad_value=self.pad_value,
-                                       dw=g[self.name + '/kernel'], residual=res, post=post)
+                                       dw=g[self.name + '/kernel'], residual=res, post=post, w_version=wver)
             if out is not None:
                 if self.mode == 'CONSTANT':
                     return out
@@ -343,10 +379,10 @@ class ConvUnit:
             self.ctx.side_reads[dz.data_ptr()] = done          # see Context.before_inplace_write
         if not need_dx:
             return None
-        # wf: the flipped filter formed above is still in the context's scratch (nothing in between writes it) - no second launch
+        # wf: the flipped filter formed above (the layer's own buffer) - no second launch
         if self.mode == 'CONSTANT':
-            return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to)
-        gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1))
+            return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to, w_version=wver)
+        gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1), w_version=wver)
         if add_to is not None and add_to.is_contiguous():
             self.ctx.before_inplace_write(add_to)
             return ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode, out=add_to, accumulate=True)

@@ -84,6 +84,113 @@ def get_math_mode():
     return [k for k, v in MATH_MODES.items() if v == _math_mode][0]
 
 
+# ---- filter spectra across calls (include/pcnn.h pcnn_set_filter_version).  The layer classes know when their weights change: every change - an optimizer
+# step, a load, a torch-side in-place write to the parameter bucket (torch counts those: Tensor._version) - bumps ONE process-wide version; a convolution
+# called with `w_version` = that number lets its handle keep the filter's spectrum until the number moves.  Calls without `w_version` (raw ops users,
+# tools, tests) run with version 0: nothing cached, any tensor contents are fine.  PCNN_FILTER_CACHE=0 turns the feature off.
+_filter_cache_on = __import__('os').environ.get('PCNN_FILTER_CACHE', '1') != '0'
+_filter_version = 1
+_filter_epoch = 0
+
+
+def weights_changed():
+    """Some layer weights may hold new values: spectra cached under the old version are refreshed on their next use."""
+    global _filter_version
+    _filter_version += 1
+
+
+def weights_released():
+    """A parameter bucket went away: every handle drops its cached spectra before its next cached call (the refresh reads every known filter)."""
+    global _filter_epoch, _filter_version
+    _filter_epoch += 1
+    _filter_version += 1
+
+
+def filter_version():
+    return _filter_version if _filter_cache_on else 0
+
+
+def set_filter_cache(on):
+    global _filter_cache_on
+    _filter_cache_on = bool(on)
+
+
+def filter_cache_stats():
+    """Sum over this process's handles: dict(entries, bytes, hits, fills, refreshes) - pcnn_filter_cache_stats."""
+    tot = dict(entries=0, bytes=0, hits=0, fills=0, refreshes=0)
+    for h in _handles.values():
+        v = [ctypes.c_longlong() for _ in range(5)]
+        h.call('pcnn_filter_cache_stats', *[byref(x) for x in v])
+        for k, x in zip(tot, v):
+            tot[k] += x.value
+    return tot
+
+
+_flip_layers = __import__('weakref').WeakSet()   # layers.Conv objects that keep a flipped filter of their own (they have run a backward pass)
+_flips_version = 0
+
+
+def register_flipped(layer):
+    _flip_layers.add(layer)
+
+
+_flip_table = (None, None, 0, 0)                 # (key, device table, n, total) of pcnn_conv2d_flip_transpose_table
+
+
+def sync_flipped_filters(version):
+    """The promise behind a weights version covers EVERY filter pointer a handle has seen, the flipped filters of the backward pass included: the
+    first cached call under a new version makes its handle refresh all of them at once.  So before that call every layer's flipped filter is
+    re-formed from the current weights - here, in ONE launch (pcnn_conv2d_flip_transpose_table; the table of pointers lives on the device and is
+    rebuilt only when a layer joins), on the calling stream (the model's main stream: the first convolution of a step runs before any branch
+    stream forks off)."""
+    global _flips_version, _flip_table
+    if not version or version == _flips_version:
+        return
+    layers = sorted((l for l in _flip_layers if getattr(l, '_wf', None) is not None), key=id)
+    if layers:
+        key = tuple((id(l), l._wf.data_ptr()) for l in layers)
+        if key != _flip_table[0] and torch.cuda.is_current_stream_capturing():
+            for l in layers:                                           # the set of layers changed and nothing may be uploaded inside a capture:
+                l._reflip(version)                                     # one launch per layer, as before the table existed
+            _flips_version = version
+            return
+        if key != _flip_table[0]:
+            arr = np.zeros(len(layers), dtype=[('w', '<u8'), ('wt', '<u8'), ('kh', '<i4'), ('kw', '<i4'), ('ci', '<i4'), ('co', '<i4'), ('start', '<i8')])
+            start = 0
+            for i, l in enumerate(layers):
+                w = l.store.w[l.name + '/kernel']
+                arr[i] = (w.data_ptr(), l._wf.data_ptr(), l.kh, l.kw, l.cin, l.cout, start)
+                start += w.numel()
+            _flip_table = (key, torch.from_numpy(arr.view(np.uint8)).to(layers[0]._wf.device), len(layers), start)
+        _, tab, n, total = _flip_table
+        handle().call('pcnn_conv2d_flip_transpose_table', _p(tab), c_int(n), c_int64(total))
+        for l in layers:
+            l._wf_ver = version
+    _flips_version = version
+
+
+class _FilterVersion:
+    """`with _FilterVersion(h, v):` - the handle runs the enclosed call under weights version v and returns to 0 (uncached) afterwards, so a later call
+    that says nothing about its filter's contents can never meet a cached spectrum."""
+    __slots__ = ('h', 'v')
+
+    def __init__(self, h, v):
+        self.h, self.v = h, int(v or 0)
+
+    def __enter__(self):
+        if self.v:
+            h = self.h
+            if getattr(h, '_fepoch', 0) != _filter_epoch:
+                h.call('pcnn_filter_cache_clear')
+                h._fepoch = _filter_epoch
+            h.call('pcnn_set_filter_version', self.v)
+
+    def __exit__(self, *exc):
+        if self.v:
+            self.h.call('pcnn_set_filter_version', 0)
+        return False
+
+
 def handle():
     """The libpcnn handle of (current device, torch's current stream): one handle per stream (include/pcnn.h), so the weight gradients on
     the side stream have their own filter scratch and spectral workspace and never share library state with the main stream."""
@@ -234,7 +341,9 @@ def conv_desc(x_shape, ldx, w_shape, out_hw, ldy, pad_top, pad_left, pad_mode='C
 
 
 def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CONSTANT', pad_value=0.0, act='linear',
-               bn_scale=None, bn_shift=None, residual=None, out=None, act_out=None, y_absmax=None):
+               bn_scale=None, bn_shift=None, residual=None, out=None, act_out=None, y_absmax=None, w_version=0):
+    """w_version: 0 (default) - nothing is known about w's contents; else the caller's weights version (filter_version()): the spectral route may
+    reuse the spectrum it computed for this very tensor under the same version."""
     N, H, W, Cin = x.shape
     kh, kw, ci, Cout = w.shape
     assert w.is_contiguous()
@@ -243,9 +352,11 @@ def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CON
         out = empty((N, Ho, Wo, Cout), x.device)
     d = conv_desc(x.shape, _ld(x), w.shape, (Ho, Wo), _ld(out), pad_top, pad_left, pad_mode, pad_value, act,
                   _ld(residual) if residual is not None else 0, _ld(act_out) if act_out is not None else 0)
-    _launch('conv_fwd', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout,
-            lambda: handle().call('pcnn_conv2d_fwd_absmax', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out),
-                                  _p(y_absmax)),
+    def run():
+        h = handle()
+        with _FilterVersion(h, w_version):
+            h.call('pcnn_conv2d_fwd_absmax', byref(d), _p(x), _p(w), _p(bias), _p(bn_scale), _p(bn_shift), _p(residual), _p(out), _p(act_out), _p(y_absmax))
+    _launch('conv_fwd', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout, run,
             4.0 * (N * H * W * Cin + N * Ho * Wo * Cout * (1 + (residual is not None) + (act_out is not None)) + kh * kw * Cin * Cout))
     return out
 
@@ -288,7 +399,7 @@ class Post:
         self.applied, self.raw = False, None
 
 
-def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, dw, residual=None, post=None):
+def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTANT', pad_value=0.0, dw, residual=None, post=None, w_version=0):
     """Both gradients of the fused pad+conv in one call when the layer takes the spectral route (pcnn_conv2d_bwd_spectral: dz's spectrum is
     computed once for the data gradient and the weight gradient).  wf: the flipped / transposed filter (kh,kw,Cout,Cin).  Fills dw and returns
     the data-gradient convolution's output - dx for CONSTANT padding (+ `residual` if given), the gradient on the padded domain otherwise
@@ -314,12 +425,16 @@ def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTAN
         post.raw = empty((N, H, W, Cin), x.device) if post.want_raw else None
         pd = PostDesc(post.a.data_ptr(), _ld(post.a), ACTS[post.act], LEAKY_ALPHA, post.dbias.data_ptr() if post.dbias is not None else None,
                       post.raw.data_ptr() if post.raw is not None else None, Cin)
-        _launch('conv_bwd_fused', 2.0 * flops,
-                lambda: h.call('pcnn_conv2d_bwd_spectral_post', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw), byref(pd)), nbytes)
+        def run_post():
+            with _FilterVersion(h, w_version):
+                h.call('pcnn_conv2d_bwd_spectral_post', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw), byref(pd))
+        _launch('conv_bwd_fused', 2.0 * flops, run_post, nbytes)
         post.applied = True
         return out
-    _launch('conv_bwd_fused', 2.0 * flops,
-            lambda: h.call('pcnn_conv2d_bwd_spectral', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw)), nbytes)
+    def run():
+        with _FilterVersion(h, w_version):
+            h.call('pcnn_conv2d_bwd_spectral', byref(d), byref(dg), _p(x), _p(dz), _p(wf), _p(residual), _p(out), _p(dw))
+    _launch('conv_bwd_fused', 2.0 * flops, run, nbytes)
     return out
 
 
@@ -753,15 +868,18 @@ def pi_loss_bwd(pred, rhs, kern, coef, dpred):
 
 
 def adam_step(w, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, vhat=None):
+    weights_changed()                                                 # a raw-pointer write torch does not count: cached filter spectra go stale
     handle().call('pcnn_adam_amsgrad_step', c_int64(w.numel()), _p(w), _p(g), _p(m), _p(v), _p(vhat), c_float(lr), c_float(beta1), c_float(beta2),
                   c_float(eps), c_int(step), c_float(grad_scale))
 
 
 def sgd_step(w, g, lr, grad_scale=1.0):
+    weights_changed()                                                 # a raw-pointer write torch does not count: cached filter spectra go stale
     handle().call('pcnn_sgd_step', c_int64(w.numel()), _p(w), _p(g), c_float(lr), c_float(grad_scale))
 
 
 def sgd_momentum_step(w, g, v, lr, momentum, nesterov, grad_scale=1.0):
+    weights_changed()                                                 # a raw-pointer write torch does not count: cached filter spectra go stale
     handle().call('pcnn_sgd_momentum_step', c_int64(w.numel()), _p(w), _p(g), _p(v), c_float(lr), c_float(momentum), c_int(1 if nesterov else 0), c_float(grad_scale))
 
 

@@ -107,6 +107,8 @@ class DataParallel:
         for store in (model.stores if hasattr(model, 'stores') else [model.store]):
             self.broadcast(store.flat_w)
             self.broadcast(store.flat_stats)
+        from . import ops
+        ops.weights_changed()                                           # rank 0's weights have replaced this rank's: cached filter spectra are stale
         stores = list(model.stores if hasattr(model, 'stores') else [model.store])
 
         def grad_sync(flat_g):

@@ -275,6 +275,13 @@ def test_dense_spp_scales_ring_jacobi():
     xt = torch.tensor(xs, requires_grad=True); ft = torch_twin.spatial_pyramid_pool(xt, levels, 'max'); df = f32(rng.standard_normal(ft.shape))
     (ft * torch.tensor(df)).sum().backward()
     assert rel(nchw(ops.spp_max_bwd(arg, dev(df), (3, 11, 13, 4))), xt.grad.numpy()) < TOL
+    # a sample that has gone NaN (a diverged training run) must not turn into a write outside the tensor: the maximum of an all-NaN bin is NaN
+    # (tf.reduce_max) and its argmax stays an index inside the sample
+    xn = nhwc(xs).clone(); xn[1] = float('nan')
+    outn, argn = ops.spp_max_fwd(xn, bins_d)
+    assert torch.isnan(outn[1]).all() and torch.equal(outn[0], out[0]) and torch.equal(outn[2], out[2])
+    assert int(argn.min()) >= 0 and int(argn.max()) < 11 * 13 * 4
+    assert torch.isfinite(ops.spp_max_bwd(argn, dev(df), (3, 11, 13, 4))).all()
     # channel scale / sample scale
     xc = f32(rng.standard_normal((3, 9, 10, 32))); s = f32(rng.standard_normal((3, 32))); dyc = f32(rng.standard_normal(xc.shape))
     assert rel(ops.channel_scale_fwd(dev(xc), dev(s)).cpu().numpy(), xc * s[:, None, None, :]) < TOL
