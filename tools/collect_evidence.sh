@@ -20,6 +20,9 @@ if [ "$STAGE" = 1 ]; then
   cp "$ROOT"/gpurun_out/${R}_c?_pmc_summary_*.json "$ROOT"/gpurun_out/${R}_c?_kernel_stats_*.csv "$OUT/"
 else
   python bench.py > "$OUT/${R}_bench_c4.json" 2> "$OUT/bench_c4.err"; echo "bench c4 rc=$?"; cp bench_detail.json "$OUT/${R}_bench_c4_detail.json"
+  python tools/bench_inference.py 2>&1 | grep -v amdgpu > "$OUT/${R}_inference_throughput.txt"
+  python tools/probe_xform.py 8 2>&1 | grep -v amdgpu > "$OUT/${R}_probe_xform.txt"
+  python tools/probe_narrow_mfma.py 2>&1 | grep -v amdgpu > "$OUT/${R}_probe_narrow_mfma.txt"
   python tools/probe_layers.py 2>&1 | grep -v amdgpu > "$OUT/${R}_probe_layers.txt"
   python tools/bench_dataset.py 2>&1 | grep -v amdgpu > "$OUT/${R}_dataset_throughput.txt"
   python tools/bench_pcnn.py 2>&1 | grep -v amdgpu > "$OUT/${R}_next_models_throughput.txt"
