@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-traffic counters of one training step, per workload and math mode (run on the GPU box from the repo root through gpurun):
 #   gpurun -- 'bash tools/collect_pmc.sh [round [workloads [modes]]]'      e.g.  bash tools/collect_pmc.sh r03 "c4 c3" "fp32"
-# Three separate --pmc passes each (FETCH_SIZE and WRITE_SIZE do not fit one pass; the third counts matrix-pipe busy cycles and active cycles;
+# Three separate --pmc passes each, of one warm-up step (it fills the filter-spectrum cache; tools/pmc_summary.py drops its rows) + one counted step (FETCH_SIZE and WRITE_SIZE do not fit one pass; the third counts matrix-pipe busy cycles and active cycles;
 # never combined with --stats / sys-trace), the program directly after `--`; plus one `--kernel-trace --stats` run of 1 + 3 steps for the
 # per-kernel time of the roofline table.  Output: gpurun_out/pmc_<round>_<workload>_<mode>_*/ and gpurun_out/<round>_<workload>_pmc_summary_<mode>.json
 # (+ <round>_<workload>_kernel_stats_<mode>.csv): copy them to profiles/.
@@ -23,7 +23,7 @@ for mode in $MODES; do
     out=$ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_${ctr}
     rm -rf "$out"
     pmc=$ctr; if [ $ctr = MFMA ]; then pmc="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; fi
-    (cd /tmp && rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out" -- python3 "$ROOT/bench.py" --workload $wl --math $mode --steps 1 --warmup 0 \
+    (cd /tmp && rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out" -- python3 "$ROOT/bench.py" --workload $wl --math $mode --steps 1 --warmup 1 \
         --no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0 > "$ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_${ctr}.log" 2>&1)
     echo "pass $wl $mode $ctr done"
   done

@@ -22,15 +22,21 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KERNELS = (r'(conv_fwd_split_kernel<\d, \d>|conv_fwd_kernel<\d>|wgrad_split_kernel|wgrad_kernel|spec_fwd_kernel<\w+, \w+>|spec_inv_kernel|spec_mix_kernel<\d>|spec_mix_lds_kernel<\d>|spec_wmix_kernel|spec_mixw_kernel|'
-           r'spec64_fwd4?_kernel<\w+>|spec64_inv_kernel|fft32_fwd_kernel<\w+>|fft32_inv_kernel|fft64_fwd_kernel<\w+>|fft64_inv_kernel|'
+           r'spec64_fwd4?_kernel<\w+>|spec64_inv_kernel|fft32_fwd_kernel<\w+>|fft32_inv_kernel|fft64_fwd_kernel<\w+(?:, \w+)*>|fft64_inv_kernel|fft32_fwd_multi_kernel|fft64_fwd_multi_kernel|'
            r'conv_small_fwd_kernel|conv_small_wgrad_kernel|resnet3_stage_kernel|split_convert_kernel|split_absmax_kernel|epilogue_bwd\w*|deconv_fwd_mfma_kernel|resize_fwd_kernel)')
 CONV = ('conv_fwd', 'wgrad', 'spec', 'fft', 'conv_small', 'resnet3_stage')      # what bench.py's `roofline` covers: every convolution launch
 
 
 def per_kernel(path, counter, scale=1024.0):
+    """The counter passes run ONE warm-up step in front of the counted one (tools/collect_pmc.sh: --steps 1 --warmup 1): the first step of a process
+    fills the filter-spectrum cache with one launch per filter, which no later step repeats.  Rows up to the first optimizer launch (adam_kernel, the
+    last kernel of a step) are the warm-up and are dropped; a file without two optimizer launches is taken whole."""
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] != counter:
+    rows = sorted((r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter), key=lambda r: int(r['Dispatch_Id']))
+    marks = [int(r['Dispatch_Id']) for r in rows if 'adam_kernel' in r['Kernel_Name']]
+    first = marks[0] if len(marks) >= 2 else -1
+    for r in rows:
+        if int(r['Dispatch_Id']) <= first:
             continue
         m = re.search(KERNELS, r['Kernel_Name'])
         if m:
