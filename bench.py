@@ -577,6 +577,10 @@ def run(args):
             out['dataset'] = dataset_block()
         except Exception as e:   # the headline must not die on the side measurement
             out['dataset'] = {'error': repr(e)}
+    try:                                       # detail file only: what the kept filter spectra cost (pcnn_set_filter_version)
+        out['filter_cache'] = dict(ops.filter_cache_stats(), enabled=bool(ops.filter_version()))
+    except Exception as e:
+        out['filter_cache'] = {'error': repr(e)}
     emit(out, args.detail)
 
 

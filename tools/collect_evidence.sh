@@ -20,6 +20,8 @@ if [ "$STAGE" = 1 ]; then
   cp "$ROOT"/gpurun_out/${R}_c?_pmc_summary_*.json "$ROOT"/gpurun_out/${R}_c?_kernel_stats_*.csv "$OUT/"
 else
   python bench.py > "$OUT/${R}_bench_c4.json" 2> "$OUT/bench_c4.err"; echo "bench c4 rc=$?"; cp bench_detail.json "$OUT/${R}_bench_c4_detail.json"
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/${R}_smoke.log" 2>&1; echo "smoke rc=$?"
+  python bench.py --no-c3 --no-cpu-baseline --no-dataset --detail "$OUT/${R}_bench_c4_only_detail.json" > "$OUT/${R}_bench_c4_only.json" 2>/dev/null   # filter_cache block: the c4 model alone
   python tools/bench_inference.py 2>&1 | grep -v amdgpu > "$OUT/${R}_inference_throughput.txt"
   python tools/probe_xform.py 8 2>&1 | grep -v amdgpu > "$OUT/${R}_probe_xform.txt"
   python tools/probe_narrow_mfma.py 2>&1 | grep -v amdgpu > "$OUT/${R}_probe_narrow_mfma.txt"

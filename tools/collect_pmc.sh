@@ -18,6 +18,7 @@ for mode in $MODES; do
   (cd /tmp && rocprofv3 --kernel-trace --stats -d "$st" --output-format csv -- python3 "$ROOT/bench.py" --workload $wl --math $mode --steps 3 --warmup 1 \
       --no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0 > "$ROOT/gpurun_out/stats_${ROUND}_${wl}_${mode}.log" 2>&1)
   cp "$st"/*/*_kernel_stats.csv "$ROOT/gpurun_out/${ROUND}_${wl}_kernel_stats_${mode}.csv"
+  cp "$st"/*/*_kernel_trace.csv "$ROOT/gpurun_out/${ROUND}_${wl}_kernel_trace_${mode}.csv"
   echo "stats $wl $mode done"
   for ctr in FETCH_SIZE WRITE_SIZE MFMA; do
     out=$ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_${ctr}
@@ -30,6 +31,6 @@ for mode in $MODES; do
   f=$(ls $ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_FETCH_SIZE/*/*counter_collection.csv | head -1)
   w=$(ls $ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_WRITE_SIZE/*/*counter_collection.csv | head -1)
   m=$(ls $ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_MFMA/*/*counter_collection.csv | head -1)
-  python3 tools/pmc_summary.py "$f" "$w" "$ROOT/gpurun_out/${ROUND}_${wl}_pmc_summary_${mode}.json" $mode "$m" "$ROOT/gpurun_out/${ROUND}_${wl}_kernel_stats_${mode}.csv" 4 | tail -30
+  python3 tools/pmc_summary.py "$f" "$w" "$ROOT/gpurun_out/${ROUND}_${wl}_pmc_summary_${mode}.json" $mode "$m" "$ROOT/gpurun_out/${ROUND}_${wl}_kernel_trace_${mode}.csv" 4 | tail -30
 done
 done

@@ -6,7 +6,8 @@ the stamp matches the tree it runs from.
 A third pass (SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE, optional) adds the matrix-pipe busy fraction per kernel: BUSY sums the busy cycles
 of the 1024 SIMDs, GUI_ACTIVE the active cycles of the 8 XCDs, so busy fraction = BUSY / (128 * GUI_ACTIVE).
 
-A kernel-stats CSV of `rocprofv3 --kernel-trace --stats` over the same command with S steps (optional, with S) adds each kernel's time per step,
+A kernel-stats CSV of `rocprofv3 --kernel-trace --stats` over the same command with S steps - or, better, that run's kernel TRACE csv, whose first
+step is then dropped like the counter passes' warm-up step - (optional, with S) adds each kernel's time per step,
 so that the summary carries the per-kernel roofline table bench.py prints: launches and ms per step, bytes per launch, achieved TB/s against
 the 8 TB/s HBM peak, matrix-pipe busy fraction.
 
@@ -61,7 +62,16 @@ def main():
             kernels[k]['mfma_busy_frac'] = sum(busy[k]) / (128.0 * sum(active[k]))
     if len(sys.argv) > 7:            # per-kernel time from the --stats run: average duration per launch, launches per step
         steps = float(sys.argv[7])
-        for r in csv.DictReader(open(sys.argv[6])):
+        rows = list(csv.DictReader(open(sys.argv[6])))
+        if rows and 'Start_Timestamp' in rows[0]:
+            # the run's kernel TRACE (one row per launch): the first step of the process - up to its optimizer launch - is dropped like the warm-up step of
+            # the counter passes (it fills the filter-spectrum cache with one small launch per filter, which would dilute the per-launch averages)
+            rows.sort(key=lambda r: int(r['Dispatch_Id']))
+            marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+            if len(marks) >= 2:
+                rows, steps = rows[marks[0] + 1:], float(len(marks) - 1)
+            rows = [{'Name': r['Kernel_Name'], 'Calls': 1, 'TotalDurationNs': int(r['End_Timestamp']) - int(r['Start_Timestamp'])} for r in rows]
+        for r in rows:
             m = re.search(KERNELS, r['Name'])
             if m and m.group(1) in kernels:
                 kv = kernels[m.group(1)]
