@@ -492,8 +492,8 @@ def run(args):
         rf, rb, rs, rc = prof.select(lambda k, f, b: k == 'resize_fwd')
         direct_tflops = af / as_ / 1e12 if as_ else None
         return {'bound': 'hbm',
-                'kernel': 'all convolution launches of the timed steps (forward, data gradient, weight gradient): tiled spectral route (spec_fwd / spec64_fwd, '
-                          'spec_mix, spec_inv / spec64_inv, spec_wmix: the DFT as fp32 MFMA GEMM, 64-point tiles for 11..15 taps) for the wide filters, '
+                'kernel': 'all convolution launches of the timed steps (forward, data gradient, weight gradient): tiled spectral route (fft32 / fft64_fwd, '
+                          'spec_mix / spec_mixw on the matrix cores, fft32 / fft64_inv with the fused epilogues: in-register FFTs, 64-point tiles for 13..15 taps) for the wide filters, '
                           'fp32-MFMA implicit GEMM, vector-ALU forward and 16x16x4-MFMA weight-gradient kernels for the 3x3 layers of <= 16 channels',
                 'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS if achieved else None,
                 'achieved_source': 'ALGORITHMIC bytes (every layer\'s input + output + filter, forward + data gradient + weight gradient: SURVEY 8d) / the summed HIP-event time of all convolution launches in this run',
