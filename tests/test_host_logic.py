@@ -236,3 +236,37 @@ def test_rccl_load_failure_is_an_error_return_not_a_crash():
     rc, rc2, msg = r.stdout.strip().split(' ', 2)
     assert rc == '1' and rc2 == '1'
     assert 'librccl_missing.so' in msg and len(msg) > 30
+
+
+def test_weights_version_bookkeeping_of_the_filter_cache():
+    """Host side of pcnn_set_filter_version (no GPU): the layer classes' weights version moves on every torch-side write to a parameter bucket
+    (Tensor._version), on the library's own raw-pointer writers (they call ops.weights_changed) and when a bucket dies; with the cache switched off the
+    version handed to the library is 0, i.e. nothing is ever kept."""
+    import gc
+    import torch
+    from poisson_cnn_amd import layers, ops
+    store = layers.ParamStore()
+    store.add('a/kernel', (3, 3, 2, 4), 'glorot')
+    store.add('a/bias', (4,), 'zeros')
+    store.finalize(torch.device('cpu'))
+    store.initialize(seed=1)
+    v0 = store.filter_version()
+    assert v0 == ops.filter_version() and v0 > 0
+    assert store.filter_version() == v0                                   # nothing written: the version stands
+    store.w['a/kernel'].mul_(2.0)                                         # a view of the bucket, written through torch
+    v1 = store.filter_version()
+    assert v1 > v0 and store.filter_version() == v1
+    store.flat_w.add_(1.0)
+    assert store.filter_version() > v1
+    v2 = ops.filter_version()
+    ops.weights_changed()                                                 # what train.Adam / SGD and parallel.attach call after their raw-pointer writes
+    assert ops.filter_version() == v2 + 1 and store.filter_version() == v2 + 1
+    ops.set_filter_cache(False)
+    try:
+        assert ops.filter_version() == 0 and store.filter_version() == 0
+    finally:
+        ops.set_filter_cache(True)
+    epoch, v3 = ops._filter_epoch, ops.filter_version()
+    del store
+    gc.collect()
+    assert ops._filter_epoch == epoch + 1 and ops.filter_version() > v3    # a dying bucket: every handle empties its cache before its next cached call
