@@ -181,6 +181,9 @@ class _FilterVersion:
         if self.v:
             h = self.h
             if getattr(h, '_fepoch', 0) != _filter_epoch:
+                if torch.cuda.is_current_stream_capturing():         # clearing synchronises and frees: not inside a capture - this call runs uncached,
+                    self.v = 0                                       # the cache is emptied by the first call after the capture
+                    return
                 h.call('pcnn_filter_cache_clear')
                 h._fepoch = _filter_epoch
             h.call('pcnn_set_filter_version', self.v)
