@@ -173,3 +173,39 @@ def test_all_flipped_filters_in_one_launch_equal_the_per_filter_kernel():
         w = l.store.w[l.name + '/kernel']
         assert torch.equal(l._wf, ops.flip_transpose_weights(w)), l.name
         assert torch.equal(l._wf, w.flip(0, 1).permute(0, 1, 3, 2).contiguous()), l.name
+
+
+def test_torch_optim_through_the_tape_with_and_without_the_cache():
+    """autograd.Differentiable + torch.optim: the optimizer writes the kernels' parameter bucket in place through torch (Tensor._version moves), so the
+    kept spectra are refreshed before the next forward - three SGD steps give the same bits with the cache on and off."""
+    from poisson_cnn_amd import keras_layers as K, ops
+    from poisson_cnn_amd.autograd import Differentiable
+    ops.set_spectral_mode('force')
+
+    def run(cache):
+        ops.set_filter_cache(cache)
+        torch.manual_seed(0)
+        conv = Differentiable(K.apply_advanced_padding_and_call_conv_layer('SYMMETRIC', K.Conv2D(16, 7, activation='tanh')))
+        res = Differentiable(K.resnet(2, filters=16, kernel_size=5, activation='tanh', padding_mode='symmetric'))
+        g = torch.Generator(device='cuda').manual_seed(5)
+        x = torch.randn(2, 3, 96, 80, device='cuda', generator=g)
+        tgt = torch.randn(2, 16, 96, 80, device='cuda', generator=g)
+        with torch.no_grad():
+            res(conv(x))                                                  # lazy build: the parameter buckets exist after the first call
+        opt = torch.optim.SGD(list(conv.parameters()) + list(res.parameters()), lr=1e-3)
+        outs = []
+        for _ in range(3):
+            opt.zero_grad()
+            y = res(conv(x))
+            loss = (y - tgt).square().mean()
+            loss.backward()
+            opt.step()
+            outs.append((float(loss.detach()), y.detach().clone()))
+        return outs, conv.weight.detach().clone(), res.weight.detach().clone()
+
+    a, wa, ra = run(True)
+    b, wb, rb = run(False)
+    assert a[0][0] != a[2][0]                                             # the weights did move
+    for (la, ya), (lb, yb) in zip(a, b):
+        assert la == lb and torch.equal(ya, yb)
+    assert torch.equal(wa, wb) and torch.equal(ra, rb)
