@@ -590,8 +590,8 @@ __device__ __forceinline__ void y64_gather(const float* U, int offr, int offi, i
   }
 }
 
-// 8 waves of up to 256 registers, two units per wave and phase (unit u of wave w: window rows 4 (2w + u) + lane group, column 2w + u): the
-// whole next item (two rows of 64 values per lane) is requested while the second y phase runs.  (A 16-wave build of the same phases - 128
+// 8 waves of up to 256 registers, two units per wave and phase (unit u of wave w: window rows 4 (2w + u) + lane group, column 2w + u); an item's two
+// rows of 64 values per lane are requested at the top of the item (no prefetch: see PCNN_PF64_NONE below).  (A 16-wave build of the same phases - 128
 // registers - cannot hold a row of 64 beside the y-axis state: it spilled 50-110 registers in every arrangement tried.)
 #ifndef PCNN_PF64_ONE
 #define PCNN_PF64_ONE 0
@@ -599,6 +599,12 @@ __device__ __forceinline__ void y64_gather(const float* U, int offr, int offi, i
 #ifndef PCNN_PF64_FULL
 #define PCNN_PF64_FULL 0
 #endif
+#ifndef PCNN_PF64_NONE
+#define PCNN_PF64_NONE 1
+#endif
+constexpr bool PF64_NONE = PCNN_PF64_NONE; // 8-wave form WITHOUT any prefetch (both rows requested at the top of the item): the shipped form since the end of round 5 -
+                                           // unit 0's row held across the even y phase (PCNN_PF64_NONE=0) costs 29 spilled registers, and the spill-free kernel is 2.4 %
+                                           // faster per 15-tap forward although its loads are exposed (profiles/r05_probe_fwd64_no_prefetch.txt)
 constexpr bool PF64_FULL = PCNN_PF64_FULL; // 8-wave form: request BOTH rows of the next item under the even y phase (128 registers in flight: spills ~60)
 constexpr bool PF64_ONE = PCNN_PF64_ONE;   // 16-wave form: request the next item's row under the even y phase (64 registers in flight)
 template <bool MASKED, int NU>
@@ -617,12 +623,13 @@ __device__ __forceinline__ void fft64_fwd_body(const FwdParams& p, const int nvi
   // the padded tail of the virtual item list (tg >= ntg) runs as a copy of a real item that stores nothing: the workgroup keeps its barriers
   auto safe = [&](int vv) { int tg, hf; item64(vv, tg, hf); return tg < ntg ? vv : (vv & 8); };
   fwd64_describe_t<NU>(p, safe(v), lane, c16, cur, row, NU * wave);
-  if (NU == 2 || PF64_ONE) fwd64_request<0>(cur, row, R);
+  if ((NU == 2 && !PF64_NONE) || PF64_ONE) fwd64_request<0>(cur, row, R);
   if (NU == 2 && PF64_FULL) fwd64_request<1>(cur, row, R);
   for (;;) {
     const int next = v + gdim;
     const bool more = next < nvirt;
     // (unit 0's row was requested a phase ahead - below; unit 1's here: the registers cannot hold both beside the y-axis state)
+    if (NU == 2 && PF64_NONE) fwd64_request<0>(cur, row, R);
     if (NU == 2 && !PF64_FULL) fwd64_request<1>(cur, row, R);
     else if (NU == 1 && !PF64_ONE) fwd64_request<0>(cur, row, R);
     // ---- x axis: the whole real FFT of this lane's two rows.  The ODD bins go through LDS first (16 complex columns, every unit the same path)
@@ -684,7 +691,7 @@ __device__ __forceinline__ void fft64_fwd_body(const FwdParams& p, const int nvi
     // state spill 66 registers; during the odd phase the even bins still occupy 64)
     if (more) {
       fwd64_describe_t<NU>(p, safe(next), lane, c16, cur, row, NU * wave);
-      if (NU == 2 || PF64_ONE) fwd64_request<0>(cur, row, R);
+      if ((NU == 2 && !PF64_NONE) || PF64_ONE) fwd64_request<0>(cur, row, R);
       if (NU == 2 && PF64_FULL) fwd64_request<1>(cur, row, R);
     }
     lds_barrier();
