@@ -233,6 +233,16 @@ int pcnn_conv2d_epilogue_bwd_absmax(pcnn_handle h, int64_t npix, int C, const fl
  * that read (y,x).  accumulate != 0 adds into gx. */
 int pcnn_pad_fold_bwd(pcnn_handle h, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int pad_mode,
                       const float* gp, int ldgp, float* gx, int ldgx, int accumulate);
+/* The same fold AND the activation backward of the layer that produced the convolution's input, in one pass (round 5; the counterpart of
+ * pcnn_conv2d_bwd_spectral_post for SYMMETRIC / REFLECT-padded layers, whose data gradient arrives on the padded domain): g = fold(gp) [+ add_to],
+ * post->raw_out = g (optional), dz = g * bn_scale * act'(post->act_out), post->dbias[c] = sum dz, dsum_dy_a[c] = sum g * act_out, dsum_dy[c] = sum g
+ * (each optional; bn_scale NULL = 1: the arguments of pcnn_conv2d_epilogue_bwd, whose arithmetic this is operation for operation; fixed summation
+ * order).  dx itself never reaches memory.  Eligibility (channels and every channel stride a multiple of 4, 16-byte aligned tensors, C <= 256) must be asked first; workspace:
+ * pcnn_colsum_workspace(C) bytes. */
+int pcnn_pad_fold_bwd_post_eligible(int C, int ldgp, int ld_add, const void* gp, const void* add_to, const pcnn_post_desc* post, int lddz, const void* dz);
+int pcnn_pad_fold_bwd_post(pcnn_handle h, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int pad_mode, const float* gp, int ldgp,
+                           const float* add_to, int ld_add, const pcnn_post_desc* post, const float* bn_scale, float* dsum_dy_a, float* dsum_dy,
+                           float* dz, int lddz, void* workspace, size_t workspace_bytes);
 
 /* Inference-mode BatchNormalization(axis=1, epsilon) folded to a per-channel affine (blocks/resnet.py:26-27,
  * models/Homogeneous_Poisson_NN_Legacy.py:55):  scale = gamma / sqrt(var + eps), shift = beta - mean * scale, for n channels

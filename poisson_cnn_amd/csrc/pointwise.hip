@@ -181,6 +181,73 @@ __global__ void pad_fold_vec4_kernel(int N, int H, int W, int C, int pt, int pb,
   }
 }
 
+// tf.pad adjoint + the PRODUCER's activation backward in one pass (pcnn_pad_fold_bwd_post; round 5): the gradient of a SYMMETRIC / REFLECT-padded
+// convolution arrives on the padded domain; folding it back and multiplying by act'(a) of the layer that produced the convolution's input used to be two
+// passes (pad_fold: read gp, write dx; epilogue_bwd: read dx and a, write dz).  Here: g = fold(gp) [+ add_to], raw_out = g (optional: a skip connection
+// branches off), dz = g act'(a), bias-gradient partial sums per block (colsum_final_kernel combines them in a fixed order) - dx never reaches memory.
+// float4 form only (the caller checks: C, the channel strides and the base pointers multiples of 4 floats); thread layout of epilogue_bwd_vec4_kernel.
+__global__ __launch_bounds__(CS_BLOCK) void pad_fold_post_vec4_kernel(int N, int H, int W, int C, int pt, int pb, int pl, int pr, int mode,
+                                                                      const float* __restrict__ gp, int ldgp, const float* __restrict__ add_to, int ldadd,
+                                                                      const float* __restrict__ a, int lda, const float* __restrict__ bn_scale, int act, float alpha,
+                                                                      float* __restrict__ raw, int ldraw, float* __restrict__ dz, int lddz,
+                                                                      float* __restrict__ partial /*[gridDim][3][C]*/) {
+  __shared__ float red[3][CS_BLOCK * 4];
+  const int Hp = H + pt + pb, Wp = W + pl + pr;
+  const int64_t npix = (int64_t)N * H * W;
+  const int GQ = C >> 2, R = CS_BLOCK / GQ;
+  const int tid = threadIdx.x, r = tid / GQ, q = tid - r * GQ, c = q << 2;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r < R) {
+    float sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = bn_scale ? bn_scale[c + j] : 1.f;
+    for (int64_t pix = (int64_t)blockIdx.x * R + r; pix < npix; pix += (int64_t)gridDim.x * R) {
+      int64_t t = pix; const int x = t % W; t /= W; const int y = t % H; const int n = t / H;
+      int ys[3], xs[3], ny = 0, nx = 0;
+      ys[ny++] = y + pt;
+      xs[nx++] = x + pl;
+      if (mode == PCNN_PAD_SYMMETRIC) {
+        if (y < pt) ys[ny++] = pt - 1 - y;
+        if (H - 1 - y < pb) ys[ny++] = pt + H + (H - 1 - y);
+        if (x < pl) xs[nx++] = pl - 1 - x;
+        if (W - 1 - x < pr) xs[nx++] = pl + W + (W - 1 - x);
+      } else if (mode == PCNN_PAD_REFLECT) {
+        if (y >= 1 && y <= pt) ys[ny++] = pt - y;
+        if (H - 2 - y >= 0 && H - 2 - y < pb) ys[ny++] = pt + H + (H - 2 - y);
+        if (x >= 1 && x <= pl) xs[nx++] = pl - x;
+        if (W - 2 - x >= 0 && W - 2 - x < pr) xs[nx++] = pl + W + (W - 2 - x);
+      }
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int ia = 0; ia < ny; ++ia)                                 // the summation order of pad_fold_vec4_kernel: the folded values are the same bits
+        for (int ib = 0; ib < nx; ++ib) {
+          const float4 v = *reinterpret_cast<const float4*>(gp + (((int64_t)n * Hp + ys[ia]) * Wp + xs[ib]) * ldgp + c);
+          g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+        }
+      if (add_to) { const float4 o = *reinterpret_cast<const float4*>(add_to + pix * ldadd + c); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+      if (raw) *reinterpret_cast<float4*>(raw + pix * ldraw + c) = g;
+      const float4 a4 = *reinterpret_cast<const float4*>(a + pix * lda + c);
+      const float gv[4] = {g.x, g.y, g.z, g.w}, av[4] = {a4.x, a4.y, a4.z, a4.w};
+      float z[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                                   // the arithmetic of epilogue_bwd_vec4_kernel, operation for operation
+        z[j] = gv[j] * sc[j] * pcnn_act_grad_from_out(av[j], act, alpha);
+        s0[j] += z[j]; s1[j] += gv[j] * av[j]; s2[j] += gv[j];
+      }
+      *reinterpret_cast<float4*>(dz + pix * lddz + c) = make_float4(z[0], z[1], z[2], z[3]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][tid * 4 + j] = s0[j]; red[1][tid * 4 + j] = s1[j]; red[2][tid * 4 + j] = s2[j]; }
+  __syncthreads();
+  if (tid < C) {                       // channel tid: entries (r * GQ + tid / 4) * 4 + tid % 4 = r * C + tid
+    for (int k = 0; k < 3; ++k) {
+      float s = 0.f;
+      for (int rr = 0; rr < R; ++rr) s += red[k][rr * C + tid];
+      partial[((int64_t)blockIdx.x * 3 + k) * C + tid] = s;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- simple elementwise kernels
 __global__ void axpby_kernel(int64_t npix, int C, float alpha, const float* __restrict__ x, int ldx, float beta, float* __restrict__ y, int ldy) {
   const int64_t total = npix * C;
@@ -464,6 +531,37 @@ extern "C" int pcnn_pad_fold_bwd(pcnn_handle h, int N, int H, int W, int C, int 
     hipLaunchKernelGGL(pad_fold_kernel, grid1d((int64_t)N * H * W * C), dim3(256), 0, h->stream, N, H, W, C, pt, pb, pl, pr, pad_mode, gp, ldgp,
                        gx, ldgx, accumulate);
   PCNN_CHECK_LAUNCH(h, "pcnn_pad_fold_bwd");
+  return 0;
+}
+
+extern "C" int pcnn_pad_fold_bwd_post_eligible(int C, int ldgp, int ld_add, const void* gp, const void* add_to, const pcnn_post_desc* post, int lddz, const void* dz) {
+  if (!post || !post->act_out || !gp || !dz) return 0;
+  if (C < 4 || C > CS_BLOCK || (C & 3) || (ldgp & 3) || (lddz & 3) || (post->ld_act_out & 3)) return 0;
+  if (add_to && (ld_add & 3)) return 0;
+  if (post->raw_out && (post->ld_raw & 3)) return 0;
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(gp) | reinterpret_cast<uintptr_t>(add_to) | reinterpret_cast<uintptr_t>(dz) |
+                         reinterpret_cast<uintptr_t>(post->act_out) | reinterpret_cast<uintptr_t>(post->raw_out);
+  return (bits & 15) == 0 ? 1 : 0;
+}
+
+extern "C" int pcnn_pad_fold_bwd_post(pcnn_handle h, int N, int H, int W, int C, int pt, int pb, int pl, int pr, int pad_mode, const float* gp, int ldgp,
+                                      const float* add_to, int ld_add, const pcnn_post_desc* post, const float* bn_scale, float* dsum_dy_a, float* dsum_dy,
+                                      float* dz, int lddz, void* workspace, size_t workspace_bytes) {
+  PCNN_REQUIRE(h, h && gp && post && dz && workspace, "pcnn_pad_fold_bwd_post: null argument");
+  PCNN_REQUIRE(h, pad_mode >= 0 && pad_mode <= 2 && pt >= 0 && pb >= 0 && pl >= 0 && pr >= 0, "pcnn_pad_fold_bwd_post: bad padding");
+  PCNN_REQUIRE(h, pcnn_pad_fold_bwd_post_eligible(C, ldgp, ld_add, gp, add_to, post, lddz, dz),
+               "pcnn_pad_fold_bwd_post: shape not eligible (ask pcnn_pad_fold_bwd_post_eligible first: channels and strides multiples of 4, 16-byte aligned tensors)");
+  PCNN_REQUIRE(h, workspace_bytes >= pcnn_colsum_workspace(C), "pcnn_pad_fold_bwd_post: workspace too small");
+  const int64_t npix = (int64_t)N * H * W;
+  const int nb = colsum_blocks(npix, pow2_ge(C));
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(pad_fold_post_vec4_kernel, dim3(nb), dim3(CS_BLOCK), 0, h->stream, N, H, W, C, pt, pb, pl, pr, pad_mode, gp, ldgp, add_to, ld_add,
+                     post->act_out, post->ld_act_out, bn_scale, post->act, post->act_alpha, post->raw_out, post->ld_raw, dz, lddz, partial);
+  PCNN_CHECK_LAUNCH(h, "pcnn_pad_fold_bwd_post");
+  if (post->dbias || dsum_dy_a || dsum_dy) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, h->stream, partial, nb, C, post->dbias, dsum_dy_a, dsum_dy);
+    PCNN_CHECK_LAUNCH(h, "pcnn_pad_fold_bwd_post(final)");
+  }
   return 0;
 }
 

@@ -305,10 +305,18 @@ class ConvUnit:
     def post_spec(self, want_raw=False):
         """This layer's activation backward (dz = dy act'(a), dbias = sum dz) as an offer to the data-gradient kernel of the layer that CONSUMES
         its output (ops.Post; pass it as `post=` to that layer's backward, then call this layer's backward with dz_ready=post.applied).  None
-        where there is nothing to fuse or the epilogue carries more than an activation (BatchNormalization, strides, a linear layer)."""
-        if self.saved is None or self.bn_name is not None or self.stride > 1 or self.act == 'linear' or self.saved[2] is not None:
+        where there is nothing to fuse or the epilogue carries more than that (training-mode BatchNormalization, strides, a linear layer without
+        BatchNormalization).  An inference-mode BatchNormalization behind the activation rides along as bn_scale + the two sums its gamma / beta
+        gradients need: only the fold route of SYMMETRIC / REFLECT layers takes such an offer (ops.pad_fold_bwd_post), the spectral kernels leave it."""
+        if self.saved is None or self.stride > 1 or self.saved[2] is not None:
             return None
-        return ops.Post(self.saved[1], self.act, self.store.g[self.name + '/bias'] if self.use_bias else None, want_raw)
+        sc, _ = self._bn()
+        if sc is None and self.act == 'linear':
+            return None
+        s = self.store
+        s1 = s.bn_s1[self.bn_off:self.bn_off + self.cout] if sc is not None else None
+        s2 = s.bn_s2[self.bn_off:self.bn_off + self.cout] if sc is not None else None
+        return ops.Post(self.saved[1], self.act, s.g[self.name + '/bias'] if self.use_bias else None, want_raw, bn_scale=sc, s_dy_a=s1, s_dy=s2)
 
     def backward(self, dy, need_dx=True, inplace=False, add_to=None, dz_ready=False, post=None):
         """add_to: optional tensor added to the returned input gradient inside the data-gradient kernel's epilogue (a skip connection's
@@ -332,7 +340,7 @@ class ConvUnit:
         trivial = self.act == 'linear' and sc is None
         amax = None                    # max|dz|: a by-product of the epilogue pass that the split-mode weight gradient would otherwise recompute
         if dz_ready:
-            assert sc is None and bn_stats is None
+            assert bn_stats is None                                   # (an inference-mode BN's scale and sums were part of the offer: ops.Post.bn_scale)
             dz = dy
         elif trivial and not self.use_bias:
             dz = dy
@@ -355,6 +363,10 @@ class ConvUnit:
             if out is not None:
                 if self.mode == 'CONSTANT':
                     return out
+                if post is not None and not post.applied:              # SYMMETRIC / REFLECT: the fold back onto the grid takes the producer's activation backward
+                    dzp = ops.pad_fold_bwd_post(out, (H, W), (self.pads_y, self.pads_x), self.mode, post, add_to=add_to, ws=self.ctx.ws)
+                    if dzp is not None:
+                        return dzp
                 if add_to is not None and add_to.is_contiguous():
                     self.ctx.before_inplace_write(add_to)
                     return ops.pad_fold_bwd(out, (H, W), (self.pads_y, self.pads_x), self.mode, out=add_to, accumulate=True)
@@ -383,6 +395,10 @@ class ConvUnit:
         if self.mode == 'CONSTANT':
             return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to, w_version=wver)
         gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1), w_version=wver)
+        if post is not None and not post.applied:
+            dzp = ops.pad_fold_bwd_post(gp, (H, W), (self.pads_y, self.pads_x), self.mode, post, add_to=add_to, ws=self.ctx.ws)
+            if dzp is not None:
+                return dzp
         if add_to is not None and add_to.is_contiguous():
             self.ctx.before_inplace_write(add_to)
             return ops.pad_fold_bwd(gp, (H, W), (self.pads_y, self.pads_x), self.mode, out=add_to, accumulate=True)

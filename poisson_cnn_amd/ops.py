@@ -397,8 +397,9 @@ class Post:
     want_raw: the un-multiplied gradient is needed as well (a skip connection branches off here).  After the call `applied` says whether the
     kernel took it (then `raw` holds the un-multiplied gradient if it was asked for)."""
 
-    def __init__(self, a, act, dbias=None, want_raw=False):
+    def __init__(self, a, act, dbias=None, want_raw=False, bn_scale=None, s_dy_a=None, s_dy=None):
         self.a, self.act, self.dbias, self.want_raw = a, act, dbias, want_raw
+        self.bn_scale, self.s_dy_a, self.s_dy = bn_scale, s_dy_a, s_dy   # an inference-mode BatchNormalization behind the activation (fold route only: pad_fold_bwd_post)
         self.applied, self.raw = False, None
 
 
@@ -424,7 +425,7 @@ def conv2d_bwd_fused(x, dz, w_shape, wf, *, pad_top, pad_left, pad_mode='CONSTAN
     out = empty((N, out_hw[0], out_hw[1], Cin), x.device)
     flops = 2.0 * N * dz.shape[1] * dz.shape[2] * kh * kw * Cin * Cout
     nbytes = 4.0 * (2 * N * H * W * Cin + N * dz.shape[1] * dz.shape[2] * Cout + 2 * kh * kw * Cin * Cout)
-    if post is not None and mode == 'CONSTANT' and _post_fusion and h.lib.pcnn_conv2d_bwd_spectral_post_eligible(h._h, byref(d), byref(dg)):
+    if post is not None and post.bn_scale is None and mode == 'CONSTANT' and _post_fusion and h.lib.pcnn_conv2d_bwd_spectral_post_eligible(h._h, byref(d), byref(dg)):
         post.raw = empty((N, H, W, Cin), x.device) if post.want_raw else None
         pd = PostDesc(post.a.data_ptr(), _ld(post.a), ACTS[post.act], LEAKY_ALPHA, post.dbias.data_ptr() if post.dbias is not None else None,
                       post.raw.data_ptr() if post.raw is not None else None, Cin)
@@ -485,6 +486,37 @@ def pad_fold_bwd(gp, out_hw, pads, pad_mode, out=None, accumulate=False):
     handle().call('pcnn_pad_fold_bwd', c_int(N), c_int(H), c_int(W), c_int(C), c_int(pt), c_int(pb), c_int(pl), c_int(pr),
                   c_int(PAD_MODES[pad_mode.upper()]), _p(gp), c_int(_ld(gp)), _p(gx), c_int(_ld(gx)), c_int(1 if accumulate else 0))
     return gx
+
+
+_fold_post = __import__('os').environ.get('PCNN_FOLD_POST', '1') != '0'          # developer switch (A/B timing): 0 = fold and activation backward as two passes
+
+
+def pad_fold_bwd_post(gp, out_hw, pads, pad_mode, post, add_to=None, ws=None):
+    """pad_fold_bwd AND the producer's activation backward in one pass (pcnn_pad_fold_bwd_post): returns dz = (fold(gp) [+ add_to]) * act'(post.a), sets
+    post.applied / post.raw (the un-multiplied gradient, if post.want_raw) and writes post.dbias - or returns None (nothing done) where the shape is not
+    eligible or the fusion is switched off (PCNN_POST_FUSION=0): the caller then folds and lets the producer run its own epilogue pass."""
+    if not _post_fusion or not _fold_post:
+        return None
+    N, Hp, Wp, C = gp.shape
+    H, W = out_hw
+    (pt, pb), (pl, pr) = pads
+    assert Hp == H + pt + pb and Wp == W + pl + pr
+    lib = _lib.load()
+    dz = empty((N, H, W, C), gp.device)
+    raw = empty((N, H, W, C), gp.device) if post.want_raw else None
+    pd = PostDesc(post.a.data_ptr(), _ld(post.a), ACTS[post.act], LEAKY_ALPHA, post.dbias.data_ptr() if post.dbias is not None else None,
+                  raw.data_ptr() if raw is not None else None, C)
+    if add_to is not None and not (add_to.dim() == 4 and tuple(add_to.shape) == (N, H, W, C)):
+        return None
+    ld_add = _ld(add_to) if add_to is not None else 0
+    if not lib.pcnn_pad_fold_bwd_post_eligible(c_int(C), c_int(_ld(gp)), c_int(ld_add), _p(gp), _p(add_to), byref(pd), c_int(_ld(dz)), _p(dz)):
+        return None
+    wsb = (ws or _default_ws).get(lib.pcnn_colsum_workspace(c_int(C)), gp.device)
+    handle().call('pcnn_pad_fold_bwd_post', c_int(N), c_int(H), c_int(W), c_int(C), c_int(pt), c_int(pb), c_int(pl), c_int(pr), c_int(PAD_MODES[pad_mode.upper()]),
+                  _p(gp), c_int(_ld(gp)), _p(add_to), c_int(ld_add), byref(pd), _p(post.bn_scale), _p(post.s_dy_a), _p(post.s_dy), _p(dz), c_int(_ld(dz)),
+                  _p(wsb), c_size_t(wsb.numel() * 4))
+    post.raw, post.applied = raw, True
+    return dz
 
 
 def bn_fold(gamma, beta, mean, var, scale, shift, eps=BN_EPS):

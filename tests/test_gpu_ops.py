@@ -580,3 +580,43 @@ def test_metalearning_bottleneck_blocks(kind, method, use_resnet, use_bn, hw):
     okw = dict(kind=kind, f=3, up=3, filters=5, k=3, n_convs=3, acts=['tanh'] * 3, mode='SYMMETRIC', value=0.0, act='leaky_relu', method=method, pool='average',
                use_resnet=use_resnet, use_bn=use_bn, kdown=5, kdeconv=3, dacts=['tanh'] * 3)
     _ml_check(blk, w, lambda p, xt, dt: oml.mbottleneck(p, name, xt, dt, **okw), x, di, lambda: call(training=True))
+
+
+@pytest.mark.parametrize('mode', ['SYMMETRIC', 'REFLECT'])
+@pytest.mark.parametrize('act', ['leaky_relu', 'tanh'])
+def test_pad_fold_with_the_producers_activation_backward_in_one_pass(mode, act):
+    """pcnn_pad_fold_bwd_post == pad_fold_bwd (+ skip gradient) followed by epilogue_bwd: dz and the raw copy bit for bit (same sums in the same order),
+    the bias gradient to summation-order rounding."""
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(11)
+    N, H, W, C, pads = 2, 37, 29, 12, ((3, 3), (2, 4))
+    gp = torch.randn(N, H + 6, W + 6, C, generator=g).cuda()
+    a = torch.tanh(torch.randn(N, H, W, C, generator=g)).cuda()
+    skip = torch.randn(N, H, W, C, generator=g).cuda()
+    for add_to, want_raw in ((None, False), (skip, True)):
+        dx = ops.pad_fold_bwd(gp, (H, W), pads, mode)
+        if add_to is not None:
+            dx = ops.axpby(1.0, add_to, 1.0, dx)
+        db_ref = ops.zeros((C,))
+        dz_ref = ops.epilogue_bwd(dx, a, act=act, dz=ops.empty((N, H, W, C), gp.device), dbias=db_ref)
+        db = ops.zeros((C,))
+        post = ops.Post(a, act, db, want_raw=want_raw)
+        dz = ops.pad_fold_bwd_post(gp, (H, W), pads, mode, post, add_to=add_to)
+        assert dz is not None and post.applied
+        assert torch.equal(dz, dz_ref)
+        assert (post.raw is not None) == want_raw and (not want_raw or torch.equal(post.raw, dx))
+        assert float((db - db_ref).abs().max()) <= 1e-5 * float(db_ref.abs().max()) + 1e-6
+    # an inference-mode BatchNormalization behind the activation: bn_scale in dz, and the two sums of its gamma / beta gradients
+    sc = (torch.rand(C, generator=g) + 0.5).cuda()
+    dx = ops.pad_fold_bwd(gp, (H, W), pads, mode)
+    ref = [ops.zeros((C,)) for _ in range(3)]
+    dz_ref = ops.epilogue_bwd(dx, a, act=act, bn_scale=sc, dz=ops.empty((N, H, W, C), gp.device), dbias=ref[0], s_dy_a=ref[1], s_dy=ref[2])
+    got = [ops.zeros((C,)) for _ in range(3)]
+    post = ops.Post(a, act, got[0], bn_scale=sc, s_dy_a=got[1], s_dy=got[2])
+    dz = ops.pad_fold_bwd_post(gp, (H, W), pads, mode, post)
+    assert post.applied and torch.equal(dz, dz_ref)
+    for u, v in zip(got, ref):
+        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-6
+    # not eligible (3 channels): nothing is done, the caller keeps the two-pass route
+    post = ops.Post(a[..., :3].contiguous(), act, None)
+    assert ops.pad_fold_bwd_post(gp[..., :3].contiguous(), (H, W), pads, mode, post) is None and not post.applied
