@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/study_${TAG:-fft}_${1:-15}_${2:-64}.txt
 for bits in ${BITS:-0 1 2 3 4 7}; do
   d=$ROOT/gpurun_out/study_$bits
   rm -rf $d
-  (cd /tmp && PCNN_LIBRARY=$ROOT/poisson_cnn_amd/libpcnn_study.so PCNN_FFT_STUDY=$bits rocprofv3 --kernel-trace --stats -d $d --output-format csv -- python3 $ROOT/tools/study_fft.py ${1:-15} ${2:-64} > $d.log 2>&1)
+  (cd /tmp && PCNN_LIBRARY=$ROOT/build/study/libpcnn_study.so PCNN_FFT_STUDY=$bits rocprofv3 --kernel-trace --stats -d $d --output-format csv -- python3 $ROOT/tools/study_fft.py ${1:-15} ${2:-64} > $d.log 2>&1)
   echo "bits $bits: $(grep 'study bits' $d.log)" >> $OUT
   python3 - $d >> $OUT <<'PY'
 import csv, glob, sys

@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/study_mix_keep.txt
 for k in 4 3 2 0; do for bits in 0 64; do
   d=$ROOT/gpurun_out/study_keep${k}_$bits
   rm -rf $d
-  (cd /tmp && PCNN_LIBRARY=$ROOT/poisson_cnn_amd/libpcnn_keep$k.so PCNN_FFT_STUDY=$bits rocprofv3 --kernel-trace --stats -d $d --output-format csv -- python3 $ROOT/tools/study_fft.py 7 32 > $d.log 2>&1)
+  (cd /tmp && PCNN_LIBRARY=$ROOT/build/study/libpcnn_keep$k.so PCNN_FFT_STUDY=$bits rocprofv3 --kernel-trace --stats -d $d --output-format csv -- python3 $ROOT/tools/study_fft.py 7 32 > $d.log 2>&1)
   echo "keep $k of 4 MFMAs, rows bit $bits: $(grep 'study bits' $d.log)" >> $OUT
   python3 - $d >> $OUT <<'PY'
 import csv, glob, sys

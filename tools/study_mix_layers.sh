@@ -6,5 +6,5 @@
 ROOT=$(pwd)
 for k in 4 3; do for bits in 0 64; do
   echo "== keep $k of 4 MFMAs, rows bit $bits"
-  PCNN_LIBRARY=$ROOT/poisson_cnn_amd/libpcnn_keep$k.so PCNN_FFT_STUDY=$bits python3 tools/probe_xform.py 8 2>&1 | grep -v amdgpu.ids | grep "k 7 32->32 @1024\|k15 32->32\|k 9 24\|sums"
+  PCNN_LIBRARY=$ROOT/build/study/libpcnn_keep$k.so PCNN_FFT_STUDY=$bits python3 tools/probe_xform.py 8 2>&1 | grep -v amdgpu.ids | grep "k 7 32->32 @1024\|k15 32->32\|k 9 24\|sums"
 done; done
