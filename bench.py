@@ -255,14 +255,18 @@ def launch_check(args, dp):
         dp.all_reduce_sum(bucket)
     if dev == 'cuda':
         torch.cuda.synchronize()
+    local = time.perf_counter() - t0
     dp.barrier()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    per_rank = [1e3 * v / args.steps for v in dp.gather_over_ranks(local)]
     if dp.rank == 0:
         print(json.dumps({'metric': 'launch-check (no model)', 'dry_run': True, 'value': args.steps / elapsed, 'unit': 'all-reduces/s (22.2 MB fp32 bucket)',
                           'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                           'config': {'workload': 'launch-check', 'collective': dp.collective_name(), 'parallelism': 'dp%d' % dp.world_size,
-                                     'ranks_seen': dp.ranks_seen(), 'rccl': dp.rccl_version()}}), flush=True)
+                                     'ranks_seen': dp.ranks_seen(), 'rccl': dp.rccl_version()},
+                          'rank_ms_per_step': {'max': max(per_rank), 'min': min(per_rank), 'ranks': per_rank, 'conv_ms_per_step': [0.0] * dp.world_size},
+                          'affinity': AFFINITY}), flush=True)
 
 
 PROFILE_ROUND = 'r05'
@@ -287,7 +291,9 @@ def compact_line(d):
     out['value'], out['ms_per_step'] = _r(out['value'], 3), _r(out['ms_per_step'], 3)
     out['config'] = {'workload': cfg.get('workload'), 'global_batch': cfg.get('global_batch'), 'grid': cfg.get('grid'), 'parallelism': cfg.get('parallelism'),
                      'math': cfg.get('math'), 'collective': cfg.get('collective'), 'ranks_seen': cfg.get('ranks_seen'), 'rccl': cfg.get('rccl')}
-    out['rank_ms_per_step'] = {k: _r(v, 3) for k, v in (d.get('rank_ms_per_step') or {}).items()}
+    out['rank_ms_per_step'] = {k: ([_r(x, 2) for x in v] if isinstance(v, list) else _r(v, 3)) for k, v in (d.get('rank_ms_per_step') or {}).items()}
+    if d.get('affinity'):
+        out['affinity'] = d['affinity']
     out['collective_ms'] = _r(d.get('collective_ms'), 4)
     out['roofline'] = {'bound': rf.get('bound'), 'kernel': 'all conv launches of a step (spectral + direct + narrow)', 'achieved': _r(rf.get('achieved'), 1),
                        'peak': rf.get('peak'), 'unit': rf.get('unit'), 'frac': _r(rf.get('frac')), 'traffic': rf.get('traffic'),
@@ -436,7 +442,8 @@ def run(args):
         prof = None if overlap else ops.KernelTimer()
         elapsed, local, loss = region(prof)
         # per-rank view of the same region (before the closing barrier): load imbalance between ranks shows as max > min
-        rank_ms = {'max': 1e3 * dp.max_over_ranks(local) / steps, 'min': -1e3 * dp.max_over_ranks(-local) / steps}
+        per_rank = [1e3 * v / steps for v in dp.gather_over_ranks(local)]
+        rank_ms = {'max': max(per_rank), 'min': min(per_rank), 'ranks': per_rank}
         note('%s: timed region %.3f s' % (mode, elapsed))
         single = None
         if overlap:                    # roofline region: the same steps on ONE stream, HIP events around every convolution launch
@@ -449,6 +456,10 @@ def run(args):
                 note('%s: single-stream roofline region %.3f s' % (mode, e2))
             finally:
                 model.ctx.use_side = True
+        # every rank's own convolution-kernel time per step (HIP events of the single-stream region): with rank_ms_per_step.ranks this tells a slow
+        # rank (clock, NUMA placement) from collective cost on a scaling curve
+        conv_s = sum(prof.totals(k)[1] for k in ('conv_fwd', 'conv_wgrad', 'conv_bwd_fused', 'conv_stage')) if prof is not None else 0.0
+        rank_ms['conv_ms_per_step'] = [1e3 * v / steps for v in dp.gather_over_ranks(conv_s)]
         return elapsed, prof, loss, rank_ms, single
 
     def collective_ms(reps=10):
@@ -561,7 +572,7 @@ def run(args):
                    'global_batch': gbs, 'grid': [H, W], 'parallelism': 'dp%d' % dp.world_size, 'math': head, 'library_default_math': 'fp32',
                    'overlap_wgrad': bool(args.overlap_wgrad), 'final_loss': hb['final_loss'], 'collective': dp.collective_name() if dp.world_size > 1 else None,
                    'ranks_seen': dp.ranks_seen(), 'rccl': dp.rccl_version()},
-        'rank_ms_per_step': hb['rank_ms_per_step'], 'collective_ms': coll_ms,
+        'rank_ms_per_step': hb['rank_ms_per_step'], 'collective_ms': coll_ms, 'affinity': AFFINITY,
         'roofline': hb['roofline'],
     }
     for mode in modes[:-1]:
@@ -584,10 +595,63 @@ def run(args):
     emit(out, args.detail)
 
 
+def bind_to_gpu_numa_node(local_rank):
+    """Pins this rank to the CPUs of its GPU's NUMA node - os.sched_setaffinity in the rank's own process, BEFORE torch is
+    imported or any HIP call is made (no numactl / taskset wrapper, nothing re-exec'ed).  The GPU's node comes from sysfs alone: the KFD topology
+    lists the GPU nodes in HIP's enumeration order (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES applied on top), each with the PCI address whose
+    sysfs entry names the NUMA node.  Anything missing or inconsistent - no topology, node -1, an empty intersection with the CPUs this process
+    may use (a cgroup share) - leaves the affinity untouched.  PCNN_BENCH_AFFINITY=0 switches it off.  Returns a report dict."""
+    rep = {'bound': False}
+    if os.environ.get('PCNN_BENCH_AFFINITY', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        rep['why'] = 'disabled'
+        return rep
+    try:
+        base = '/sys/class/kfd/kfd/topology/nodes'
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, n, 'properties')) if len(ln.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                loc, dom = int(props.get('location_id', '0')), int(props.get('domain', '0'))
+                gpus.append('%04x:%02x:%02x.%x' % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 0x7))
+        for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):       # each filters the list the previous one left
+            v = os.environ.get(var)
+            if v:
+                idx = [int(t) for t in v.split(',') if t.strip().isdigit()]
+                gpus = [gpus[i] for i in idx if i < len(gpus)]
+        if not gpus:
+            rep['why'] = 'no GPU nodes in the KFD topology'
+            return rep
+        bdf = gpus[local_rank % len(gpus)]
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
+        rep.update(pci=bdf, numa_node=node)
+        if node < 0:
+            rep['why'] = 'the device reports no NUMA node'
+            return rep
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            a, _, b = part.partition('-')
+            cpus.update(range(int(a), int(b or a) + 1))
+        mine = cpus & os.sched_getaffinity(0)
+        if not mine:
+            rep['why'] = 'the node shares no CPU with this process\'s allowed set'
+            return rep
+        os.sched_setaffinity(0, mine)
+        rep.update(bound=True, cpus=len(mine))
+    except (OSError, ValueError, KeyError, IndexError) as e:
+        rep['why'] = repr(e)
+    return rep
+
+
+AFFINITY = None
+
+
 def main():
+    global AFFINITY
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
+    if args.gpus > 1:                       # a rank process (self-launched or the driver's torch.distributed.run child): torch is not imported yet
+        AFFINITY = bind_to_gpu_numa_node(int(os.environ.get('LOCAL_RANK', '0')))
     run(args)
 
 

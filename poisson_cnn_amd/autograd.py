@@ -43,14 +43,13 @@ class _Pair(torch.autograd.Function):
         layer = module.layer
         if module._pending:
             raise RuntimeError('%s was applied twice before backward(): a libpcnn layer keeps the activations of one call - use one layer object per '
-                               'application (as the reference\'s models do)' % type(layer).__name__)
+                               'application (as the reference\'s models do); if the earlier forward was never differentiated, call module.reset()' % type(layer).__name__)
         out = module._call(module._rebuild(tensors), True)
         if not isinstance(out, torch.Tensor):
             raise TypeError('%s returned %s: only single-tensor outputs are differentiable here' % (type(layer).__name__, type(out).__name__))
         module._pending = True
         ctx.module = module
         ctx.n = len(tensors)
-        ctx.mark_non_differentiable(*[t for t in tensors if not t.requires_grad])
         return out
 
     @staticmethod
@@ -140,6 +139,7 @@ class Differentiable(torch.nn.Module):
             self._warmed = True
         self._bind_parameters()
         if not (torch.is_grad_enabled() and self.training):
+            self._pending = False                              # an inference call replaces whatever an undifferentiated training forward left behind
             with torch.no_grad():
                 return self._call(self._rebuild(tensors), False)
         # which tensor inputs the layer's backward returns gradients for: all of them where it returns a list (MergeWithAttention), else the first
@@ -147,6 +147,11 @@ class Differentiable(torch.nn.Module):
         self._tensor_slots_differentiable = list(range(n))
         w = self.weight if self.weight is not None else torch.zeros(0, device=tensors[0].device if n else 'cpu')
         return _Pair.apply(self, w, *tensors)
+
+    def reset(self):
+        """Forgets a training-mode forward that will never be differentiated (a logged loss, an exception before loss.backward()): the next forward is
+        accepted again.  The layer's saved activations are simply overwritten by that forward."""
+        self._pending = False
 
     def extra_repr(self):
         return '%s, %d parameters' % (type(self.layer).__name__, 0 if self.weight is None else self.weight.numel())

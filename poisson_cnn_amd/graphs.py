@@ -69,6 +69,9 @@ class _Captured:
                 ops.handle().call('pcnn_set_workspace_retain', c_int(1))
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
+            # the flipped-filter table of the layer set the warm-up registered, built eagerly: the capture records one table launch (not one flip
+            # per layer), and this graph owns a reference to the table and to every flipped filter it addresses
+            self._keep += ops.prepare_flip_table_for_capture()
             ops.weights_changed()                                     # a replay must refresh the cached filter spectra (the weights move between replays,
             with torch.cuda.graph(self.graph, stream=self.stream):    # no host code runs): the refresh launch is recorded only if the version is new here
                 out = fn()

@@ -294,6 +294,10 @@ class ConvUnit:
             self._wf = torch.empty((self.kh, self.kw, self.cout, self.cin), dtype=torch.float32, device=w.device)
             self._wf_ver = None
             ops.register_flipped(self)
+        if ver and self._wf_ver is not None and self._wf_ver != ver:
+            # a new weights version met in a BACKWARD pass (another model's optimizer step between this layer's forward and backward): the cached
+            # convolution below makes the handle refresh every kept filter, so every registered layer's flipped filter must be current first
+            ops.sync_flipped_filters(ver)
         if not ver or self._wf_ver != ver:
             self._reflip(ver)
         return self._wf, ver

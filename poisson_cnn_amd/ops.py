@@ -137,6 +137,37 @@ def register_flipped(layer):
 _flip_table = (None, None, 0, 0)                 # (key, device table, n, total) of pcnn_conv2d_flip_transpose_table
 
 
+def _flip_layer_set():
+    layers = sorted((l for l in _flip_layers if getattr(l, '_wf', None) is not None), key=id)
+    return layers, tuple((id(l), l._wf.data_ptr()) for l in layers)
+
+
+def _build_flip_table(layers, key):
+    """Uploads the device table of (filter, flipped filter, shape) entries.  The previous table is NOT freed here by hand: a captured graph that recorded
+    a table launch holds a reference to the tensor it recorded (graphs._Captured._keep, flip_table_tensor), so a retired table lives exactly as long
+    as a graph can replay it (a replay must never read a recycled allocation as pointer entries)."""
+    global _flip_table
+    arr = np.zeros(len(layers), dtype=[('w', '<u8'), ('wt', '<u8'), ('kh', '<i4'), ('kw', '<i4'), ('ci', '<i4'), ('co', '<i4'), ('start', '<i8')])
+    start = 0
+    for i, l in enumerate(layers):
+        w = l.store.w[l.name + '/kernel']
+        arr[i] = (w.data_ptr(), l._wf.data_ptr(), l.kh, l.kw, l.cin, l.cout, start)
+        start += w.numel()
+    _flip_table = (key, torch.from_numpy(arr.view(np.uint8)).to(layers[0]._wf.device), len(layers), start)
+
+
+def prepare_flip_table_for_capture():
+    """Called by graphs._Captured right before a capture (outside it): the table is rebuilt for the layer set the warm-up left behind, so that the
+    capture records ONE table launch instead of one flip per layer, and returned so that the graph keeps it (and the flipped filters it points
+    to) alive for its replays.  Returns a list of tensors to hold."""
+    layers, key = _flip_layer_set()
+    if not layers:
+        return []
+    if key != _flip_table[0]:
+        _build_flip_table(layers, key)
+    return [_flip_table[1]] + [l._wf for l in layers]
+
+
 def sync_flipped_filters(version):
     """The promise behind a weights version covers EVERY filter pointer a handle has seen, the flipped filters of the backward pass included: the
     first cached call under a new version makes its handle refresh all of them at once.  So before that call every layer's flipped filter is
@@ -146,22 +177,15 @@ def sync_flipped_filters(version):
     global _flips_version, _flip_table
     if not version or version == _flips_version:
         return
-    layers = sorted((l for l in _flip_layers if getattr(l, '_wf', None) is not None), key=id)
+    layers, key = _flip_layer_set()
     if layers:
-        key = tuple((id(l), l._wf.data_ptr()) for l in layers)
         if key != _flip_table[0] and torch.cuda.is_current_stream_capturing():
             for l in layers:                                           # the set of layers changed and nothing may be uploaded inside a capture:
                 l._reflip(version)                                     # one launch per layer, as before the table existed
             _flips_version = version
             return
         if key != _flip_table[0]:
-            arr = np.zeros(len(layers), dtype=[('w', '<u8'), ('wt', '<u8'), ('kh', '<i4'), ('kw', '<i4'), ('ci', '<i4'), ('co', '<i4'), ('start', '<i8')])
-            start = 0
-            for i, l in enumerate(layers):
-                w = l.store.w[l.name + '/kernel']
-                arr[i] = (w.data_ptr(), l._wf.data_ptr(), l.kh, l.kw, l.cin, l.cout, start)
-                start += w.numel()
-            _flip_table = (key, torch.from_numpy(arr.view(np.uint8)).to(layers[0]._wf.device), len(layers), start)
+            _build_flip_table(layers, key)
         _, tab, n, total = _flip_table
         handle().call('pcnn_conv2d_flip_transpose_table', _p(tab), c_int(n), c_int64(total))
         for l in layers:

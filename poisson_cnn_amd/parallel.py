@@ -180,3 +180,14 @@ class DataParallel:
         t = torch.tensor([value], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_over_ranks(self, value):
+        """Every rank's scalar, in rank order, on every rank (reports: a slow rank must be distinguishable from collective cost)."""
+        if self.world_size == 1:
+            return [float(value)]
+        dev = 'cuda' if (self.backend == 'nccl') else 'cpu'
+        t = torch.zeros(self.world_size, dtype=torch.float64, device=dev)
+        t[self.rank] = float(value)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.cpu().tolist()]
+

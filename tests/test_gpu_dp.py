@@ -297,3 +297,58 @@ def test_c_abi_collective_rendezvous_with_two_processes():
     else:                                                                              # RCCL's refusal of a duplicate device: an error return on both ranks
         assert all('pcnn_comm_init' in d['init'] for d in outs), outs
         print('two ranks on one device: %s' % outs[0]['init'][:200])
+
+
+_CABI2DEV_SNIPPET = """
+import json, os, sys, torch
+sys.path.insert(0, %r)
+rank = int(os.environ['RANK'])
+torch.cuda.set_device(rank)                                        # one device per rank: RCCL has no reason to refuse
+from poisson_cnn_amd import parallel
+import torch.distributed as dist
+dp = parallel.DataParallel.from_env(backend='nccl')
+dp.enable_c_abi_collective()                                       # must succeed here: an exception fails the rank
+n = 5556956                                                        # hpnn.json's flat gradient bucket: 22.2 MB
+g = torch.Generator(device='cuda').manual_seed(11 + rank)
+a = torch.randn(n, device='cuda', generator=g)
+b = a.clone()
+dp.all_reduce_sum(a)                                               # pcnn_allreduce (RCCL bound inside libpcnn)
+dist.all_reduce(b, op=dist.ReduceOp.SUM)                           # torch.distributed's RCCL
+torch.cuda.synchronize()
+print('CABI2DEV ' + json.dumps({'rank': rank, 'ranks_seen': dp.ranks_seen(), 'name': dp.collective_name(), 'equal': bool(torch.equal(a, b)),
+                                'finite': bool(torch.isfinite(a).all()), 'moved': bool((a != 0).any())}), flush=True)
+dp.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: on a one-GPU box the rendezvous test above covers what can be covered')
+def test_c_abi_allreduce_on_two_devices_equals_torch_distributed_bit_for_bit():
+    """with two devices there is no excuse - both ranks MUST obtain a communicator through the C-ABI rendezvous, reduce the real
+    22.2 MB gradient bucket with pcnn_allreduce and get exactly the bits torch.distributed's RCCL all-reduce gives (two ranks: one addition per
+    element, no ordering freedom)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   PCNN_DIST_TIMEOUT_S='120', NCCL_DEBUG='WARN')
+        procs.append(subprocess.Popen([sys.executable, '-c', _CABI2DEV_SNIPPET % root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            assert p.returncode == 0, (o[-1000:], e[-3000:])
+            line = [ln for ln in o.splitlines() if ln.startswith('CABI2DEV ')]
+            assert len(line) == 1, (o[-1000:], e[-2000:])
+            outs.append(json.loads(line[0][9:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for d in outs:
+        assert d['ranks_seen'] == 2 and 'C-ABI' in d['name'] and d['equal'] and d['finite'] and d['moved'], outs
+

@@ -156,6 +156,27 @@ def test_bench_self_launches_four_ranks_and_reports_the_ranks_it_saw():
     assert len(lines) == 1 and len(lines[0]) < 3072, r.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 4 and out['config']['ranks_seen'] == 4 and out['config']['parallelism'] == 'dp4' and out['value'] > 0
+    # every rank's own step time and convolution-kernel time (a slow rank vs collective cost), and what the NUMA binding did
+    rm = out['rank_ms_per_step']
+    assert len(rm['ranks']) == 4 and len(rm['conv_ms_per_step']) == 4 and all(v > 0 for v in rm['ranks'])
+    assert abs(rm['max'] - max(rm['ranks'])) < 1e-9 and abs(rm['min'] - min(rm['ranks'])) < 1e-9
+    assert isinstance(out['affinity'], dict) and 'bound' in out['affinity']          # no KFD topology in this container: bound False with a reason
+
+
+def test_numa_binding_leaves_the_affinity_alone_when_the_topology_is_absent_or_disabled(monkeypatch):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    before = os.sched_getaffinity(0)
+    rep = bench.bind_to_gpu_numa_node(3)
+    if not rep['bound']:
+        assert 'why' in rep and os.sched_getaffinity(0) == before
+    else:                                                                            # a box with GPUs: the new set is a non-empty subset of the old one
+        assert os.sched_getaffinity(0) <= before and rep['cpus'] == len(os.sched_getaffinity(0)) > 0
+        os.sched_setaffinity(0, before)
+    monkeypatch.setenv('PCNN_BENCH_AFFINITY', '0')
+    assert bench.bind_to_gpu_numa_node(0) == {'bound': False, 'why': 'disabled'} and os.sched_getaffinity(0) == before
 
 
 def test_bench_parent_returns_within_seconds_when_a_rank_dies_before_the_barrier():

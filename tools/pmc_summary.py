@@ -1,5 +1,5 @@
-"""Builds profiles/<name>.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --math <mode> --steps 1 --warmup 0
---no-cpu-baseline --no-dataset`: per-kernel average bytes per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section),
+"""Builds profiles/<name>.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --math <mode> --steps 1 --warmup 1
+--no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0` (tools/collect_pmc.sh; the warm-up step's rows are dropped here): per-kernel average bytes per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section),
 stamped with the hash of the kernel sources it was measured on (poisson_cnn_amd._lib.source_hash) - bench.py reports `traffic` only when
 the stamp matches the tree it runs from.
 
@@ -25,17 +25,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 KERNELS = (r'(conv_fwd_split_kernel<\d, \d>|conv_fwd_kernel<\d>|wgrad_split_kernel|wgrad_kernel|spec_fwd_kernel<\w+, \w+>|spec_inv_kernel|spec_mix_kernel<\d>|spec_mix_lds_kernel<\d>|spec_wmix_kernel|spec_mixw_kernel|'
            r'spec64_fwd4?_kernel<\w+>|spec64_inv_kernel|fft32_fwd_kernel<\w+>|fft32_inv_kernel|fft64_fwd_kernel<\w+(?:, \w+)*>|fft64_inv_kernel|fft32_fwd_multi_kernel|fft64_fwd_multi_kernel|'
            r'conv_small_fwd_kernel|conv_small_wgrad_kernel|resnet3_stage_kernel|split_convert_kernel|split_absmax_kernel|epilogue_bwd\w*|deconv_fwd_mfma_kernel|resize_fwd_kernel)')
+OPTIMIZER = re.compile(r'(adam|sgd\w*|rmsprop)_kernel')      # the last kernel of a training step, whatever the optimizer
+DROPPED = {}                                                # counter file -> was a warm-up step found and dropped?
 CONV = ('conv_fwd', 'wgrad', 'spec', 'fft', 'conv_small', 'resnet3_stage')      # what bench.py's `roofline` covers: every convolution launch
 
 
 def per_kernel(path, counter, scale=1024.0):
     """The counter passes run ONE warm-up step in front of the counted one (tools/collect_pmc.sh: --steps 1 --warmup 1): the first step of a process
     fills the filter-spectrum cache with one launch per filter, which no later step repeats.  Rows up to the first optimizer launch (adam_kernel, the
-    last kernel of a step) are the warm-up and are dropped; a file without two optimizer launches is taken whole."""
+    last kernel of a step) are the warm-up and are dropped; a file without two optimizer launches is taken whole and the
+    summary says so ('warmup_dropped': false - its per-launch averages then include the cache-filling step)."""
     acc = collections.defaultdict(list)
     rows = sorted((r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter), key=lambda r: int(r['Dispatch_Id']))
-    marks = [int(r['Dispatch_Id']) for r in rows if 'adam_kernel' in r['Kernel_Name']]
+    marks = [int(r['Dispatch_Id']) for r in rows if OPTIMIZER.search(r['Kernel_Name'])]
     first = marks[0] if len(marks) >= 2 else -1
+    DROPPED[path] = len(marks) >= 2
     for r in rows:
         if int(r['Dispatch_Id']) <= first:
             continue
@@ -67,7 +71,7 @@ def main():
             # the run's kernel TRACE (one row per launch): the first step of the process - up to its optimizer launch - is dropped like the warm-up step of
             # the counter passes (it fills the filter-spectrum cache with one small launch per filter, which would dilute the per-launch averages)
             rows.sort(key=lambda r: int(r['Dispatch_Id']))
-            marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+            marks = [i for i, r in enumerate(rows) if OPTIMIZER.search(r['Kernel_Name'])]
             if len(marks) >= 2:
                 rows, steps = rows[marks[0] + 1:], float(len(marks) - 1)
             rows = [{'Name': r['Kernel_Name'], 'Calls': 1, 'TotalDurationNs': int(r['End_Timestamp']) - int(r['Start_Timestamp'])} for r in rows]
@@ -93,9 +97,10 @@ def main():
     ca = sum(sum(active[k]) for k in active if k.startswith(CONV))
     if ca > 0:
         kernels['conv (all convolution kernels of one training step)']['mfma_busy_frac'] = cb / (128.0 * ca)
-    json.dump({'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --math %s --steps 1 --warmup 0 '
-                          '--no-cpu-baseline --no-dataset (separate passes; a third one counts SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; tools/collect_pmc.sh)' % math,
+    json.dump({'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --math %s --steps 1 --warmup 1 '
+                          '--no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0 (the warm-up step is dropped; separate passes; a third one counts SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; tools/collect_pmc.sh)' % math,
                'source_hash': _lib.source_hash(),
+               'warmup_dropped': all(DROPPED.values()),
                'note': 'bytes = Counter_Value * 1024; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE reports 1/2 of the bytes of '
                        '16-B-per-lane reads, so traffic = 2*FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are included in FETCH_SIZE, so this is '
                        'an upper bound on HBM reads.  The "conv (...)" row is the sum over all convolution kernels of the step.',
