@@ -168,7 +168,13 @@ class reverse_poisson_dataset_generator:
         return shape, dx
 
     def _dev(self, a):
-        return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device)
+        """host array -> float32 device tensor through a pinned staging buffer and an asynchronous copy on the current stream: a pageable upload
+        (torch.tensor(..., device=...)) synchronises the stream, ten times per batch (profiles/r06_train_shipped.txt); torch's pinned-memory cache
+        keeps the staging buffer alive until the copy has run."""
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        if self.device.type != 'cuda':
+            return t.to(self.device)
+        return t.pin_memory().to(self.device, non_blocking=True)
 
     def _taylor_tables(self, H, W, domain_sizes):
         """1-D tables of generate_soln_and_rhs_taylor (reverse.py:231-256): X, X'', Y, Y'' per sample."""
@@ -283,7 +289,13 @@ class numerical_dataset_generator:
         return self.batches_per_epoch
 
     def _dev(self, a):
-        return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device)
+        """host array -> float32 device tensor through a pinned staging buffer and an asynchronous copy on the current stream: a pageable upload
+        (torch.tensor(..., device=...)) synchronises the stream, ten times per batch (profiles/r06_train_shipped.txt); torch's pinned-memory cache
+        keeps the staging buffer alive until the copy has run."""
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        if self.device.type != 'cuda':
+            return t.to(self.device)
+        return t.pin_memory().to(self.device, non_blocking=True)
 
     def _smooth_field(self, ctrl, out_hw, max_magnitude):
         """generate_random_RHS / generate_random_boundaries core (numerical.py:10-72): control points -> legacy bicubic

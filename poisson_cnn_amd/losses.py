@@ -70,12 +70,19 @@ class integral_loss:
         np.add.at(v, hi, w32.astype(np.float64) * t)
         return v
 
+    def _axis_on_device(self, n, nq, device):
+        key = (n, nq, str(device))
+        v = self._maps.get(key)
+        if v is None:
+            v = self._maps[key] = torch.from_numpy(self._axis_vector(n, nq)).to(device)      # float64, n values
+        return v
+
     def weight_map(self, H, W, device):
-        key = (H, W, str(device))
-        if key not in self._maps:
-            G = np.outer(self._axis_vector(H, self.n_quadpts[0]), self._axis_vector(W, self.n_quadpts[1]))
-            self._maps[key] = torch.tensor(G, dtype=torch.float32, device=device)
-        return self._maps[key]
+        """G = outer(v_H, v_W): the product in float64 rounded once to float32 - formed on the device from the two cached axis vectors (one tiny
+        launch per call).  Keeping a whole (H, W) map per shape, as until round 5, grows without bound under the shipped training workload
+        (experiments/hpnn.json: a new grid shape in [192, 384]^2 every batch - 37 k possible shapes x 0.3 MB); the axis vectors are at most a few
+        hundred short arrays.  Same bits as the host-side outer product it replaces."""
+        return torch.outer(self._axis_on_device(H, self.n_quadpts[0], device), self._axis_on_device(W, self.n_quadpts[1], device)).to(torch.float32)
 
 
 class loss_wrapper:

@@ -45,6 +45,59 @@ def _as_device(t, device):
     return t.to(device=device, dtype=torch.float32).contiguous()
 
 
+def _host_logs(logs):
+    """train_step's dict with device scalars -> Python floats through ONE device-to-host copy (each float(tensor) is a stream synchronise of its own)."""
+    dev = [(k, v) for k, v in logs.items() if isinstance(v, torch.Tensor)]
+    out = {k: (v if isinstance(v, float) else float(v)) for k, v in logs.items() if not isinstance(v, torch.Tensor)}
+    if dev:
+        vals = torch.stack([v.reshape(()).float() for _, v in dev]).tolist()
+        out.update({k: x for (k, _), x in zip(dev, vals)})
+    return {k: out[k] for k in logs}
+
+
+class _Prefetcher:
+    """fit()'s input pipeline: batch i + 1 is produced while step i runs - what Keras' OrderedEnqueuer does for the reference's Sequence generators
+    (train/hpnn_legacy_train.py:60 `model.fit(dataset, ...)`).  The generators of poisson_cnn_amd.dataset draw O(10)-sized parameters on the host
+    (13 ms per batch of 50 for the shipped config) and synthesise the fields on the device: run on a stream of their own, their uploads and kernels
+    do not queue behind the training step, and the host work hides under the step's kernels.  The consumer stream waits for the producer's event;
+    the tensors are handed over with record_stream so that the caching allocator does not recycle them early.  PCNN_PREFETCH=0: generate in line."""
+
+    def __init__(self, dataset, device):
+        self.dataset = dataset
+        self.on = os.environ.get('PCNN_PREFETCH', '1') != '0' and torch.cuda.is_available() and torch.device(device).type == 'cuda'
+        self.stream = torch.cuda.Stream(device=device) if self.on else None
+        self.pending = None
+
+    def request(self, idx):
+        if not self.on:
+            self.pending = (idx, None, None)
+            return
+        # (no wait for the training stream: the generator allocates fresh tensors, and blocks the consumer released are recycled by the caching
+        # allocator only after the events record_stream left on them - so the synthesis kernels overlap the step as well)
+        with torch.cuda.stream(self.stream):
+            batch = self.dataset[idx]
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.pending = (idx, batch, ev)
+
+    def take(self):
+        idx, batch, ev = self.pending
+        self.pending = None
+        if ev is None:
+            return self.dataset[idx]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+
+        def hand_over(v):
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)
+            elif isinstance(v, (list, tuple)):
+                for u in v:
+                    hand_over(u)
+        hand_over(batch)
+        return batch
+
+
 class _ModelBase:
     """What the three model classes share: the Keras-style weight API over a ParamStore, compile(), fit()."""
     model_name = 'model'
@@ -133,10 +186,36 @@ class _ModelBase:
     def stores(self):
         return [self.store]
 
-    def compile(self, loss, optimizer):
+    def compile(self, loss, optimizer, max_input_shape=None):
+        """max_input_shape = (per-process batch, H, W): the largest batch the training loop will see (train.main passes the maximum of the dataset's
+        random_output_shape_range) - see presize()."""
         self.optimizer = optimizer
         self.loss_fn = loss
         optimizer.bind(self.stores)
+        if max_input_shape is not None:
+            self.presize(max_input_shape)
+
+    def presize(self, max_input_shape):
+        """One forward + backward on a synthetic batch of the LARGEST shape the training loop will see, without an optimizer step: the libpcnn handles'
+        workspaces, the branch / side streams' scratch and torch's allocator pools all reach their high-water mark here, once.  The shipped training
+        workload (experiments/hpnn.json:62-75: a new grid shape in [192, 384]^2 every batch, train/hpnn_legacy_train.py:26-60) otherwise re-grows them
+        every time a larger shape comes along - a stream synchronise + free + allocate inside a convolution call, up to 0.6 s for one step
+        (profiles/r06_train_shipped.txt).  Weights, optimizer state and BatchNormalization statistics are left exactly as they were."""
+        batch = self._dummy_batch(tuple(int(v) for v in max_input_shape))
+        if self.loss_fn is None:
+            raise RuntimeError('presize() needs compile(loss, optimizer) first')
+        stats = [(st, st.flat_stats.clone()) for st in self.stores if getattr(st, 'flat_stats', None) is not None]
+        self._forward_backward(batch)
+        for st in self.stores:
+            st.flat_g.zero_()
+        for st, snap in stats:
+            st.flat_stats.copy_(snap)
+        if getattr(self, '_acc', None) is not None:
+            self._acc.zero_()
+        torch.cuda.synchronize()
+
+    def _dummy_batch(self, shape):
+        raise NotImplementedError('%s: presize() is implemented for Homogeneous_Poisson_NN_Legacy' % type(self).__name__)
 
     metric_sync = None   # set by parallel.DataParallel.attach: (loss, mse) -> their GLOBAL values (one tiny all-reduce)
 
@@ -165,10 +244,14 @@ class _ModelBase:
             agg = {'loss': 0.0, 'mse': 0.0}
             logs = {'loss': float('nan'), 'mse': float('nan')}
             step = -1
+            fetch = _Prefetcher(dataset, self.device)
+            fetch.request(0)
             for step in range(n):
-                inp, tar = dataset[step]
+                inp, tar = fetch.take()
                 logs = self.train_step((tuple(inp), tar))
-                logs = {k: (float(v) if not isinstance(v, float) else v) for k, v in logs.items()}
+                if step + 1 < n:                               # the next batch is generated (host draws + uploads + synthesis kernels on a stream of its
+                    fetch.request(step + 1)                    # own) while this step's kernels run; dataset[step] is still called once per step, in order
+                logs = _host_logs(logs)                        # the step's one host round trip
                 for k in agg:
                     agg[k] += logs[k]
                 for cb in callbacks:
@@ -480,7 +563,21 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
         self.backward(dpred)
         return loss, pred
 
+    def _dummy_batch(self, shape):
+        N, H, W = shape
+        g = torch.Generator(device='cpu').manual_seed(0)
+        rhs = (torch.rand((N, 1, H, W), generator=g) * 2 - 1).to(self.device)
+        return (rhs, torch.full((N, 1), 0.02, device=self.device)), (torch.rand((N, 1, H, W), generator=g) * 0.1).to(self.device)
+
     def _train_step_cf(self, data):
+        loss, gt, pred = self._forward_backward(data)
+        if self.grad_sync is not None:
+            self.grad_sync(self.store.flat_g)
+        self.optimizer.apply_gradients()
+        return self._logs(loss, self.loss_fn.mse_metric(gt, pred))
+
+    def _forward_backward(self, data):
+        """forward, loss and backward of one batch (with the reference's gradient accumulation, :275-289): store.flat_g holds the gradient."""
         (rhs, dx), y_true = data
         rhs, dx, y_true = _as_device(rhs, self.device), _as_device(dx, self.device), _as_device(y_true, self.device)
         dx = dx.reshape(dx.shape[0], -1)[:, :1].contiguous()
@@ -500,10 +597,7 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
                 ops.axpby_flat(1.0 / steps, S.flat_g, 0.0 if s == 0 else 1.0, self._acc)     # grads = sum / steps (:287)
                 gt = y_true[a:b]
             ops.axpby_flat(1.0, self._acc, 0.0, S.flat_g)
-        if self.grad_sync is not None:
-            self.grad_sync(S.flat_g)
-        self.optimizer.apply_gradients()
-        return self._logs(loss, self.loss_fn.mse_metric(gt, pred))
+        return loss, gt, pred
 
 
 # =====================================================================================================================

@@ -232,7 +232,14 @@ def main(argv=None):
         model = Homogeneous_Poisson_NN_Legacy(**config['model'])
     optimizer = choose_optimizer(config['training']['optimizer'])(**config['training']['optimizer_parameters'])
     loss = loss_wrapper(global_batch_size=gbs, **config['training']['loss_parameters'])
-    model.compile(loss=loss, optimizer=optimizer)
+    # the largest batch this run will see, for model.presize(): only where the generator draws its grid shape from a range (the analytic generators)
+    rng_ = config['dataset'].get('random_output_shape_range')
+    presize = None
+    if rng_ is not None and isinstance(model, Homogeneous_Poisson_NN_Legacy) and os.environ.get('PCNN_PRESIZE', '1') != '0':
+        r = np.asarray(rng_, dtype=np.int64)
+        r = np.tile(r[None], (2, 1)) if r.ndim == 1 else r
+        presize = (dcfg['batch_size'], int(r[0, 1]), int(r[1, 1]))
+    model.compile(loss=loss, optimizer=optimizer, max_input_shape=presize)
     dp.attach(model)
     cb = [ModelCheckpoint(args.checkpoint_dir + '/chkpt.checkpoint'), ReduceLROnPlateau(patience=4, min_lr=config['training']['min_learning_rate']),
           TerminateOnNaN()]

@@ -1,5 +1,7 @@
 """GPU parity of the whole Homogeneous_Poisson_NN_Legacy forward pass, the loss and the full training step
 (gradients of every parameter, Adam update) against the fp64 oracle / its autograd twin."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -352,3 +354,76 @@ def test_channels_last_model_api():
     np.testing.assert_array_equal(res['channels_first'][0], res['channels_last'][0])
     assert res['channels_first'][1] == res['channels_last'][1]
     np.testing.assert_array_equal(res['channels_first'][2], res['channels_last'][2])
+
+
+_SHAPE_STEP_SNIPPET = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from poisson_cnn_amd import configs
+from poisson_cnn_amd.dataset import reverse_poisson_dataset_generator
+from poisson_cnn_amd.losses import loss_wrapper
+from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+from poisson_cnn_amd.train import Adam
+state_in, state_out, step, H, W = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+cfg = configs.hpnn()
+model = Homogeneous_Poisson_NN_Legacy(**cfg['model'])
+model.compile(loss=loss_wrapper(global_batch_size=50, **cfg['training']['loss_parameters']), optimizer=Adam(learning_rate=1e-4))
+if state_in != '-':
+    st = np.load(state_in)
+    model.store.flat_w.copy_(torch.from_numpy(st['w'])); model.store.flat_stats.copy_(torch.from_numpy(st['stats']))
+    model.optimizer.m.copy_(torch.from_numpy(st['m'])); model.optimizer.v.copy_(torch.from_numpy(st['v'])); model.optimizer.iterations = int(st['it'])
+    from poisson_cnn_amd import ops
+    ops.weights_changed()
+d = dict(cfg['dataset'], batches_per_epoch=1)
+gen = reverse_poisson_dataset_generator(seed=100 + step, **d)
+gen.fixed_output_shape = (H, W)
+inp, tar = gen[0]
+logs = model.train_step((tuple(inp), tar))
+torch.cuda.synchronize()
+np.savez(state_out, w=model.store.flat_w.cpu().numpy(), stats=model.store.flat_stats.cpu().numpy(), m=model.optimizer.m.cpu().numpy(),
+         v=model.optimizer.v.cpu().numpy(), it=model.optimizer.iterations, loss=float(logs['loss']))
+"""
+
+
+def test_shipped_batch_over_changing_shapes_equals_one_step_per_fresh_process(tmp_path):
+    """the shipped training configuration (experiments/hpnn.json: batch 50, a new grid shape every batch) through fit() - with the
+    workspaces pre-sized at compile(), the next batch generated on its own stream while a step runs, one host round trip per step - for 6 steps over
+    3 distinct shapes, against the SAME six steps run one per fresh process (nothing cached, nothing pre-sized, nothing prefetched; weights and Adam
+    state handed over through files): the weights must be BIT-equal.  Per-shape state (tile tables, workspace growth, kept filter spectra, allocator
+    reuse, stream hand-over) must never leak into the arithmetic."""
+    import subprocess
+    import sys
+    from poisson_cnn_amd import configs
+    from poisson_cnn_amd.dataset import reverse_poisson_dataset_generator
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.models import Homogeneous_Poisson_NN_Legacy
+    from poisson_cnn_amd.train import Adam
+    shapes = [(200, 232), (192, 301), (260, 196)] * 2
+    cfg = configs.hpnn()
+
+    class Seq:                                                            # the Keras Sequence fit() walks: step i = the generator seeded 100 + i at shapes[i]
+        def __len__(self):
+            return len(shapes)
+
+        def __getitem__(self, i):
+            gen = reverse_poisson_dataset_generator(seed=100 + i, **dict(cfg['dataset'], batches_per_epoch=1))
+            gen.fixed_output_shape = shapes[i]
+            return gen[0]
+    model = Homogeneous_Poisson_NN_Legacy(**cfg['model'])
+    model.compile(loss=loss_wrapper(global_batch_size=50, **cfg['training']['loss_parameters']), optimizer=Adam(learning_rate=1e-4), max_input_shape=(50, 260, 301))
+    w0 = model.store.flat_w.clone()
+    hist = model.fit(Seq(), epochs=1, verbose=0)
+    torch.cuda.synchronize()
+    w_fit = model.store.flat_w.cpu().numpy()
+    assert np.isfinite(w_fit).all() and not np.array_equal(w_fit, w0.cpu().numpy())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prev = '-'
+    for i, (H, W) in enumerate(shapes):
+        out = str(tmp_path / ('state%d.npz' % i))
+        r = subprocess.run([sys.executable, '-c', _SHAPE_STEP_SNIPPET % root, prev, out, str(i), str(H), str(W)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        prev = out
+    last = np.load(prev)
+    assert int(last['it']) == 6
+    assert np.array_equal(last['w'], w_fit), float(np.abs(last['w'] - w_fit).max())
+    assert abs(float(last['loss']) - hist['loss'][-1]) == 0.0

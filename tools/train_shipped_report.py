@@ -21,13 +21,13 @@ if os.path.exists(ks) and os.path.exists(kt):
     tot_ns = sum(float(r['TotalDurationNs']) for r in rows)
     calls = sum(int(r['Calls']) for r in rows)
     u = json.load(open(kt))['pass1_every_shape_new']
-    wall = u['mean_step_ms'] + u['mean_gen_ms']
+    wall = u['mean_step_ms']
     print('\n## kernel time vs wall (rocprofv3 --kernel-trace --stats, %d steps, includes the first steps)' % steps)
-    print('kernel-time sum per step %.2f ms | launches per step %.0f | wall per step under the tracer: step %.2f + generation %.2f = %.2f ms | wall / kernel sum = %.3f'
-          % (tot_ns * 1e-6 / steps, calls / steps, u['mean_step_ms'], u['mean_gen_ms'], wall, wall / (tot_ns * 1e-6 / steps)))
-    print('untraced wall per step (pass 1): step %.2f + generation %.2f ms  ->  untraced wall / kernel sum = %.3f'
-          % (main['pass1_every_shape_new']['mean_step_ms'], main['pass1_every_shape_new']['mean_gen_ms'],
-             (main['pass1_every_shape_new']['mean_step_ms'] + main['pass1_every_shape_new']['mean_gen_ms']) / (tot_ns * 1e-6 / steps)))
+    print('kernel-time sum per step %.2f ms | launches per step %.0f | wall per step under the tracer (batch end to batch end, generation included) %.2f ms, of which host time in dataset[i] %.2f ms | wall / kernel sum = %.3f'
+          % (tot_ns * 1e-6 / steps, calls / steps, wall, u['mean_gen_ms'], wall / (tot_ns * 1e-6 / steps)))
+    for ps in ('pass1_every_shape_new', 'pass2_same_shapes_again'):
+        if ps in main:
+            print('untraced wall per step (%s) %.2f ms  ->  untraced wall / kernel sum = %.3f' % (ps, main[ps]['mean_step_ms'], main[ps]['mean_step_ms'] / (tot_ns * 1e-6 / steps)))
     print('%-70s %8s %10s %8s' % ('kernel', 'calls/st', 'ms/step', '%'))
     for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:28]:
         print('%-70s %8.1f %10.3f %8.2f' % (r['Name'][:70], int(r['Calls']) / steps, float(r['TotalDurationNs']) * 1e-6 / steps, 100 * float(r['TotalDurationNs']) / tot_ns))
