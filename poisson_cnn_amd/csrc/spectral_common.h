@@ -18,6 +18,42 @@ constexpr int SP_PAD = PCNN_SP_PAD;
 __host__ __device__ __forceinline__ int64_t sp_item(int64_t item, int rows) { return item * ((int64_t)rows * RS + SP_PAD); }
 __host__ __device__ __forceinline__ size_t sp_bytes(size_t items, int rows) { return items * ((size_t)rows * RS + SP_PAD) * sizeof(float); }
 
+// ---- row order inside an item.  CANONICAL order (the matrix-core transform family, the debug exports and the tests): the header comment above.
+// The FFT family (spectral_fft.hip, the default) interleaves the real and the imaginary row of a frequency in blocks of PCNN_SP_P frequencies, so that
+// the per-frequency kernels - which read / write the (Re, Im) row pair of ONE frequency of every item - find the pair inside one 256 P-byte piece of the
+// item instead of T rows (4 / 8 KB) apart: row(k, part) = 2 P (k / P) + P part + k % P inside a column block, k = frequency index of the column (complex
+// column: fy = 0..T-1; real column: the pair index, k = 0 the two real frequencies fy = 0 | T/2, k >= 1: Re | Im of fy = k).  P = T (T/2 for the real
+// columns) IS the canonical order.  The mixing kernels only follow the slot tables (rr, ri), built from the same function for each family.
+#ifndef PCNN_SP_P
+#define PCNN_SP_P 1
+#endif
+__host__ __device__ constexpr int sp_blk(int P, int k, int part) { return 2 * P * (k / P) + P * part + (k % P); }
+__host__ __device__ constexpr int sp_pc(int T, int P) { return P < T ? P : T; }             // block size of a complex column
+__host__ __device__ constexpr int sp_pr(int T, int P) { return P < T / 2 ? P : T / 2; }     // ... of a real column
+// complex column of a T-point tile: row (inside the column's 2 T rows) of part (0 real, 1 imaginary) of frequency fy
+__host__ __device__ constexpr int sp_row_c(int T, int fy, int part, int P = PCNN_SP_P) { return sp_blk(sp_pc(T, P), fy, part); }
+// real column: row (inside the column's T rows) of half-complex entry s (s <= T/2: Re fy = s; s > T/2: Im fy = s - T/2)
+__host__ __device__ constexpr int sp_row_r(int T, int s, int P = PCNN_SP_P) {
+  return s == T / 2 ? sp_blk(sp_pr(T, P), 0, 1) : (s < T / 2 ? sp_blk(sp_pr(T, P), s, 0) : sp_blk(sp_pr(T, P), s - T / 2, 1));
+}
+// canonical row r of an item -> its row in the order with block size P
+__host__ __device__ constexpr int sp_row_from_canonical(int T, int r, int P = PCNN_SP_P) {
+  return r < 2 * T ? (r / T) * T + sp_row_r(T, r % T, P) : 2 * T + ((r - 2 * T) / (2 * T)) * 2 * T + sp_row_c(T, (r - 2 * T) % T, ((r - 2 * T) % (2 * T)) / T, P);
+}
+static_assert(sp_row_from_canonical(32, 5, 64) == 5 && sp_row_from_canonical(32, 16, 64) == 16 && sp_row_from_canonical(32, 64 + 37, 64) == 64 + 37 && sp_row_from_canonical(64, 128 + 64 + 9, 64) == 128 + 64 + 9, "P >= T is the canonical order");
+static_assert(sp_row_from_canonical(32, 16, 1) == 1 && sp_row_from_canonical(32, 3, 1) == 6 && sp_row_from_canonical(32, 16 + 3, 1) == 7 && sp_row_from_canonical(32, 64 + 32 + 5, 1) == 64 + 11, "P = 1: Re | Im adjacent");
+// the mixing slots (rr, ri, kind, 0) of a tile size in the order with block size P: T^2 / 2 of them (kind 1: the slot packs two REAL frequencies)
+inline void sp_build_slots(int T, int P, int* slots) {
+  int n = 0;
+  auto put = [&](int rr, int ri, int kind) { slots[4 * n] = rr; slots[4 * n + 1] = ri; slots[4 * n + 2] = kind; slots[4 * n + 3] = 0; ++n; };
+  for (int b = 0; b < 2; ++b) {
+    put(b * T + sp_row_r(T, 0, P), b * T + sp_row_r(T, T / 2, P), 1);
+    for (int fy = 1; fy < T / 2; ++fy) put(b * T + sp_row_r(T, fy, P), b * T + sp_row_r(T, T / 2 + fy, P), 0);
+  }
+  for (int fx = 1; fx < T / 2; ++fx)
+    for (int fy = 0; fy < T; ++fy) put(2 * T + 2 * T * (fx - 1) + sp_row_c(T, fy, 0, P), 2 * T + 2 * T * (fx - 1) + sp_row_c(T, fy, 1, P), 0);
+}
+
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 zero16() {

@@ -413,30 +413,35 @@ __global__ __launch_bounds__(512, 1) void spec_inv_kernel(InvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------ per-frequency channel mixing
-struct MixParams { const float* xs; float* ys; const float* wsp; const int4* slots; int ntile, gin, gout, rows, Cin, cpt, study; };   // wsp: filter spectrum; Cin: its input channels; cpt: lanes per packed tile      // rows: spectrum rows per item (T*T)
+struct MixParams { const float* xs; float* ys; const float* wsp; const int4* slots; int ntile, gin, gout, rows, Cin, cpt; };   // wsp: filter spectrum; Cin: its input channels; cpt: lanes per packed tile      // rows: spectrum rows per item (T*T)
 
-// K order inside one 64-row block of M_f (one input channel group): step ks = 16 p + j pairs channel j (lanes 0-31) with channel 16 + j
-// (lanes 32-63) of part p (0: real row, 1: imaginary row) - so a lane's A operands are 16 CONSECUTIVE channels of its tile's row.
+// Y^ = X^ H per frequency, H = conj(W^) (correlation), as THREE real products (Gauss) instead of the four of [Yr | Yi] = [Xr | Xi] [[Hr, Hi], [-Hi, Hr]]:
+//   k1 = (Xr + Xi) Hr,  k2 = Xr (Hi - Hr),  k3 = Xi (Hr + Hi);   Yr = k1 - k3,  Yi = k1 + k2
+// - 48 instead of 64 MFMAs per M-tile and channel group, three accumulators instead of two, 48 instead of 64 filter registers per group.  Rounds 4 / 5 measured
+// the kernel at 0.62 of HBM with the matrix pipe 0.52 busy and priced this change with diagnostic builds before building it (profiles/r05_study_mix_keep.txt,
+// r05_study_mix_layers_upper_bounds.txt: 746 -> 657 us per launch at 7 taps with a quarter of the MFMAs gone, 603 with the real and imaginary row of a
+// frequency adjacent as well - the FFT family's row order since round 6, spectral_common.h).  The sums Xr + Xi and the differences of the filter spectrum
+// are formed in fp32: the result differs from the four-product form by rounding only (tests/test_gpu_spectral*.py at unchanged tolerances).
+// A slot that packs two REAL frequencies (sl.z == 1; rows rr and ri hold two independent real spectra): Y(rr) = X(rr) Wr, Y(ri) = X(ri) Wi - the same three
+// accumulators with A1 = Xr, A2 = Xi, B3 = 0 and Yi = k2 alone (a uniform factor s = 0 in place of 1).
+// K order: step j pairs channel j (lanes 0-31) with channel 16 + j (lanes 32-63) - a lane's A operands are 16 CONSECUTIVE channels of its tile's rows.
+// cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and the filter block is block diagonal - a tile's channels mix only among themselves.
 // (3 workgroups per CU - 168 VGPRs - was measured: 7 % slower; the kernel is bound by the HBM read + write stream, not by latency)
 template <int GIN>
 __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, c = lane & 31;
   const int slot = blockIdx.x, go = blockIdx.z;
   const int4 sl = p.slots[slot];
-#ifdef PCNN_FFT_STUDY                                                     // diagnostic build (make study): 64 = the imaginary row next to the real one
-  const int rr = (p.study & 64) ? (sl.x & ~1) : sl.x, ri = (p.study & 64) ? (sl.x | 1) : sl.y;
-#else
   const int rr = sl.x, ri = sl.y;
-#endif
-  // M_f = [[Hr, Hi], [-Hi, Hr]], H = conj(W^), straight from the filter spectrum Wsp[ci * gout + go][row][co] (conj: correlation): this lane's
-  // 16 input channels j + 16 half of its output channel c - 32 loads of L2-resident rows.  A slot that packs two real frequencies (sl.z == 1)
-  // is block diagonal in (real row, imaginary row).  cpt < 32 (tile packing): lane = cpt * tile + channel on both sides and M_f is block
-  // diagonal - a tile's channels mix only among themselves.  (Until round 3 a separate kernel wrote these matrices to a buffer: one more
-  // launch per convolution and 64 loads per lane here.)
-  float breg[GIN][32][2];
+  int kind = sl.z;
+  asm volatile("" : "+v"(kind));                               // per-lane on purpose: a uniform selector becomes scalar branches around the MFMA loop (two copies)
+  const bool real2 = kind == 1;
+  const float s_cplx = real2 ? 0.f : 1.f;
+  // straight from the filter spectrum Wsp[ci * gout + go][row][co]: this lane's 16 input channels j + 16 half of its output channel c - 32 loads of
+  // L2-resident rows
+  float b1[GIN][16], b2[GIN][16], b3[GIN][16];
   {
     const int co = c % p.cpt;
-    const bool real2 = sl.z == 1;
 #pragma unroll
     for (int gi = 0; gi < GIN; ++gi)
 #pragma unroll
@@ -447,8 +452,10 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
           const float* wg = p.wsp + pcnn_spec::sp_item(ci * p.gout + go, p.rows) + co;
           wr = wg[rr * RS]; wi = wg[ri * RS];
         }
-        breg[gi][j][0] = wr;                     breg[gi][j][1] = real2 ? 0.f : -wi;          // K part 0 (real input rows)
-        breg[gi][16 + j][0] = real2 ? 0.f : wi;  breg[gi][16 + j][1] = real2 ? wi : wr;       // K part 1 (imaginary input rows)
+        // Hr = wr, Hi = -wi
+        b1[gi][j] = wr;
+        b2[gi][j] = real2 ? wi : -wi - wr;                 // Hi - Hr
+        b3[gi][j] = real2 ? 0.f : wi - wr;                 // -(Hr + Hi): Yr = k1 + Xi b3
       }
   }
   const int nMt = (p.ntile + 31) >> 5;
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
   if (mt >= nMt) return;
   load_a(mt, 0, a);
   auto m_tile = [&](int mt) {
-    f32x16 acc[2] = {zero16(), zero16()};
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};
 #pragma unroll
     for (int gi = 0; gi < GIN; ++gi) {
       // the next operand block (next channel group, or the next M-tile's first group) is requested before this one's MFMAs (two blocks
@@ -475,13 +482,11 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
       if (gi + 1 < GIN) load_a(mt, gi + 1, an);
       else if (mt + mstride < nMt) load_a(mt + mstride, 0, an);
 #pragma unroll
-      for (int ks = 0; ks < 32; ++ks) {
-        const float av = a[ks >> 4][(ks & 15) >> 2][ks & 3];
-#ifdef PCNN_MIX_KEEP                                                      // diagnostic builds only: keep PCNN_MIX_KEEP of every 4 k-steps on the matrix pipe (0: none) - what would
-        if ((ks & 3) >= PCNN_MIX_KEEP) { acc[0][ks & 15] += av * breg[gi][ks][0]; acc[1][ks & 15] += av * breg[gi][ks][1]; continue; }   // fewer MFMAs buy?
-#endif
-        acc[0] = mfma(av, breg[gi][ks][0], acc[0]);
-        acc[1] = mfma(av, breg[gi][ks][1], acc[1]);
+      for (int j = 0; j < 16; ++j) {
+        const float xr = a[0][j >> 2][j & 3], xi = a[1][j >> 2][j & 3];
+        acc[0] = mfma(fmaf(s_cplx, xi, xr), b1[gi][j], acc[0]);
+        acc[1] = mfma(real2 ? xi : xr, b2[gi][j], acc[1]);
+        acc[2] = mfma(xi, b3[gi][j], acc[2]);
       }
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp)
@@ -489,13 +494,11 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
         for (int j4 = 0; j4 < 4; ++j4) a[pp][j4] = an[pp][j4];
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int row = nt ? ri : rr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int trow = mt * 32 + acc_row(r, half);
-        NT_STORE(4, acc[nt][r], &p.ys[pcnn_spec::sp_item((int64_t)trow * p.gout + go, p.rows) + row * RS + c]);            // rows >= ntile: padding of the buffer (pad32)
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int trow = mt * 32 + acc_row(r, half);
+      float* o = &p.ys[pcnn_spec::sp_item((int64_t)trow * p.gout + go, p.rows) + c];              // rows >= ntile: padding of the buffer (pad32)
+      NT_STORE(4, acc[0][r] + acc[2][r], o + rr * RS);
+      NT_STORE(4, fmaf(s_cplx, acc[0][r], acc[1][r]), o + ri * RS);
     }
   };
   // first M-tile outside the loop: every pass inside it then starts from the same memory-counter state (operand loads, then the previous
@@ -814,8 +817,9 @@ int wgrad_splits(int Tg = 32) {
 }
 
 // workspace header: the constant tables of both tile sizes; the per-call regions follow
+// (two slot tables per tile size: the canonical row order of the matrix-core transform family, and the FFT family's interleaved order - spectral_common.h)
 constexpr size_t O_TAB32 = 0, O_SLOTS32 = O_TAB32 + ((TAB_FLOATS * 4 + 255) & ~255), O_TAB64 = O_SLOTS32 + NSLOT * 16,
-                 O_SLOTS64 = O_TAB64 + TAB64_FLOATS * 4, O_REST = O_SLOTS64 + 2048 * 16;
+                 O_SLOTS64 = O_TAB64 + TAB64_FLOATS * 4, O_SLOTS32F = O_SLOTS64 + 2048 * 16, O_SLOTS64F = O_SLOTS32F + NSLOT * 16, O_REST = O_SLOTS64F + 2048 * 16;
 static_assert(O_REST % 256 == 0, "workspace header alignment");
 
 // grows the handle's workspace (never beyond the caller's limit, pcnn_set_workspace_limit); the tables are (re)uploaded after every growth
@@ -829,17 +833,22 @@ int ensure_workspace(pcnn_handle h, size_t bytes_after_tables, char** rest) {
     if (h->spec_ws_limit && cap > h->spec_ws_limit) cap = h->spec_ws_limit;
     if (hipMalloc(&h->spec_ws, cap) != hipSuccess) PCNN_FAIL(h, "spectral convolution: cannot allocate %zu B of workspace", cap);
     h->spec_ws_bytes = cap;
-    static std::vector<float> tab, tab64; static std::vector<int> slots, slots64;   // static: the async copies below read them after this call returns
+    static std::vector<float> tab, tab64; static std::vector<int> slots, slots64, slots32f, slots64f;   // static: the async copies below read them after this call returns
     if (tab.empty()) {
       build_tables(tab, slots);
       tab64.resize(TAB64_FLOATS); slots64.resize(2048 * 4);
       build_tables64(tab64.data(), slots64.data());
+      slots32f.resize(NSLOT * 4); slots64f.resize(2048 * 4);
+      pcnn_spec::sp_build_slots(32, PCNN_SP_P, slots32f.data());
+      pcnn_spec::sp_build_slots(64, PCNN_SP_P, slots64f.data());
     }
     char* b = static_cast<char*>(h->spec_ws);
     if (hipMemcpyAsync(b + O_TAB32, tab.data(), TAB_FLOATS * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
         hipMemcpyAsync(b + O_SLOTS32, slots.data(), NSLOT * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
         hipMemcpyAsync(b + O_TAB64, tab64.data(), TAB64_FLOATS * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipMemcpyAsync(b + O_SLOTS64, slots64.data(), 2048 * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+        hipMemcpyAsync(b + O_SLOTS64, slots64.data(), 2048 * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(b + O_SLOTS32F, slots32f.data(), NSLOT * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(b + O_SLOTS64F, slots64f.data(), 2048 * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess)
       PCNN_FAIL(h, "spectral convolution: table upload failed");
   }
   *rest = static_cast<char*>(h->spec_ws) + O_REST;
@@ -855,8 +864,9 @@ int fit_chunk(pcnn_handle h, int chunk, F bytes_for) {
 
 Geom geom_of(pcnn_handle h, int Tg) {
   char* b = static_cast<char*>(h->spec_ws);
-  if (Tg == 64) return Geom{64, 4096, 2048, reinterpret_cast<const float*>(b + O_TAB64), reinterpret_cast<const int4*>(b + O_SLOTS64)};
-  return Geom{32, ROWS, NSLOT, reinterpret_cast<const float*>(b + O_TAB32), reinterpret_cast<const int4*>(b + O_SLOTS32)};
+  const bool fft = h->spectral_xform == PCNN_XFORM_FFT;                 // the row order belongs to the transform family (spectral_common.h)
+  if (Tg == 64) return Geom{64, 4096, 2048, reinterpret_cast<const float*>(b + O_TAB64), reinterpret_cast<const int4*>(b + (fft ? O_SLOTS64F : O_SLOTS64))};
+  return Geom{32, ROWS, NSLOT, reinterpret_cast<const float*>(b + O_TAB32), reinterpret_cast<const int4*>(b + (fft ? O_SLOTS32F : O_SLOTS32))};
 }
 
 template <typename K>
@@ -905,8 +915,6 @@ void launch_inv(pcnn_handle h, const Geom& gm, InvParams p, int ntile) {
 
 void launch_mix(pcnn_handle h, const Geom& gm, MixParams mx, int gin, int gout, int nt) {
   mx.slots = gm.slots; mx.rows = gm.rows; mx.ntile = nt;
-  static const int study = getenv("PCNN_FFT_STUDY") ? atoi(getenv("PCNN_FFT_STUDY")) : 0;
-  mx.study = study;
   const int nMt = pcnn_cdiv(nt, 32);
   const int gy = std::max(1, std::min(pcnn_cdiv(nMt, 4), 3));
   if (gin == 1) hipLaunchKernelGGL(spec_mix_kernel<1>, dim3(gm.nslot, gy, gout), dim3(256), 0, h->stream, mx);
@@ -938,6 +946,11 @@ int pick_tile(pcnn_handle h, const pcnn_conv_desc* d) {
   // matrix-core transforms.  With the FFT transforms (round 5) the 32-point kernels gained more than the 64-point ones: 11 taps 2.16 vs 2.19 ms forward,
   // 3.44 vs 3.47 fused backward at 8 x 1024^2 (profiles/r05_probe_xform32.txt / _xform64.txt) - 32-point tiles; 13 / 15 taps stay at 64 (2.70 -> 2.45, 3.22 -> 2.72).
   if (d->kh >= 11 && d->kw >= 11 && d->kh < 13 && d->kw < 13) return (h->spectral_xform != PCNN_XFORM_FFT && tiles >= 256) ? 64 : 32;
+  // 14 / 15 taps: 64-point tiles from 9 tiles per image on (round 6, tools/probe_tile_shipped.py at the shipped training shapes - batch 50, grids of 192..384 points,
+  // profiles/r06_probe_tile_shipped.txt: 15 taps 32->32 forward 0.92 / 0.70 ms at 192^2 ... 2.96 / 2.32 at 384^2, fused backward 1.31 / 1.10 ... 4.92 / 3.67 -
+  // with 32-point tiles a 15-tap layer moves 3.2 spectrum values per output pixel, with 64-point tiles 1.6, and that outweighs the ragged last tile row of a small
+  // image); 13 taps break even below ~300 points per side and keep the 36-tile rule.
+  if (d->kh >= 14 && d->kw >= 14 && tiles >= 9) return 64;
   return (d->kh >= 13 && d->kw >= 13 && tiles >= 36) ? 64 : 32;
 }
 
@@ -1256,6 +1269,20 @@ int pcnn_spectral_conv_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float
 // SYMMETRIC / REFLECT layers, the gradient on the padded domain).
 // Diagnostic (tests, tools): the spectrum rows of ONE 64 x 64 window at the image origin, item layout of spectral_common.h (4096 rows x 32 floats per
 // channel group), as the forward transform writes them - tests/test_gpu_spectral64.py compares the kernel forms (PCNN_FWD64_RADIX = 2 | 4) row by row.
+// the debug exports hand the spectrum out in CANONICAL row order whatever the transform family wrote (spectral_common.h): out[item][r][c] = sp[item][row(r)][c]
+__global__ __launch_bounds__(256) void spec_canonical_rows_kernel(const float* __restrict__ sp, float* __restrict__ out, int T, int rows, int P) {
+  const int item = blockIdx.y;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < rows * 32; e += gridDim.x * 256) {
+    const int r = e >> 5, c = e & 31;
+    out[(size_t)item * rows * 32 + e] = sp[pcnn_spec::sp_item(item, rows) + pcnn_spec::sp_row_from_canonical(T, r, P) * RS + c];
+  }
+}
+static int canonical_copy(pcnn_handle h, const float* sp, float* out, int T, int items) {
+  const int P = h->spectral_xform == PCNN_XFORM_FFT ? PCNN_SP_P : 64;
+  hipLaunchKernelGGL(spec_canonical_rows_kernel, dim3(16, items), dim3(256), 0, h->stream, sp, out, T, T * T, P);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 extern "C" int pcnn_debug_tile_spectrum64(pcnn_handle h, int H, int W, int C, const float* x, int ylim, int xlim, float* out) {
   PCNN_REQUIRE(h, h && x && out && H >= 1 && W >= 1 && C >= 1 && C <= 64, "pcnn_debug_tile_spectrum64: bad argument");
   const int groups = pcnn_cdiv(C, 32);
@@ -1269,9 +1296,7 @@ extern "C" int pcnn_debug_tile_spectrum64(pcnn_handle h, int H, int W, int C, co
   f.ylim = ylim; f.xlim = xlim; f.ext_y = 1 << 30; f.ext_x = 1 << 30; f.pack = 1; f.cpt = 32; f.tgx = 1;
   launch_fwd(h, gm, f, 1);
   PCNN_CHECK_LAUNCH(h, "pcnn_debug_tile_spectrum64");
-  for (int g = 0; g < groups; ++g)
-    if (hipMemcpyAsync(out + (size_t)g * 4096 * 32, f.sp + pcnn_spec::sp_item(g, 4096), 4096 * 32 * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
-      PCNN_FAIL(h, "pcnn_debug_tile_spectrum64: copy failed");
+  if (canonical_copy(h, f.sp, out, 64, groups)) PCNN_FAIL(h, "pcnn_debug_tile_spectrum64: copy failed");
   return 0;
 }
 
@@ -1298,9 +1323,7 @@ extern "C" int pcnn_debug_forward_spectrum32(pcnn_handle h, int H, int W, int C,
   if (pack > 1) { f.cstride = f.cpt; f.cvalid = f.cpt; }
   launch_fwd(h, gm, f, ntile);
   PCNN_CHECK_LAUNCH(h, "pcnn_debug_forward_spectrum32");
-  for (int i = 0; i < ntile * groups; ++i)
-    if (hipMemcpyAsync(out + (size_t)i * 1024 * 32, f.sp + pcnn_spec::sp_item(i, 1024), 1024 * 32 * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
-      PCNN_FAIL(h, "pcnn_debug_forward_spectrum32: copy failed");
+  if (canonical_copy(h, f.sp, out, 32, ntile * groups)) PCNN_FAIL(h, "pcnn_debug_forward_spectrum32: copy failed");
   return 0;
 }
 

@@ -181,7 +181,7 @@ __device__ __forceinline__ void fft32_fwd_body(const FwdParams& p, float* U, con
       // (stores: uniform base + 32-bit lane offset + immediate - no 64-bit address per 4 KB window in vector registers)
       const unsigned lo = (unsigned)((half ? 32 : 0) * RS + c);
 #pragma unroll
-      for (int s = 0; s < T; ++s) if (!FFT_STUDY(1)) NT_STORE(1, hc_get(V, s), &(out + (s * RS))[lo]);
+      for (int s = 0; s < T; ++s) if (!FFT_STUDY(1)) NT_STORE(1, hc_get(V, s), &(out + (sp_row_r(T, s) * RS))[lo]);
     } else {
       // complex column fx = wave; lane half = parity of the output frequencies: Z[2m + par] = FFT16( (u[y] +- u[y + 16]) W32^(par y) )[m]
       const float* ur = U + wave * 32 + c, *ui = U + (16 + wave) * 32 + c;
@@ -202,14 +202,15 @@ __device__ __forceinline__ void fft32_fwd_body(const FwdParams& p, float* U, con
         }
       }
       if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
-      // register q holds Z[2 bitrev(q) + par]: spectrum rows 64 + 64 (fx - 1) + fy (real part), + 32 (imaginary part)
+      // register q holds Z[2 bitrev(q) + par]: rows sp_row_c(fy = 2m + par, part) of the column's 64 (spectral_common.h; the odd frequency of a
+      // pair lies a constant number of rows behind the even one: the lane half's offset)
       float* o = out + (64 + 64 * (wave - 1)) * RS;                   // uniform
-      const unsigned lo = (unsigned)(half * RS + c);
+      const unsigned lo = (unsigned)(half * (sp_row_c(T, 1, 0) - sp_row_c(T, 0, 0)) * RS + c);
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         if (FFT_STUDY(1)) continue;
-        NT_STORE(1, vr[bitrev(m, 16)], &(o + ((2 * m) * RS))[lo]);
-        NT_STORE(1, vi[bitrev(m, 16)], &(o + ((32 + 2 * m) * RS))[lo]);
+        NT_STORE(1, vr[bitrev(m, 16)], &(o + (sp_row_c(T, 2 * m, 0) * RS))[lo]);
+        NT_STORE(1, vi[bitrev(m, 16)], &(o + (sp_row_c(T, 2 * m, 1) * RS))[lo]);
       }
     }
     if (next >= total) break;
@@ -319,10 +320,13 @@ __device__ __forceinline__ void epilogue_row(const InvParams& p, const float* X,
 // ONE code path for both (a uniform row step on the scalar ALU): the prefetch registers then have a single definition point in the item loop.
 __device__ __forceinline__ void inv_request(const float* in, int wave, int half, int c, float (&B)[32]) {
   const float* sp = in + (wave == 0 ? 0 : (64 + 64 * (wave - 1)) * RS);
-  const int step = wave == 0 ? RS : 2 * RS;
-  const unsigned lo = (unsigned)((wave == 0 ? 32 * RS : RS) * half + c);
+  const unsigned lo = (unsigned)((wave == 0 ? 32 : sp_row_c(T, 1, 0) - sp_row_c(T, 0, 0)) * RS * half + c);
 #pragma unroll
-  for (int j = 0; j < T; ++j) { B[j] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &sp[lo]); sp += step; }
+  for (int j = 0; j < T; ++j) {
+    // wave 0: half-complex entry j of the real column; wave fx: Re (j < 16) / Im of Z[2 (j & 15) + par] - a uniform (scalar) choice between two row constants
+    const int row = wave == 0 ? sp_row_r(T, j) : sp_row_c(T, 2 * (j & 15), j >> 4);
+    B[j] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(sp + row * RS)[lo]);
+  }
 }
 
 // Prefetch of the next item's spectrum column (32 registers that stay live through the x axis and the epilogue): with it the epilogue variants spill
@@ -669,11 +673,11 @@ __device__ __forceinline__ void fft64_fwd_body(const FwdParams& p, const int nvi
       if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
       if (store) {
         float* o = out + (128 + 128 * (2 * q)) * RS;
-        const unsigned lo = (unsigned)(cl * RS + c16);
+        const unsigned lo = (unsigned)(sp_row_c(64, cl, 0) * RS + c16);     // row(4 m + cl) = row(4 m) + row(cl) for every block size (spectral_common.h)
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-          NT_STORE(1, vr[bitrev(m, 16)], &(o + ((4 * m) * RS))[lo]);
-          NT_STORE(1, vi[bitrev(m, 16)], &(o + ((64 + 4 * m) * RS))[lo]);
+          NT_STORE(1, vr[bitrev(m, 16)], &(o + (sp_row_c(64, 4 * m, 0) * RS))[lo]);
+          NT_STORE(1, vi[bitrev(m, 16)], &(o + (sp_row_c(64, 4 * m, 1) * RS))[lo]);
         }
       }
     }
@@ -708,11 +712,11 @@ __device__ __forceinline__ void fft64_fwd_body(const FwdParams& p, const int nvi
         if (!FFT_STUDY(4)) cfft_dif<16, -1>(vr, vi);
         if (store) {
           float* o = out + (128 + 128 * (2 * (q + 1) - 1)) * RS;
-          const unsigned lo = (unsigned)(cl * RS + c16);
+          const unsigned lo = (unsigned)(sp_row_c(64, cl, 0) * RS + c16);     // row(4 m + cl) = row(4 m) + row(cl) for every block size (spectral_common.h)
 #pragma unroll
           for (int m = 0; m < 16; ++m) {
-            NT_STORE(1, vr[bitrev(m, 16)], &(o + ((4 * m) * RS))[lo]);
-            NT_STORE(1, vi[bitrev(m, 16)], &(o + ((64 + 4 * m) * RS))[lo]);
+            NT_STORE(1, vr[bitrev(m, 16)], &(o + (sp_row_c(64, 4 * m, 0) * RS))[lo]);
+            NT_STORE(1, vi[bitrev(m, 16)], &(o + (sp_row_c(64, 4 * m, 1) * RS))[lo]);
           }
         }
       } else {
@@ -728,9 +732,9 @@ __device__ __forceinline__ void fft64_fwd_body(const FwdParams& p, const int nvi
           if (!FFT_STUDY(4)) rfft_fwd<32>(V);
           if (store) {
 #pragma unroll
-            for (int k = 0; k <= 16; ++k) NT_STORE(1, hc_get(V, k), &(o + ((2 * k) * RS))[lo]);                 // Re Z[2k] -> row 2k
+            for (int k = 0; k <= 16; ++k) NT_STORE(1, hc_get(V, k), &(o + (sp_row_r(64, 2 * k) * RS))[lo]);                 // Re Z[2k]: half-complex entry 2k of the column
 #pragma unroll
-            for (int k = 1; k < 16; ++k) NT_STORE(1, hc_get(V, 16 + k), &(o + ((32 + 2 * k) * RS))[lo]);        // Im Z[2k] -> row 32 + 2k
+            for (int k = 1; k < 16; ++k) NT_STORE(1, hc_get(V, 16 + k), &(o + (sp_row_r(64, 32 + 2 * k) * RS))[lo]);        // Im Z[2k]: entry 32 + 2k
           }
         } else {
           // d[n] = u[n] - u[n + 32]; c[n] = (d[n] - i d[n + 16]) W64^n, n < 16; C[m] = Z[4m + 1]; Z[4m + 3] = conj C[15 - m]
@@ -743,10 +747,10 @@ __device__ __forceinline__ void fft64_fwd_body(const FwdParams& p, const int nvi
           if (store) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-              NT_STORE(1, vr[bitrev(m, 16)], &(o + ((4 * m + 1) * RS))[lo]);
-              NT_STORE(1, vi[bitrev(m, 16)], &(o + ((32 + 4 * m + 1) * RS))[lo]);
-              NT_STORE(1, vr[bitrev(15 - m, 16)], &(o + ((4 * m + 3) * RS))[lo]);
-              NT_STORE(1, -vi[bitrev(15 - m, 16)], &(o + ((32 + 4 * m + 3) * RS))[lo]);
+              NT_STORE(1, vr[bitrev(m, 16)], &(o + (sp_row_r(64, 4 * m + 1) * RS))[lo]);
+              NT_STORE(1, vi[bitrev(m, 16)], &(o + (sp_row_r(64, 32 + 4 * m + 1) * RS))[lo]);
+              NT_STORE(1, vr[bitrev(15 - m, 16)], &(o + (sp_row_r(64, 4 * m + 3) * RS))[lo]);
+              NT_STORE(1, -vi[bitrev(15 - m, 16)], &(o + (sp_row_r(64, 32 + 4 * m + 3) * RS))[lo]);
             }
           }
         }
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
             const int fy = 4 * m + cl, fp = fy <= 32 ? fy : 64 - fy;
             const float sg = fy <= 32 ? 1.f : -1.f;
             const bool hasim = fp != 0 && fp != 32;
-            const unsigned rr = (unsigned)(fp * RS), ri = (unsigned)((32 + (hasim ? fp : 1)) * RS);
+            const unsigned rr = (unsigned)(sp_row_r(64, fp) * RS), ri = (unsigned)(sp_row_r(64, 32 + (hasim ? fp : 1)) * RS);     // (per-lane: fp depends on the class)
             const float ar = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &in[lo + rr]), br = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + 64 * RS)[lo + rr]);
             float ai = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &in[lo + ri]), bi = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(in + 64 * RS)[lo + ri]);
             ai = hasim ? sg * ai : 0.f; bi = hasim ? sg * bi : 0.f;
@@ -841,11 +845,11 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
             sre = (q & 1) ? 15 - (q >> 1) : (q >> 1);
           } else { fx = 2 * (q + 1); sre = q + 1; }
           const float* src = in + (128 + 128 * (fx - 1)) * RS;       // uniform
-          const unsigned lo = (unsigned)(cl * RS + c16);
+          const unsigned lo = (unsigned)(sp_row_c(64, cl, 0) * RS + c16);
 #pragma unroll
           for (int m = 0; m < 16; ++m) {
-            vr[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(src + (4 * m) * RS)[lo]);
-            vi[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(src + (64 + 4 * m) * RS)[lo]);
+            vr[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(src + sp_row_c(64, 4 * m, 0) * RS)[lo]);
+            vi[m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(src + sp_row_c(64, 4 * m, 1) * RS)[lo]);
           }
         }
         if (!FFT_STUDY(4)) cfft_dif<16, +1>(vr, vi);                                      // register j: y = bitrev(j)

@@ -18,7 +18,8 @@ for _ in range(3):
     ops.conv2d_fwd(x, w, None, pad_top=k // 2, pad_left=k // 2, out=y)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(10):
+ITERS = int(os.environ.get("STUDY_ITERS", "10"))
+for _ in range(ITERS):
     ops.conv2d_fwd(x, w, None, pad_top=k // 2, pad_left=k // 2, out=y)
 torch.cuda.synchronize()
-print('study bits %s: k %d tile %d forward %.3f ms' % (os.environ.get('PCNN_FFT_STUDY', '0'), k, tile, (time.perf_counter() - t0) * 100))
+print('study bits %s: k %d tile %d forward %.3f ms' % (os.environ.get('PCNN_FFT_STUDY', '0'), k, tile, (time.perf_counter() - t0) * 1e3 / ITERS))
