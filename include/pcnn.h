@@ -109,7 +109,8 @@ int pcnn_get_spectral_transform(pcnn_handle h);
  * again before passing filters whose contents the version does not describe (poisson_cnn_amd.ops does that for every call without `w_version`).
  * Contract: a cached filter pointer must stay readable until pcnn_filter_cache_clear / pcnn_destroy (the refresh reads every known filter); memory:
  * Cin x ceil(Cout/32) x T^2 x 128 B per filter (4 MB at 32 -> 32 channels and 32-point tiles, 16 MB at 64-point tiles), pcnn_filter_cache_stats.
- * Under stream capture nothing is allocated: a filter first seen there is transformed into the workspace as with version 0. */
+ * Under stream capture nothing is allocated: a filter first seen there is transformed into the workspace as with version 0.
+ * pcnn_filter_cache_stats: entries / bytes describe what the handle holds now; hits / fills / refreshes are cumulative over the handle's life (a clear does not reset them). */
 int pcnn_set_filter_version(pcnn_handle h, uint64_t version);
 int pcnn_filter_cache_clear(pcnn_handle h);
 int pcnn_filter_cache_stats(pcnn_handle h, long long* entries, long long* bytes, long long* hits, long long* fills, long long* refreshes);

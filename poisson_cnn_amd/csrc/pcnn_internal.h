@@ -27,6 +27,7 @@ struct pcnn_handle_s {
   std::vector<void*> retired;     // ... here, until pcnn_destroy
   unsigned long long filter_version = 0;   // pcnn_set_filter_version: 0 = filter spectra are recomputed by every call; else the caller's weights version
   void* filter_cache = nullptr;   // ... and the spectra kept per (filter pointer, shape, tile size), spectral_conv.hip
+  long long fc_hits = 0, fc_fills = 0, fc_refreshes = 0;   // cumulative over the handle's life (pcnn_filter_cache_clear empties the cache, not these)
   void* comm = nullptr;           // RCCL communicator (ncclComm_t) of pcnn_comm_init, see collective.hip
   int comm_rank = 0, comm_size = 0;
 };

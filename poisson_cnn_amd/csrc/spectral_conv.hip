@@ -1065,7 +1065,6 @@ struct FilterCache {
   std::vector<FwdParams> host[2];                                   // [0]: 32-point entries, [1]: 64-point entries (FFT family), in the order of the device table
   FwdParams* dev[2] = {nullptr, nullptr};
   size_t cap[2] = {0, 0};
-  long long hits = 0, fills = 0, refreshes = 0;
   size_t bytes = 0;
 };
 FilterCache* cache_of(pcnn_handle h) {
@@ -1089,7 +1088,7 @@ void refresh_filters(pcnn_handle h, FilterCache* fc) {
     }
     en.version = h->filter_version;
   }
-  ++fc->refreshes;
+  ++h->fc_refreshes;
 }
 // the spectrum of filter `w` ((kh, kw, Cin, Cout), output channel groups gout) for this call: a cached buffer, or `ws_slot` freshly filled
 const float* filter_spectrum(pcnn_handle h, const Geom& gm, const float* w, float* ws_slot, int kh, int kw, int Cin, int Cout, int gout) {
@@ -1098,7 +1097,7 @@ const float* filter_spectrum(pcnn_handle h, const Geom& gm, const float* w, floa
   FilterCache* fc = cache_of(h);
   for (FilterEntry& en : fc->e)
     if (en.w == w && en.kh == kh && en.kw == kw && en.Cin == Cin && en.Cout == Cout && en.gout == gout && en.T == gm.T && en.xform == h->spectral_xform) {
-      if (en.version != h->filter_version) refresh_filters(h, fc); else ++fc->hits;
+      if (en.version != h->filter_version) refresh_filters(h, fc); else ++h->fc_hits;
       return en.buf;
     }
   // first sight of this filter: a buffer of its own - unless the stream is being captured (no allocation, no upload inside a capture)
@@ -1128,7 +1127,7 @@ const float* filter_spectrum(pcnn_handle h, const Geom& gm, const float* w, floa
   launch_fwd(h, gm, en.fp, 1);
   fc->e.push_back(en);
   fc->bytes += bytes;
-  ++fc->fills;
+  ++h->fc_fills;
   return en.buf;
 }
 }  // namespace
@@ -1159,9 +1158,9 @@ extern "C" int pcnn_filter_cache_stats(pcnn_handle h, long long* entries, long l
   const FilterCache* fc = static_cast<const FilterCache*>(h->filter_cache);
   if (entries) *entries = fc ? (long long)fc->e.size() : 0;
   if (bytes) *bytes = fc ? (long long)fc->bytes : 0;
-  if (hits) *hits = fc ? fc->hits : 0;
-  if (fills) *fills = fc ? fc->fills : 0;
-  if (refreshes) *refreshes = fc ? fc->refreshes : 0;
+  if (hits) *hits = h->fc_hits;
+  if (fills) *fills = h->fc_fills;
+  if (refreshes) *refreshes = h->fc_refreshes;
   return 0;
 }
 

@@ -120,16 +120,18 @@ def _train(cache, steps=3):
 
 
 def test_training_steps_are_bit_identical_with_and_without_the_cache():
-    import gc
     from poisson_cnn_amd import ops
-    gc.collect()                        # the counters are sums over the LIVE handles: a captured graph of an earlier test that is finalised in the middle of
-    s0 = ops.filter_cache_stats()       # this one releases its stream's handle and takes that handle's counts with it (seen once in a combined run)
+    # the counters live in a handle's cache object: a parameter bucket of an EARLIER test that has died makes every handle empty its cache - counters
+    # included - at its next cached call (ops.weights_released), so a first run (kept alive) flushes whatever is pending before the counted one
+    keep = _train(True)
+    s0 = ops.filter_cache_stats()
     l1, w1, y1, m1 = _train(True)
     s1 = ops.filter_cache_stats()
     assert s1['fills'] > s0['fills'] and s1['refreshes'] > s0['refreshes'] and s1['hits'] > s0['hits']
     l0, w0, y0, m0 = _train(False)
     assert l1 == l0 and torch.equal(w1, w0) and torch.equal(y1, y0)
     assert ops.filter_cache_stats()['fills'] == s1['fills']              # cache off: nothing was added
+    assert keep[0] == l1 and torch.equal(keep[1], w1)                    # (and the warm-up run was the same training run)
 
 
 def test_torch_side_weight_edits_and_a_dying_model_are_noticed():
