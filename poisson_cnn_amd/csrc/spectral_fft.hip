@@ -321,11 +321,25 @@ __device__ __forceinline__ void epilogue_row(const InvParams& p, const float* X,
 __device__ __forceinline__ void inv_request(const float* in, int wave, int half, int c, float (&B)[32]) {
   const float* sp = in + (wave == 0 ? 0 : (64 + 64 * (wave - 1)) * RS);
   const unsigned lo = (unsigned)((wave == 0 ? 32 : sp_row_c(T, 1, 0) - sp_row_c(T, 0, 0)) * RS * half + c);
+  if constexpr (PCNN_SP_P == 1) {
+    // Re | Im adjacent: entry j = (m = j & 15, part = j >> 4) sits at row 2 m + part of a real column and at row 4 m + part (+ 2 par: the lane offset) of
+    // a complex one - ONE code path with a uniform row step on the scalar ALU, as with the canonical order (a per-entry select between two row constants
+    // costs a scalar select per load: the inverse kernels ran 4-9 % slower with it)
+    static_assert(sp_row_r(T, 17, 1) == 3 && sp_row_r(T, 16, 1) == 1 && sp_row_c(T, 6, 1, 1) == 13, "row order the stepping form assumes");
+    const int step = (wave == 0 ? 2 : 4) * RS;
 #pragma unroll
-  for (int j = 0; j < T; ++j) {
-    // wave 0: half-complex entry j of the real column; wave fx: Re (j < 16) / Im of Z[2 (j & 15) + par] - a uniform (scalar) choice between two row constants
-    const int row = wave == 0 ? sp_row_r(T, j) : sp_row_c(T, 2 * (j & 15), j >> 4);
-    B[j] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(sp + row * RS)[lo]);
+    for (int part = 0; part < 2; ++part) {
+      const float* q = sp + part * RS;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) { B[16 * part + m] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &q[lo]); q += step; }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      // wave 0: half-complex entry j of the real column; wave fx: Re (j < 16) / Im of Z[2 (j & 15) + par] - a uniform (scalar) choice between two row constants
+      const int row = wave == 0 ? sp_row_r(T, j) : sp_row_c(T, 2 * (j & 15), j >> 4);
+      B[j] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(sp + row * RS)[lo]);
+    }
   }
 }
 
