@@ -510,9 +510,14 @@ __global__ __launch_bounds__(256, 2) void spec_mix_kernel(MixParams p) {
 // ------------------------------------------------------------------------------------------------------------------ weight gradient
 struct WMixParams { const float* xs; const float* ds; float* part; const int4* slots; int ntile, gin, S, accumulate, rows, nslot; };
 
-// P[slot][gi][quadrant][ci][co] = sum over tiles of [Xr | Xi]^T [Dr | Di]: quadrant 0 = Xr^T Dr, 1 = Xi^T Dr, 2 = Xr^T Di, 3 = Xi^T Di.
-// One wave owns all four quadrants (each operand row is loaded once per tile pair: 4 loads feed 4 MFMAs) for its share of the tiles:
-// K is split over gridDim.y workgroups x 4 waves; the partial sums are combined in a fixed order by spec_wcombine_kernel.
+// The weight-gradient spectrum C^[f] = sum over tiles of conj(X^) D^ (or its conjugate), per frequency a complex product summed over the tiles -
+// as THREE real products (Gauss; round 6, like the mixing kernels) instead of the four quadrants of [Xr | Xi]^T [Dr | Di]:
+//   Q1 = (Xr - Xi)^T Dr,  Q2 = Xr^T (Di - Dr),  Q3 = Xi^T (Dr + Di);   Re = Q1 + Q3 = Xr^T Dr + Xi^T Di,  Im = Q1 + Q2 = Xr^T Di - Xi^T Dr
+// P[slot][gi][quadrant q = 0..2][ci][co] holds Q1, Q2, Q3 (the stride stays four quadrants).  A slot that packs two REAL frequencies (sl.z == 1) wants
+// Xr^T Dr and Xi^T Di: the same three products with a factor s = 0 in place of 1 in front of Xi (Q1) and Dr (Q3).  The sums and differences are formed
+// in fp32 on the operands: the result differs from the four-quadrant form by rounding only (wgrad tests at unchanged tolerances).
+// One wave owns all three quadrants (each operand row is loaded once per tile pair) for its share of the tiles: K is split over gridDim.y workgroups x 4
+// waves; the partial sums are combined in a fixed order by spec_wcombine_kernel.
 __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -523,7 +528,10 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
   const int t0 = part * per, t1 = min(t0 + per, p.ntile);
   const float* xr = p.xs + sl.x * RS, *xi = p.xs + sl.y * RS;
   const float* dr = p.ds + sl.x * RS, *di = p.ds + sl.y * RS;
-  f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+  int kind = sl.z;
+  asm volatile("" : "+v"(kind));                               // per-lane on purpose (a uniform selector becomes scalar branches around the MFMA loop)
+  const float s_cplx = kind == 1 ? 0.f : 1.f;
+  f32x16 acc[3] = {zero16(), zero16(), zero16()};
   // operands of 2 WU tiles per step, requested one step ahead (two register sets): the loads of step i + 1 fly under the 4 WU MFMAs of step i
   constexpr int WU = 4;
   float ar[WU], ai[WU], br[WU], bi[WU], nar[WU], nai[WU], nbr[WU], nbi[WU];
@@ -543,17 +551,16 @@ __global__ __launch_bounds__(256, 2) void spec_wmix_kernel(WMixParams p) {
     for (int u = 0; u < WU; ++u) {
       const bool ok = tb + 2 * u + half < t1;
       const float a0 = ok ? ar[u] : 0.f, a1 = ok ? ai[u] : 0.f;
-      acc[0] = mfma(a0, br[u], acc[0]);
-      acc[1] = mfma(a1, br[u], acc[1]);
-      acc[2] = mfma(a0, bi[u], acc[2]);
-      acc[3] = mfma(a1, bi[u], acc[3]);
+      acc[0] = mfma(fmaf(-s_cplx, a1, a0), br[u], acc[0]);
+      acc[1] = mfma(a0, bi[u] - br[u], acc[1]);
+      acc[2] = mfma(a1, fmaf(s_cplx, br[u], bi[u]), acc[2]);
     }
 #pragma unroll
     for (int u = 0; u < WU; ++u) { ar[u] = nar[u]; ai[u] = nai[u]; br[u] = nbr[u]; bi[u] = nbi[u]; }
   }
   float* o = p.part + (((int64_t)part * p.nslot + slot) * p.gin + gi) * 4 * 1024 + c;
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
+  for (int qd = 0; qd < 3; ++qd) {
     float old[16];                                                   // accumulate: the quadrant's old values as one burst (a load between two
     if (p.accumulate) {                                              // stores is waited for with vmcnt(0): 64 exposed latencies per workgroup)
 #pragma unroll
@@ -585,6 +592,9 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
   float hr[16], hi[16];
   const bool real2 = sl.z == 1;
   const float s_neg = real2 ? 0.f : -1.f, s_pos = real2 ? 0.f : 1.f;
+  int kind = sl.z;
+  asm volatile("" : "+v"(kind));                               // per-lane copy for the weight-gradient products (selects, not branches)
+  const float s_cplx = kind == 1 ? 0.f : 1.f;
   {
     const int co = c % p.cpt;
 #pragma unroll
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
     w[0] = NT_LOAD(16, reinterpret_cast<const f32x4*>(&xr[ix])); w[1] = NT_LOAD(16, reinterpret_cast<const f32x4*>(&xi[ix]));
     w[2] = *reinterpret_cast<const f32x4*>(&dr[id]); w[3] = *reinterpret_cast<const f32x4*>(&di[id]);
   };
-  f32x16 accp[4] = {zero16(), zero16(), zero16(), zero16()};
+  f32x16 accp[3] = {zero16(), zero16(), zero16()};                 // Q1, Q2, Q3 of spec_wmix_kernel (three real products per tile pair)
   auto mfma_w = [&](int mt, int b, f32x4 (&w)[4]) {
     float t[4][4];
 #pragma unroll
@@ -627,14 +637,9 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
     for (int j = 0; j < 4; ++j) {
       const bool ok = mt * 32 + 8 * b + 2 * j + half < p.ntile;
       const float a0 = ok ? t[0][j] : 0.f, a1 = ok ? t[1][j] : 0.f;
-      accp[0] = mfma(a0, t[2][j], accp[0]);
-      accp[1] = mfma(a1, t[2][j], accp[1]);
-      accp[2] = mfma(a0, t[3][j], accp[2]);
-#if defined(PCNN_MIX_KEEP) && PCNN_MIX_KEEP < 4
-      accp[3][j] += a1 * t[3][j];
-#else
-      accp[3] = mfma(a1, t[3][j], accp[3]);
-#endif
+      accp[0] = mfma(fmaf(-s_cplx, a1, a0), t[2][j], accp[0]);
+      accp[1] = mfma(a0, t[3][j] - t[2][j], accp[1]);
+      accp[2] = mfma(a1, fmaf(s_cplx, t[2][j], t[3][j]), accp[2]);
     }
   };
   // One M-tile = 8 phases of 16 MFMAs, weight-gradient batches and mixing quarters interleaved (W0 M0 W1 M1 W2 M2 W3 M3) so that every operand
@@ -663,9 +668,6 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
       for (int e = 0; e < 8; ++e) {
         const int j = 8 * (qu & 1) + e;
         const float av = aq[qu & 1][e >> 2][e & 3];
-#ifdef PCNN_MIX_KEEP
-        if ((e & 3) >= PCNN_MIX_KEEP) { acc[0][e] += av * hr[j]; acc[1][e] += av * hi[j]; continue; }
-#endif
         if (qu < 2) {
           acc[0] = mfma(av, hr[j], acc[0]);
           acc[1] = mfma(av * s_neg, hi[j], acc[1]);
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
   }
   float* o = p.part + (((int64_t)part * p.nslot + slot) * p.gx + g) * 4 * 1024 + c;
 #pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
+  for (int qd = 0; qd < 3; ++qd) {
     float old[16];
     if (p.accumulate) {
 #pragma unroll
@@ -715,7 +717,8 @@ __global__ __launch_bounds__(256, 2) void spec_mixw_kernel(MixWParams p) {
   }
 }
 
-// C^[f] = X^ conj(D^): Cr = P11 + P22, Ci = P21 - P12 (quadrant index = mq + 2 nq); packed real slots: C(row rr) = P11, C(row ri) = P22.
+// C^[f] = X^ conj(D^) from the three Gauss sums of spec_wmix_kernel / spec_mixw_kernel: Cr = Q1 + Q3, Ci = -(Q1 + Q2) (isign = -1: its conjugate);
+// packed real slots: C(row rr) = Q1 = Xr^T Dr, C(row ri) = Q3 = Xi^T Di.
 // Output: spectrum of a one-tile image with Cin*Cout channels, group = ci, lane = co.
 // cpt < 32 (tile packing): the wanted products are the 32 / cpt diagonal blocks (tile with itself); they are summed here.
 // One workgroup per (slot, channel group): no run-time divisions, every partial-sum read a whole 128-byte row.
@@ -726,15 +729,15 @@ __global__ __launch_bounds__(256) void spec_wcombine_kernel(const float* __restr
   for (int e = threadIdx.x; e < 1024; e += 256) {
     const int cil = e >> 5, co = e & 31, ci = gi * 32 + cil;
     if (ci >= Cin || cil >= cpt || co >= cpt) continue;
-    float P[4] = {0.f, 0.f, 0.f, 0.f};
+    float P[3] = {0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s)
       for (int sub = 0; sub < 32 / cpt; ++sub) {
         const float* b = part + (((int64_t)s * nslot + slot) * gin + gi) * 4 * 1024 + (sub * cpt + cil) * 32 + sub * cpt + co;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) P[qd] += b[qd * 1024];
+        for (int qd = 0; qd < 3; ++qd) P[qd] += b[qd * 1024];
       }
-    // P[0] = Xr^T Dr, P[1] = Xi^T Dr, P[2] = Xr^T Di, P[3] = Xi^T Di
-    const float cr = sl.z == 1 ? P[0] : P[0] + P[3], cim = sl.z == 1 ? P[3] : isign * (P[1] - P[2]);     // isign = -1: conj(X^) D^ instead of X^ conj(D^)
+    // Q1 + Q3 = Xr^T Dr + Xi^T Di; Q1 + Q2 = Xr^T Di - Xi^T Dr
+    const float cr = sl.z == 1 ? P[0] : P[0] + P[2], cim = sl.z == 1 ? P[2] : -isign * (P[0] + P[1]);     // isign = -1: conj(X^) D^ instead of X^ conj(D^)
     csp[pcnn_spec::sp_item(ci, rows) + sl.x * RS + co] = cr;
     csp[pcnn_spec::sp_item(ci, rows) + sl.y * RS + co] = cim;
   }
