@@ -61,6 +61,7 @@ def parse_args(argv=None):
                          "(runs on CPU/gloo; exercises the N > 1 launch path without a GPU)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dataset', action='store_true')
+    ap.add_argument('--no-inference', action='store_true', help='skip the forward-only block (a few seconds)')
     ap.add_argument('--no-c3', action='store_true', help='skip the 32 x 512^2 block that the default c4 run appends')
     ap.add_argument('--modes', default='fp32', help='math modes to time, in order; the LAST one is the headline.  Default: fp32 only (the library default); '
                                                     '"split_f16,fp32" also times the opt-in split mode with its accuracy gate (a third more GPU time)')
@@ -269,7 +270,7 @@ def launch_check(args, dp):
                           'affinity': AFFINITY}), flush=True)
 
 
-PROFILE_ROUND = 'r05'
+PROFILE_ROUND = 'r06'
 COMPACT_LIMIT = 3072      # bytes: the driver keeps ~8.6 KB of stdout; round 3's 23 KB line arrived cut and unparseable
 
 
@@ -315,6 +316,10 @@ def compact_line(d):
     if c3:
         out['c3'] = {'value': _r(c3.get('value'), 3), 'unit': c3.get('unit'), 'ms_per_step': _r(c3.get('ms_per_step'), 3), 'roofline_frac': _r((c3.get('roofline') or {}).get('frac')), 'executed_frac': _r((c3.get('roofline') or {}).get('executed_frac')),
                      'hbm_bound_frac': _r(((c3.get('roofline') or {}).get('hbm_bound') or {}).get('frac'))}
+    inf = d.get('inference')
+    if inf:
+        out['inference'] = {'error': str(inf['error'])[:100]} if 'error' in inf else {'ms_per_batch': _r(inf.get('ms_per_batch'), 2), 'grids_per_s': _r(inf.get('grids_per_s'), 1),
+                                                                                     'hbm_bound_frac_inference': _r((inf.get('hbm_bound') or {}).get('frac'))}
     sp = d.get('split_f16')
     if sp:
         acc = sp.get('accuracy_vs_fp32') or {}
@@ -551,6 +556,45 @@ def run(args):
 
     per_gpu, H, gbs, blocks = bench_workload(args.workload, modes, args.steps, args.warmup, True)
     coll_ms = collective_ms()
+
+    def inference_block(workload, reps=5):
+        """Forward only (model([rhs, dx]), the reference's inference path) on the headline batch: ms per batch and the HBM-bound view of its narrow
+        convolution launches - algorithmic bytes of the UNFUSED layers over the launch time, the definition of roofline.hbm_bound."""
+        _, _, ((rhs, dx), _) = make_batch(workload)
+        ops.set_math_mode('fp32')
+        for _ in range(2):
+            model([rhs, dx])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model([rhs, dx])
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        prof = ops.KernelTimer()
+        ops.set_kernel_timer(prof)
+        try:
+            for _ in range(reps):
+                model([rhs, dx])
+            torch.cuda.synchronize()
+        finally:
+            ops.set_kernel_timer(None)
+        ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        hf, hb, hs, hc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage') and b > 0 and f / b < ridge)
+        af, ab, as_, ac = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage') and b > 0)
+        return {'what': 'inference forward of the same batch (no saved activations): ms per batch; hbm_bound = its convolution launches below the fp32 ridge '
+                        '(%.1f FLOP/B), algorithmic bytes of the unfused layers / HIP-event time' % ridge,
+                'ms_per_batch': ms, 'grids_per_s': per_gpu / (ms * 1e-3),
+                'hbm_bound': {'achieved': hb / hs / 1e9 if hs else None, 'frac': hb / hs / 1e9 / PEAK_HBM_GBS if hs else None, 'launches': hc // reps,
+                              'ms': 1e3 * hs / reps},
+                'all_conv_fwd': {'algorithmic_GBs': ab / as_ / 1e9 if as_ else None, 'frac': ab / as_ / 1e9 / PEAK_HBM_GBS if as_ else None, 'launches': ac // reps,
+                                 'ms': 1e3 * as_ / reps}}
+    inference = None
+    if dp.world_size == 1 and not args.no_inference:
+        note('inference block (forward only) ...')
+        try:
+            inference = inference_block(args.workload)
+        except Exception as e:   # noqa: BLE001 - a side measurement must not kill the headline
+            inference = {'error': repr(e)}
     # the other half of BASELINE.json's metric ("at 512^2 & 1024^2"): the default c4 run appends the 32 x 512^2 workload, fp32 mode, same timing rules
     c3 = None
     if args.workload == 'c4' and not args.no_c3 and modes[-1] == 'fp32' and (dp.world_size == 1 or args.c3):
@@ -577,6 +621,8 @@ def run(args):
     }
     for mode in modes[:-1]:
         out[mode] = blocks[mode]
+    if inference is not None:
+        out['inference'] = inference
     if c3 is not None:
         out['c3'] = c3
     if dp.world_size == 1 and not args.no_cpu_baseline:

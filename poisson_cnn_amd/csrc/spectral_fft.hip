@@ -350,6 +350,9 @@ __device__ __forceinline__ void inv_request(const float* in, int wave, int half,
 #endif
 constexpr bool INV32_PREFETCH = PCNN_INV32_PREFETCH;
 
+#ifndef PCNN_ST32_NT
+#define PCNN_ST32_NT 0
+#endif
 // TANH = false: linear / relu / leaky-relu as one select with the negative-side slope in p.alpha (1 / 0 / alpha)
 template <bool TANH, bool RES, bool POST>
 __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
         float* y2img = (POST && p.y2) ? p.y2 + ipix * p.ld_y2 : nullptr;
         const unsigned chv = (unsigned)chan;
         if (rowok && !FFT_STUDY(1))
-          epilogue_row<TANH, RES, POST, T, BURST, false>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
+          epilogue_row<TANH, RES, POST, T, BURST, PCNN_ST32_NT != 0>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
       }
     }
     if (next >= total) break;

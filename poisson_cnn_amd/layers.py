@@ -707,7 +707,7 @@ class Scaling:
                 if (np.diff(iy) <= 0).any() or (np.diff(ix) <= 0).any():
                     raise ValueError('grid too small for the Scaling layer: a %dx%d pyramid level over a %dx%d map has empty bins' % (ly, lx, H, W))
                 bins += [[iy[a], iy[a + 1], ix[b], ix[b + 1]] for a in range(ly) for b in range(lx)]
-            self._bins[key] = torch.tensor(np.array(bins, dtype=np.int32), device=device)
+            self._bins[key] = ops.upload(np.array(bins, dtype=np.int32), device)
         return self._bins[key]
 
     def forward(self, x_to_scale, other, training=True):

@@ -74,7 +74,7 @@ class integral_loss:
         key = (n, nq, str(device))
         v = self._maps.get(key)
         if v is None:
-            v = self._maps[key] = torch.from_numpy(self._axis_vector(n, nq)).to(device)      # float64, n values
+            v = self._maps[key] = ops.upload(self._axis_vector(n, nq), device)      # float64, n values
         return v
 
     def weight_map(self, H, W, device):

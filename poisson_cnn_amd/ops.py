@@ -689,6 +689,19 @@ def deconv_bwd_filter(x, dy, f, *, alpha=1.0, dk=None, dbias=None, ws=None, kern
     return dk
 
 
+def upload(a, device, dtype=None):
+    """numpy array -> device tensor through pinned staging and an asynchronous copy on the current stream.  torch.tensor(a, device=...) copies from
+    pageable memory and blocks the host until everything queued on the stream before it has run - once per small table of a NEW grid shape (resize
+    tables, pyramid bins, quadrature vectors: ~16 per shape), i.e. every step of the shipped training workload (profiles/r06_train_shipped.txt)."""
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 _table_cache = {}
 
 
@@ -702,7 +715,7 @@ def resize_tables(method, n_in, n_out, device):
                                            idx.ctypes.data_as(c_void_p), wt.ctypes.data_as(c_void_p))
         if rc != 0:
             raise RuntimeError('pcnn_resize_tables failed (%d)' % rc)
-        t = (torch.tensor(idx, device=device), torch.tensor(wt, device=device))
+        t = (upload(idx, device), upload(wt, device))
         _table_cache[key] = t
     return t
 

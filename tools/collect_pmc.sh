@@ -7,7 +7,7 @@
 # (+ <round>_<workload>_kernel_stats_<mode>.csv): copy them to profiles/.
 set -e -o pipefail
 ROOT=$(pwd)
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 WORKLOADS=${2:-c4}
 MODES=${3:-fp32}
 export TMPDIR=/tmp
@@ -16,7 +16,7 @@ for mode in $MODES; do
   st=$ROOT/gpurun_out/stats_${ROUND}_${wl}_${mode}
   rm -rf "$st"
   (cd /tmp && rocprofv3 --kernel-trace --stats -d "$st" --output-format csv -- python3 "$ROOT/bench.py" --workload $wl --math $mode --steps 3 --warmup 1 \
-      --no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0 > "$ROOT/gpurun_out/stats_${ROUND}_${wl}_${mode}.log" 2>&1)
+      --no-cpu-baseline --no-dataset --no-inference --no-c3 --overlap-wgrad 0 > "$ROOT/gpurun_out/stats_${ROUND}_${wl}_${mode}.log" 2>&1)
   cp "$st"/*/*_kernel_stats.csv "$ROOT/gpurun_out/${ROUND}_${wl}_kernel_stats_${mode}.csv"
   cp "$st"/*/*_kernel_trace.csv "$ROOT/gpurun_out/${ROUND}_${wl}_kernel_trace_${mode}.csv"
   echo "stats $wl $mode done"
@@ -25,7 +25,7 @@ for mode in $MODES; do
     rm -rf "$out"
     pmc=$ctr; if [ $ctr = MFMA ]; then pmc="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; fi
     (cd /tmp && rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out" -- python3 "$ROOT/bench.py" --workload $wl --math $mode --steps 1 --warmup 1 \
-        --no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0 > "$ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_${ctr}.log" 2>&1)
+        --no-cpu-baseline --no-dataset --no-inference --no-c3 --overlap-wgrad 0 > "$ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_${ctr}.log" 2>&1)
     echo "pass $wl $mode $ctr done"
   done
   f=$(ls $ROOT/gpurun_out/pmc_${ROUND}_${wl}_${mode}_FETCH_SIZE/*/*counter_collection.csv | head -1)

@@ -1,5 +1,5 @@
 """Builds profiles/<name>.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --math <mode> --steps 1 --warmup 1
---no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0` (tools/collect_pmc.sh; the warm-up step's rows are dropped here): per-kernel average bytes per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section),
+--no-cpu-baseline --no-dataset --no-inference --no-c3 --overlap-wgrad 0` (tools/collect_pmc.sh; the warm-up step's rows are dropped here): per-kernel average bytes per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section),
 stamped with the hash of the kernel sources it was measured on (poisson_cnn_amd._lib.source_hash) - bench.py reports `traffic` only when
 the stamp matches the tree it runs from.
 
@@ -98,7 +98,7 @@ def main():
     if ca > 0:
         kernels['conv (all convolution kernels of one training step)']['mfma_busy_frac'] = cb / (128.0 * ca)
     json.dump({'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --math %s --steps 1 --warmup 1 '
-                          '--no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0 (the warm-up step is dropped; separate passes; a third one counts SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; tools/collect_pmc.sh)' % math,
+                          '--no-cpu-baseline --no-dataset --no-inference --no-c3 --overlap-wgrad 0 (the warm-up step is dropped; separate passes; a third one counts SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; tools/collect_pmc.sh)' % math,
                'source_hash': _lib.source_hash(),
                'warmup_dropped': all(DROPPED.values()),
                'note': 'bytes = Counter_Value * 1024; gfx950 correction per MI355X_MICROARCH.md (HBM): FETCH_SIZE reports 1/2 of the bytes of '

@@ -4,7 +4,7 @@ ROOT=$(pwd); export TMPDIR=/tmp
 i=0
 for lib in "$@"; do
   i=$((i+1)); d=$ROOT/gpurun_out/ab_$i; rm -rf "$d"
-  (cd /tmp && PCNN_LIBRARY=${lib:+$ROOT/$lib} rocprofv3 --kernel-trace --stats -d "$d" --output-format csv -- python3 "$ROOT/bench.py" --workload c4 --math fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-dataset --no-c3 --overlap-wgrad 0 > "$d.log" 2>&1)
+  (cd /tmp && PCNN_LIBRARY=${lib:+$ROOT/$lib} rocprofv3 --kernel-trace --stats -d "$d" --output-format csv -- python3 "$ROOT/bench.py" --workload c4 --math fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-dataset --no-inference --no-c3 --overlap-wgrad 0 > "$d.log" 2>&1)
   cp "$d"/*/*_kernel_stats.csv "$ROOT/gpurun_out/ab_${i}_kernel_stats.csv"; rm -rf "$d"
   echo "== $i: ${lib:-in-tree}"
 done
