@@ -80,6 +80,17 @@ class _Prefetcher:
             ev.record(self.stream)
         self.pending = (idx, batch, ev)
 
+    def close(self):
+        """Drops a batch that was requested and never taken, and the libpcnn handle of the producer stream (its scratch and workspaces)."""
+        self.pending = None
+        if self.on and self.stream is not None:
+            try:
+                self.stream.synchronize()
+                ops.release_stream_handle(self.stream.cuda_stream, torch.device(self.stream.device).index)
+            finally:
+                self.stream = None
+                self.on = False
+
     def take(self):
         idx, batch, ev = self.pending
         self.pending = None
@@ -239,12 +250,18 @@ class _ModelBase:
         self.stop_training = False
         for cb in callbacks:
             cb.set_model(self)
+        fetch = _Prefetcher(dataset, self.device)             # one producer stream (and one libpcnn handle on it) per fit() call
+        try:
+            return self._fit_epochs(dataset, epochs, callbacks, verbose, steps_per_epoch, history, fetch)
+        finally:
+            fetch.close()
+
+    def _fit_epochs(self, dataset, epochs, callbacks, verbose, steps_per_epoch, history, fetch):
         for epoch in range(epochs):
             n = steps_per_epoch if steps_per_epoch is not None else len(dataset)
             agg = {'loss': 0.0, 'mse': 0.0}
             logs = {'loss': float('nan'), 'mse': float('nan')}
             step = -1
-            fetch = _Prefetcher(dataset, self.device)
             fetch.request(0)
             for step in range(n):
                 inp, tar = fetch.take()
