@@ -270,3 +270,29 @@ def test_weights_version_bookkeeping_of_the_filter_cache():
     del store
     gc.collect()
     assert ops._filter_epoch == epoch + 1 and ops.filter_version() > v3    # a dying bucket: every handle empties its cache before its next cached call
+
+
+def test_host_logs_and_inline_prefetcher_on_cpu():
+    """fit()'s helpers without a GPU: _host_logs turns a dict of device scalars / floats into floats through one stacked read (order and keys kept);
+    _Prefetcher on a CPU device generates in line - dataset[i] is called exactly once per request, in order."""
+    import torch
+    from poisson_cnn_amd import models
+    logs = {'loss': torch.tensor(1.5), 'mse': torch.tensor([0.25]), 'lr': 1e-3}
+    out = models._host_logs(logs)
+    assert list(out) == ['loss', 'mse', 'lr'] and out == {'loss': 1.5, 'mse': 0.25, 'lr': 1e-3} and all(isinstance(v, float) for v in out.values())
+
+    class Seq:
+        def __init__(self):
+            self.calls = []
+
+        def __getitem__(self, i):
+            self.calls.append(i)
+            return [torch.zeros(1)], torch.zeros(1)
+    s = Seq()
+    f = models._Prefetcher(s, 'cpu')
+    assert not f.on
+    for i in range(3):
+        f.request(i)
+        f.take()
+    f.close()
+    assert s.calls == [0, 1, 2]

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--presize', type=int, default=1, help='1: model.compile(..., max_input_shape=...) from random_output_shape_range (the shipped train.main does); 0: grow on demand')
     ap.add_argument('--batch', type=int, default=None, help='override the shipped batch size (diagnostics)')
     ap.add_argument('--second-pass', type=int, default=1)
+    ap.add_argument('--mem-every', type=int, default=0, help='print allocator / device memory every N steps (soak runs)')
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -74,6 +75,10 @@ def main():
         def on_batch_end(self, batch, logs):
             self.t.append(time.perf_counter())
             self.loss.append(logs['loss'])
+            if args.mem_every and (batch + 1) % args.mem_every == 0:           # soak runs: does reserved memory creep with ever new shapes?
+                free, total = torch.cuda.mem_get_info()
+                print('[mem] step %d: allocated %.1f GB, reserved %.1f GB, device used %.1f GB' % (batch + 1, torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9,
+                                                                                                   (total - free) / 1e9), file=sys.stderr, flush=True)
 
     def run_pass(tag, seed):
         """model.fit() itself (train/hpnn_legacy_train.py:60), one epoch of `steps` batches."""
