@@ -262,7 +262,8 @@ class _ModelBase:
             agg = {'loss': 0.0, 'mse': 0.0}
             logs = {'loss': float('nan'), 'mse': float('nan')}
             step = -1
-            fetch.request(0)
+            if n > 0:
+                fetch.request(0)
             for step in range(n):
                 inp, tar = fetch.take()
                 logs = self.train_step((tuple(inp), tar))
