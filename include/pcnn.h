@@ -207,6 +207,18 @@ int pcnn_conv2d_bwd_spectral_post_eligible(pcnn_handle h, const pcnn_conv_desc* 
 int pcnn_conv2d_bwd_spectral_post(pcnn_handle h, const pcnn_conv_desc* d, const pcnn_conv_desc* dg, const float* x, const float* dz, const float* w_flipped,
                                   const float* residual, float* dx, float* dw, const pcnn_post_desc* post);
 
+/* The same fusion for the NARROW layers (<= 16 channels, 3x3 / 5x5: the tail of the final stack, models/Homogeneous_Poisson_NN_Legacy.py:86-96), whose data
+ * gradient runs on the vector-ALU kernel (csrc/conv_small.hip) and not through pcnn_conv2d_bwd_spectral: dx = conv(dz; w_flipped) with the data-gradient
+ * descriptor dg (as one would pass it to pcnn_conv2d_fwd: zero padding kh - 1 - pad_top / kw - 1 - pad_left, linear epilogue) + residual, then `post` exactly as
+ * above - raw_out receives the sum, dx receives it times act'(act_out), dbias the per-channel sums of dx (partial sums per workgroup in the handle's scratch,
+ * reduced in a fixed order: deterministic).  dx and raw_out are bit-identical to pcnn_conv2d_fwd followed by pcnn_conv2d_epilogue_bwd; dbias differs from that
+ * pair in summation order only.  Replaces the tape's tf.nn.conv2d_backprop_input + the activation gradient of the producing layer (tf.GradientTape,
+ * models/Homogeneous_Poisson_NN_Legacy.py:265-270).  Eligible: the narrow route for dg, a channel count of dx that is a multiple of 4, 16-byte aligned
+ * tensors with channel strides that are multiples of 4; otherwise call pcnn_conv2d_fwd and pcnn_conv2d_epilogue_bwd. */
+int pcnn_conv2d_dgrad_post_eligible(pcnn_handle h, const pcnn_conv_desc* dg, const float* dz, const float* residual, const float* dx, const pcnn_post_desc* post);
+int pcnn_conv2d_dgrad_post(pcnn_handle h, const pcnn_conv_desc* dg, const float* dz, const float* w_flipped, const float* residual, float* dx,
+                           const pcnn_post_desc* post);
+
 /* Diagnostics (tests / tools only; no reference counterpart): the tile spectra of one image exactly as the forward transform of a spectral
  * convolution writes them, with the transform kernels the handle currently selects - out: [tile groups][channel groups][T*T rows][32] floats
  * (layout: csrc/spectral_common.h).  tests/test_gpu_spectral_fft.py and test_gpu_spectral64.py compare the kernel families row by row. */
@@ -354,6 +366,12 @@ int pcnn_channel_scale_fwd(pcnn_handle h, int N, int64_t hw, int C, const float*
 int pcnn_channel_scale_bwd(pcnn_handle h, int N, int64_t hw, int C, const float* x, int ldx, const float* s, const float* dy, int lddy,
                            float* dx, int lddx, float* ds, void* workspace, size_t workspace_bytes);
 size_t pcnn_channel_scale_workspace(int N, int64_t hw, int C);
+/* pcnn_channel_scale_bwd with the activation backward of the layer that produced x fused in (round 6): x is that layer's saved activation output, so
+ * dz = dy s act'(x) is written instead of dx - what pcnn_channel_scale_bwd followed by pcnn_conv2d_epilogue_bwd gives, bit for bit - and dbias (may be NULL)
+ * receives the per-channel sums of dz in a fixed order.  workspace: 2 * pcnn_channel_scale_workspace(N, hw, C) bytes.  (The einsum of
+ * models/Homogeneous_Poisson_NN_Legacy.py:231 follows the leaky-ReLU of post_merge_resnet's last convolution, :227-229.) */
+int pcnn_channel_scale_bwd_post(pcnn_handle h, int N, int64_t hw, int C, const float* x, int ldx, const float* s, const float* dy, int lddy,
+                                float* dz, int lddz, float* ds, int act, float act_alpha, float* dbias, void* workspace, size_t workspace_bytes);
 /* per-sample scalar scale: y[n,..] = x[n,..]*(1+g[n]) (layers/Scaling.py:55); bwd: dx, dg[n] = sum dy*x */
 int pcnn_sample_scale_fwd(pcnn_handle h, int N, int64_t per, const float* x, const float* g, float* y);
 int pcnn_sample_scale_bwd(pcnn_handle h, int N, int64_t per, const float* x, const float* g, const float* dy, float* dx, float* dg);

@@ -16,6 +16,7 @@
 int pcnn_conv_small_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                         const float* bn_shift, const float* residual, float* y, float* act_out);
 int pcnn_conv_small_wgrad(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes);
+bool pcnn_conv_fwd_takes_narrow_route(pcnn_handle h, const pcnn_conv_desc* d);                            // spectral_conv.hip
 bool pcnn_conv_small_fwd_eligible(const pcnn_conv_desc* d);
 bool pcnn_conv_small_wgrad_eligible(const pcnn_conv_desc* d);
 size_t pcnn_conv_small_wgrad_workspace(const pcnn_conv_desc* d);
@@ -34,6 +35,11 @@ struct SmallParams {
   unsigned* absmax;
   int N, H, W, Cin, ldx, Ho, Wo, Cout, ldy, pt, pl, pad_mode; float pad_value; int act; float alpha;
   int ld_res, ld_act, tiles_x, tiles_y, vec_in, vec_out;
+  // POST (data-gradient launches, round 6): the activation backward of the layer that PRODUCED this convolution's input, applied to the gradient before it is
+  // stored - v = conv (+ residual); y2 (if given) receives v, y receives v * act'(gact) (gact = that layer's saved activation output), and the workgroup's
+  // per-channel sums of what it stored go to bpart[block * CO + o] (the bias gradient's partial sums, reduced in a fixed order by small_post_bias_kernel)
+  const float* gact = nullptr; float* y2 = nullptr; float* bpart = nullptr;
+  int ld_gact = 0, ld_y2 = 0, gmode = 0; float galpha = 1.f;
 };
 
 // tf.pad index map without control flow (selects only): a load whose address depends on it can be issued unconditionally, so that the
@@ -100,7 +106,7 @@ __device__ __forceinline__ void stage_tile_batched(float* __restrict__ lds, cons
 // launch bound: the HBM-bound shapes (CI * CO <= 64) are compiled for 8 waves per SIMD (<= 64 VGPRs) - what hides the load -> compute ->
 // store latency chain of a tile is the number of resident workgroups, not instruction-level tricks (a persistent variant with register
 // prefetch of the next tile and a 4-rows-per-thread variant were measured: 2.3x and 1.1x SLOWER)
-template <int K, int CI, int CO>
+template <int K, int CI, int CO, bool POST = false>
 __global__ __launch_bounds__(256, (CI * CO <= 64 ? 8 : 4)) void conv_small_fwd_kernel(SmallParams p) {
   constexpr int TC = STW + K - 1, CIS = lds_stride(CI);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -133,9 +139,60 @@ __global__ __launch_bounds__(256, (CI * CO <= 64 ? 8 : 4)) void conv_small_fwd_k
 #pragma unroll
         for (int o = 0; o < CO; ++o) acc[o] = fmaf(xv[ci], wp[((i * K + j) * CI + ci) * CO + o], acc[o]);
     }
-  // ---- fused epilogue: bias -> activation -> (act_out) -> BN affine -> residual -> y
   const int oy = y0 + r, ox = x0 + c;
   float ymax = 0.f;
+  if constexpr (POST) {
+    // ---- data gradient + the producer's activation backward (the launcher guarantees whole 16-byte channel quads on every tensor, a linear epilogue, no bias,
+    // no BN): residual -> y2 (raw copy for a skip connection) -> times act'(gact) -> y; per-channel sums of y for the producer's bias gradient
+    float bs[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) bs[o] = 0.f;
+    if (oy < p.Ho && ox < p.Wo) {
+      const int64_t pix = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
+      f32x4 rr[CO / 4], gg[CO / 4];
+#pragma unroll
+      for (int q = 0; q < CO / 4; ++q) {                       // all loads first: a load between two stores is waited for with vmcnt(0)
+        const int cq = 4 * q < p.Cout ? 4 * q : 0;
+        gg[q] = *reinterpret_cast<const f32x4*>(p.gact + pix * p.ld_gact + cq);
+        if (p.res) rr[q] = *reinterpret_cast<const f32x4*>(p.res + pix * p.ld_res + cq);
+      }
+#pragma unroll
+      for (int q = 0; q < CO / 4; ++q) {
+        if (4 * q < p.Cout) {
+          f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          if (p.res) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rr[q][j];
+          }
+          if (p.y2) *reinterpret_cast<f32x4*>(p.y2 + pix * p.ld_y2 + 4 * q) = v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float gq = gg[q][j];
+            v[j] *= p.gmode == PCNN_ACT_TANH ? 1.f - gq * gq : (gq > 0.f ? 1.f : p.galpha);
+            bs[4 * q + j] = v[j];
+            ymax = fmaxf(ymax, fabsf(v[j]));
+          }
+          *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + 4 * q) = v;
+        }
+      }
+    }
+    // the workgroup's sums, in a fixed order: butterfly over the 64 lanes of a wave, then the four waves one after the other
+    if (p.bpart) {
+      __syncthreads();                                           // every thread has finished reading the staged tile: its LDS is free
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        float v = bs[o];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+        if ((threadIdx.x & 63) == 0) lds[(threadIdx.x >> 6) * CO + o] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < CO) p.bpart[(int64_t)blockIdx.x * CO + threadIdx.x] = ((lds[threadIdx.x] + lds[CO + threadIdx.x]) + lds[2 * CO + threadIdx.x]) + lds[3 * CO + threadIdx.x];
+    }
+    conv_epilogue_absmax(p.absmax, ymax);
+    return;
+  }
+  // ---- fused epilogue: bias -> activation -> (act_out) -> BN affine -> residual -> y
   if (oy < p.Ho && ox < p.Wo) {
     const int64_t pix = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
     float out[CO];
@@ -204,7 +261,9 @@ __global__ void pack_small_kernel(const float* __restrict__ w, float* __restrict
 template <int K, int CI, int CO>
 void launch_small_fwd(pcnn_handle h, const SmallParams& p, int64_t nblk) {
   constexpr size_t lds = (size_t)(STH + K - 1) * (STW + K - 1) * lds_stride(CI) * sizeof(float);
-  hipLaunchKernelGGL((conv_small_fwd_kernel<K, CI, CO>), dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
+  static_assert(lds >= 4 * 16 * sizeof(float), "the POST epilogue reduces 4 waves x CO sums through the tile's LDS");
+  if (p.gact) hipLaunchKernelGGL((conv_small_fwd_kernel<K, CI, CO, true>), dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
+  else hipLaunchKernelGGL((conv_small_fwd_kernel<K, CI, CO, false>), dim3((unsigned)nblk), dim3(256), lds, h->stream, p);
 }
 
 template <int K, int CI>
@@ -569,6 +628,18 @@ void launch_stage(pcnn_handle h, StageParams p) {
   hipLaunchKernelGGL((resnet3_stage_kernel<C, TH>), dim3((unsigned)(p.N * p.tiles_x * p.tiles_y)), dim3(256), lds, h->stream, p);
 }
 
+// POST: dbias[ch] = sum over the workgroups' partial sums, in a fixed order (thread t sums blocks t, t + 256, ...; then a tree).  One workgroup per channel.
+__global__ __launch_bounds__(256) void small_post_bias_kernel(const float* __restrict__ bpart, int64_t nblk, int CO, float* __restrict__ dbias) {
+  __shared__ float red[256];
+  const int ch = blockIdx.x, t = threadIdx.x;
+  float a = 0.f;
+  for (int64_t b = t; b < nblk; b += 256) a += bpart[b * CO + ch];
+  red[t] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
+  if (t == 0) dbias[ch] = red[0];
+}
+
 }  // namespace
 
 static int pad4(int c) { return (c + 3) & ~3; }
@@ -589,8 +660,35 @@ size_t pcnn_conv_small_wgrad_workspace(const pcnn_conv_desc* d) {
   return pcnn_conv_small_wgrad_eligible(d) ? (size_t)wgrad_splits(d) * d->kh * d->kw * d->Cin * d->Cout * sizeof(float) : 0;
 }
 
+static int small_fwd_impl(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
+                          const float* bn_shift, const float* residual, float* y, float* act_out, const pcnn_post_desc* post);
+
 int pcnn_conv_small_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
                         const float* bn_shift, const float* residual, float* y, float* act_out) {
+  return small_fwd_impl(h, d, x, w, bias, bn_scale, bn_shift, residual, y, act_out, nullptr);
+}
+
+// The data gradient of a narrow layer with the activation backward of the layer that produced its input fused into the epilogue (include/pcnn.h
+// pcnn_conv2d_dgrad_post): eligible when the data-gradient convolution takes the narrow route and every tensor can be accessed in whole 16-byte channel quads.
+static bool quads_ok(const void* q, int ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0); }
+extern "C" int pcnn_conv2d_dgrad_post_eligible(pcnn_handle h, const pcnn_conv_desc* dg, const float* dz, const float* residual, const float* dx, const pcnn_post_desc* post) {
+  static const int on = getenv("PCNN_SMALL_POST") ? atoi(getenv("PCNN_SMALL_POST")) : 1;
+  if (!on || !h || !dg || !post || !post->act_out) return 0;
+  if (dg->pad_mode != PCNN_PAD_CONSTANT || dg->act != PCNN_ACT_LINEAR || dg->N < 1) return 0;
+  if (!pcnn_conv_small_fwd_eligible(dg) || !pcnn_conv_fwd_takes_narrow_route(h, dg)) return 0;
+  if (dg->Cout % 4 != 0) return 0;                               // (the gradient coming in may have any channel count: the tile loader handles it)
+  if (post->act != PCNN_ACT_LINEAR && post->act != PCNN_ACT_RELU && post->act != PCNN_ACT_LEAKY_RELU && post->act != PCNN_ACT_TANH) return 0;
+  return (quads_ok(dx, dg->ldy) && quads_ok(residual, dg->ld_res) && quads_ok(post->act_out, post->ld_act_out) && quads_ok(post->raw_out, post->ld_raw) && dz) ? 1 : 0;
+}
+extern "C" int pcnn_conv2d_dgrad_post(pcnn_handle h, const pcnn_conv_desc* dg, const float* dz, const float* w_flipped, const float* residual, float* dx,
+                                      const pcnn_post_desc* post) {
+  PCNN_REQUIRE(h, h && dg && dz && w_flipped && dx && post, "pcnn_conv2d_dgrad_post: null argument");
+  PCNN_REQUIRE(h, pcnn_conv2d_dgrad_post_eligible(h, dg, dz, residual, dx, post), "pcnn_conv2d_dgrad_post: not eligible (ask pcnn_conv2d_dgrad_post_eligible first)");
+  return small_fwd_impl(h, dg, dz, w_flipped, nullptr, nullptr, nullptr, residual, dx, nullptr, post);
+}
+
+static int small_fwd_impl(pcnn_handle h, const pcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* bn_scale,
+                          const float* bn_shift, const float* residual, float* y, float* act_out, const pcnn_post_desc* post) {
   const int CI = pad4(d->Cin), CO = pad4(d->Cout), taps = d->kh * d->kw;
   const size_t need = (size_t)taps * CI * CO * sizeof(float);
   if (h->scratch_bytes < need) {
@@ -612,9 +710,26 @@ int pcnn_conv_small_fwd(pcnn_handle h, const pcnn_conv_desc* d, const float* x, 
   p.vec_out = conv_epilogue_vec_ok(d->Cout, y, d->ldy, residual, d->ld_res, act_out, d->ld_act_out);
   const int64_t nblk = (int64_t)d->N * p.tiles_x * p.tiles_y;
   PCNN_REQUIRE(h, nblk < (1ll << 31), "pcnn_conv2d_fwd: grid too large");
+  if (post) {
+    p.gact = post->act_out; p.ld_gact = post->ld_act_out; p.y2 = post->raw_out; p.ld_y2 = post->ld_raw; p.gmode = post->act;
+    p.galpha = post->act == PCNN_ACT_LINEAR ? 1.f : (post->act == PCNN_ACT_RELU ? 0.f : post->act_alpha);
+    if (post->dbias) {                                           // the workgroups' partial sums: nblk x CO floats in the handle's auxiliary scratch
+      const size_t need = (size_t)nblk * CO * sizeof(float);
+      if (h->aux_ws_bytes < need) {
+        if (h->aux_ws) { pcnn_release(h, h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
+        if (hipMalloc(&h->aux_ws, need) != hipSuccess) PCNN_FAIL(h, "pcnn_conv2d_dgrad_post: cannot allocate %zu B of scratch", need);
+        h->aux_ws_bytes = need;
+      }
+      p.bpart = static_cast<float*>(h->aux_ws);
+    }
+  }
   const bool ok = d->kh == 3 ? dispatch_ci<3>(h, p, nblk, CI, CO) : dispatch_ci<5>(h, p, nblk, CI, CO);
   PCNN_REQUIRE(h, ok, "pcnn_conv2d_fwd(small): no kernel for %d->%d", d->Cin, d->Cout);
   PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_fwd(small)");
+  if (post && post->dbias) {
+    hipLaunchKernelGGL(small_post_bias_kernel, dim3((unsigned)d->Cout), dim3(256), 0, h->stream, p.bpart, nblk, CO, post->dbias);
+    PCNN_CHECK_LAUNCH(h, "pcnn_conv2d_dgrad_post(bias)");
+  }
   return 0;
 }
 

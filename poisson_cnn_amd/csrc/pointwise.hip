@@ -287,17 +287,25 @@ __global__ void channel_scale_fwd_kernel(int N, int64_t hw, int C, const float* 
 // dx = dy*s ; per-sample column sums of dy*x -> partial[n][blk][C]
 __global__ __launch_bounds__(CS_BLOCK) void channel_scale_bwd_kernel(int64_t hw, int C, int CP, const float* __restrict__ x, int ldx,
                                                                      const float* __restrict__ s, const float* __restrict__ dy, int lddy,
-                                                                     float* __restrict__ dx, int lddx, float* __restrict__ partial) {
+                                                                     float* __restrict__ dx, int lddx, float* __restrict__ partial,
+                                                                     int gmode, float galpha, float* __restrict__ bpartial) {
+  // bpartial != nullptr (pcnn_channel_scale_bwd_post): x IS the saved activation output of the layer that produced it, so that layer's activation backward
+  // rides along - dx = dy s act'(x), and the per-channel sums of dx (its bias gradient) are formed like the sums of ds
   __shared__ float red[CS_BLOCK];
   const int n = blockIdx.y, tid = threadIdx.x, c = tid % CP, r = tid / CP, R = CS_BLOCK / CP;
-  float acc = 0.f;
+  float acc = 0.f, bacc = 0.f;
   if (c < C) {
     const float sv = s[n * C + c];
     for (int64_t q = (int64_t)blockIdx.x * R + r; q < hw; q += (int64_t)gridDim.x * R) {
       const int64_t pix = (int64_t)n * hw + q;
-      const float g = dy[pix * lddy + c];
-      acc += g * x[pix * ldx + c];
-      dx[pix * lddx + c] = g * sv;
+      const float g = dy[pix * lddy + c], xv = x[pix * ldx + c];
+      acc += g * xv;
+      float v = g * sv;
+      if (bpartial) {
+        v *= gmode == PCNN_ACT_TANH ? 1.f - xv * xv : (xv > 0.f ? 1.f : galpha);
+        bacc += v;
+      }
+      dx[pix * lddx + c] = v;
     }
   }
   red[tid] = acc;
@@ -307,6 +315,25 @@ __global__ __launch_bounds__(CS_BLOCK) void channel_scale_bwd_kernel(int64_t hw,
     for (int q = 0; q < R; ++q) t += red[q * CP + c];
     partial[((int64_t)n * gridDim.x + blockIdx.x) * C + c] = t;
   }
+  if (bpartial) {
+    __syncthreads();
+    red[tid] = bacc;
+    __syncthreads();
+    if (r == 0 && c < C) {
+      float t = 0.f;
+      for (int q = 0; q < R; ++q) t += red[q * CP + c];
+      bpartial[((int64_t)n * gridDim.x + blockIdx.x) * C + c] = t;
+    }
+  }
+}
+
+// dbias[c] = sum over samples and blocks of the partial sums above, in a fixed order (sample-major); one thread per channel
+__global__ void channel_scale_bias_final_kernel(const float* __restrict__ bpartial, int N, int nb, int C, float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int i = 0; i < N * nb; ++i) t += bpartial[(int64_t)i * C + c];
+  dbias[c] = t;
 }
 
 __global__ void channel_scale_final_kernel(const float* __restrict__ partial, int N, int nblk, int C, float* __restrict__ ds) {
@@ -631,10 +658,30 @@ extern "C" int pcnn_channel_scale_bwd(pcnn_handle h, int N, int64_t hw, int C, c
   PCNN_REQUIRE(h, workspace_bytes >= pcnn_channel_scale_workspace(N, hw, C), "pcnn_channel_scale_bwd: workspace too small");
   const int CP = pow2_ge(C), nb = cs_blocks(hw, CP);
   float* partial = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(channel_scale_bwd_kernel, dim3(nb, N), dim3(CS_BLOCK), 0, h->stream, hw, C, CP, x, ldx, s, dy, lddy, dx, lddx, partial);
+  hipLaunchKernelGGL(channel_scale_bwd_kernel, dim3(nb, N), dim3(CS_BLOCK), 0, h->stream, hw, C, CP, x, ldx, s, dy, lddy, dx, lddx, partial, 0, 1.f, (float*)nullptr);
   PCNN_CHECK_LAUNCH(h, "pcnn_channel_scale_bwd");
   hipLaunchKernelGGL(channel_scale_final_kernel, dim3(pcnn_cdiv(N * C, 128)), dim3(128), 0, h->stream, partial, N, nb, C, ds);
   PCNN_CHECK_LAUNCH(h, "pcnn_channel_scale_bwd(final)");
+  return 0;
+}
+
+// ... with the activation backward of the layer that produced x (x = its saved activation output): dz = dy s act'(x) instead of dx, dbias = sum dz.
+// workspace: TWICE pcnn_channel_scale_workspace(N, hw, C).  dz is what pcnn_channel_scale_bwd + pcnn_conv2d_epilogue_bwd give, bit for bit.
+extern "C" int pcnn_channel_scale_bwd_post(pcnn_handle h, int N, int64_t hw, int C, const float* x, int ldx, const float* s, const float* dy, int lddy,
+                                           float* dz, int lddz, float* ds, int act, float act_alpha, float* dbias, void* workspace, size_t workspace_bytes) {
+  PCNN_REQUIRE(h, h && x && s && dy && dz && ds && workspace, "pcnn_channel_scale_bwd_post: null argument");
+  PCNN_REQUIRE(h, C >= 1 && C <= CS_BLOCK, "pcnn_channel_scale_bwd_post: C=%d unsupported", C);
+  PCNN_REQUIRE(h, act == PCNN_ACT_LINEAR || act == PCNN_ACT_RELU || act == PCNN_ACT_LEAKY_RELU || act == PCNN_ACT_TANH, "pcnn_channel_scale_bwd_post: activation %d", act);
+  PCNN_REQUIRE(h, workspace_bytes >= 2 * pcnn_channel_scale_workspace(N, hw, C), "pcnn_channel_scale_bwd_post: workspace too small");
+  const int CP = pow2_ge(C), nb = cs_blocks(hw, CP);
+  float* partial = static_cast<float*>(workspace);
+  float* bpartial = partial + (size_t)N * 256 * C;
+  const float galpha = act == PCNN_ACT_LINEAR ? 1.f : (act == PCNN_ACT_RELU ? 0.f : act_alpha);
+  hipLaunchKernelGGL(channel_scale_bwd_kernel, dim3(nb, N), dim3(CS_BLOCK), 0, h->stream, hw, C, CP, x, ldx, s, dy, lddy, dz, lddz, partial, act, galpha, bpartial);
+  PCNN_CHECK_LAUNCH(h, "pcnn_channel_scale_bwd_post");
+  hipLaunchKernelGGL(channel_scale_final_kernel, dim3(pcnn_cdiv(N * C, 128)), dim3(128), 0, h->stream, partial, N, nb, C, ds);
+  if (dbias) hipLaunchKernelGGL(channel_scale_bias_final_kernel, dim3(pcnn_cdiv(C, 64)), dim3(64), 0, h->stream, bpartial, N, nb, C, dbias);
+  PCNN_CHECK_LAUNCH(h, "pcnn_channel_scale_bwd_post(final)");
   return 0;
 }
 

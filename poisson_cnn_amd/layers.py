@@ -397,6 +397,10 @@ class ConvUnit:
             return None
         # wf: the flipped filter formed above (the layer's own buffer) - no second launch
         if self.mode == 'CONSTANT':
+            if post is not None and not post.applied:                  # narrow layers: the producer's activation backward in the data-gradient kernel's epilogue
+                dxp = ops.conv2d_dgrad_post(dz, wf, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], out_hw=(H, W), residual=add_to, post=post)
+                if dxp is not None:
+                    return dxp
             return ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1 - self.pads_y[0], pad_left=kw - 1 - self.pads_x[0], residual=add_to, w_version=wver)
         gp = ops.conv2d_fwd(dz, wf, None, pad_top=kh - 1, pad_left=kw - 1, out_hw=(H + kh - 1, W + kw - 1), w_version=wver)
         if post is not None and not post.applied:

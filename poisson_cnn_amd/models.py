@@ -517,12 +517,19 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
             post = self.final[i - 1].post_spec() if i > 0 else None
             d = self.final[i].backward(d, inplace=True, dz_ready=ready, post=post)
             ready = post is not None and post.applied
-        d, ds = ops.channel_scale_bwd(sv['scale_in'], sv['dx_info'], d, ws=self.ctx.ws)
+        # the einsum's input is post_merge_resnet's activation output: its adjoint also applies that layer's activation backward (one pass of a full-
+        # resolution 32-channel tensor instead of four; ops.channel_scale_bwd_post declines where the offer does not fit)
+        ps = self.post_merge_resnet.post_spec()
+        fused = ops.channel_scale_bwd_post(sv['scale_in'], sv['dx_info'], d, ps, ws=self.ctx.ws)
+        if fused is not None:
+            d, ds = fused
+        else:
+            d, ds = ops.channel_scale_bwd(sv['scale_in'], sv['dx_info'], d, ws=self.ctx.ws)
         dd = ds
         for i, lyr in enumerate(reversed(self.dx_dense_layers)):
             dd = lyr.backward(dd, need_dx=(i < len(self.dx_dense_layers) - 1))
         post = self.post_merge_conv.post_spec()
-        d = self.post_merge_resnet.backward(d, inplace=True, post=post)
+        d = self.post_merge_resnet.backward(d, inplace=True, dz_ready=fused is not None, post=post)
         dcat = self.post_merge_conv.backward(d, inplace=True, dz_ready=post is not None and post.applied)
         d_initial = self.non_bottleneck_conv.backward(dcat[..., :F], inplace=False)
         dmerged = dcat[..., F:]

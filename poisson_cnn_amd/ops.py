@@ -388,6 +388,30 @@ def conv2d_fwd(x, w, bias=None, *, pad_top, pad_left, out_hw=None, pad_mode='CON
     return out
 
 
+def conv2d_dgrad_post(dz, wf, *, pad_top, pad_left, out_hw, residual, post):
+    """The data gradient of a NARROW layer (vector-ALU route) with the producer's activation backward in its epilogue (pcnn_conv2d_dgrad_post): returns dx
+    (already multiplied by act') and sets post.applied / post.raw - or returns None when the library declines (not the narrow route, odd channel counts,
+    unaligned views, an inference-mode BatchNormalization in the offer): the caller then runs conv2d_fwd and the separate pass."""
+    if post is None or post.bn_scale is not None or not _post_fusion:
+        return None
+    N, H, W, Cin = dz.shape
+    kh, kw, _, Cout = wf.shape
+    Ho, Wo = out_hw
+    out = empty((N, Ho, Wo, Cout), dz.device)
+    dg = conv_desc(dz.shape, _ld(dz), wf.shape, (Ho, Wo), _ld(out), pad_top, pad_left, 'CONSTANT', 0.0, 'linear', _ld(residual) if residual is not None else 0, 0)
+    raw = empty((N, Ho, Wo, Cout), dz.device) if post.want_raw else None
+    pd = PostDesc(post.a.data_ptr(), _ld(post.a), ACTS[post.act], LEAKY_ALPHA, post.dbias.data_ptr() if post.dbias is not None else None,
+                  raw.data_ptr() if raw is not None else None, Cout)
+    h = handle()
+    if tuple(post.a.shape) != (N, Ho, Wo, Cout) or not h.lib.pcnn_conv2d_dgrad_post_eligible(h._h, byref(dg), _p(dz), _p(residual), _p(out), byref(pd)):
+        return None
+    _launch('conv_fwd', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout,
+            lambda: h.call('pcnn_conv2d_dgrad_post', byref(dg), _p(dz), _p(wf), _p(residual), _p(out), byref(pd)),
+            4.0 * (N * H * W * Cin + N * Ho * Wo * Cout * (2 + (residual is not None) + (raw is not None)) + kh * kw * Cin * Cout))
+    post.applied, post.raw = True, raw
+    return out
+
+
 def flip_transpose_weights(w, out=None):
     kh, kw, ci, co = w.shape
     wt = out if out is not None else empty((kh, kw, co, ci), w.device)
@@ -865,6 +889,23 @@ def channel_scale_bwd(x, s, dy, ws=None):
     handle().call('pcnn_channel_scale_bwd', c_int(N), c_int64(H * W), c_int(C), _p(x), c_int(_ld(x)), _p(s), _p(dy), c_int(_ld(dy)), _p(dx), c_int(_ld(dx)),
                   _p(ds), _p(wsb), c_size_t(wsb.numel() * 4))
     return dx, ds
+
+
+def channel_scale_bwd_post(x, s, dy, post, ws=None):
+    """channel_scale_bwd + the activation backward of the layer whose saved activation output IS x (pcnn_channel_scale_bwd_post): returns (dz, ds) with
+    dz = dy s act'(x) and post.dbias written, post.applied set - or None when the offer does not fit (x is not the offered activation, an inference-mode
+    BatchNormalization or a raw copy is part of it, fusion switched off)."""
+    if post is None or not _post_fusion or post.bn_scale is not None or post.want_raw or post.a.data_ptr() != x.data_ptr() or tuple(post.a.shape) != tuple(x.shape):
+        return None
+    N, H, W, C = x.shape
+    lib = _lib.load()
+    wsb = (ws or _default_ws).get(2 * lib.pcnn_channel_scale_workspace(c_int(N), c_int64(H * W), c_int(C)), x.device)
+    dz = empty((N, H, W, C), x.device)
+    ds = empty((N, C), x.device)
+    handle().call('pcnn_channel_scale_bwd_post', c_int(N), c_int64(H * W), c_int(C), _p(x), c_int(_ld(x)), _p(s), _p(dy), c_int(_ld(dy)), _p(dz), c_int(_ld(dz)),
+                  _p(ds), c_int(ACTS[post.act]), c_float(LEAKY_ALPHA), _p(post.dbias), _p(wsb), c_size_t(wsb.numel() * 4))
+    post.applied = True
+    return dz, ds
 
 
 def sample_scale_fwd(x, g):

@@ -620,3 +620,31 @@ def test_pad_fold_with_the_producers_activation_backward_in_one_pass(mode, act):
     # not eligible (3 channels): nothing is done, the caller keeps the two-pass route
     post = ops.Post(a[..., :3].contiguous(), act, None)
     assert ops.pad_fold_bwd_post(gp[..., :3].contiguous(), (H, W), pads, mode, post) is None and not post.applied
+
+
+@pytest.mark.parametrize('act', ['leaky_relu', 'tanh', 'relu'])
+def test_channel_scale_backward_with_the_producers_activation_backward(act):
+    """pcnn_channel_scale_bwd_post (round 6): the einsum's adjoint also applies the activation backward of the layer whose activation output is the einsum's
+    input - dz and ds bit-identical to channel_scale_bwd followed by epilogue_bwd, the bias gradient equal up to summation order; an offer about another
+    tensor is declined."""
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(31)
+    N, H, W, C = 3, 45, 53, 32
+    x = torch.randn(N, H, W, C, device='cuda', generator=g)
+    if act == 'tanh':
+        x = torch.tanh(x)
+    s = torch.randn(N, C, device='cuda', generator=g)
+    dy = torch.randn(N, H, W, C, device='cuda', generator=g)
+    dx_ref, ds_ref = ops.channel_scale_bwd(x, s, dy)
+    db_ref = torch.zeros(C, device='cuda')
+    dz_ref = ops.epilogue_bwd(dx_ref, x, act=act, dz=torch.empty_like(dx_ref), dbias=db_ref)
+    db = torch.full((C,), -3.0, device='cuda')
+    post = ops.Post(x, act, db)
+    out = ops.channel_scale_bwd_post(x, s, dy, post)
+    assert out is not None and post.applied
+    dz, ds = out
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref) and torch.equal(ds, ds_ref)
+    assert float((db - db_ref).abs().max()) <= 2e-6 * float(dz_ref.abs().sum(dim=(0, 1, 2)).max())
+    other = ops.Post(x.clone(), act, db)
+    assert ops.channel_scale_bwd_post(x, s, dy, other) is None and not other.applied

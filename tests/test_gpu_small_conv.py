@@ -130,3 +130,55 @@ def test_weight_gradient_with_more_tiles_than_workgroups(k, Cin, Cout):
     (F.conv2d(xt, wt, padding=p) * dz.permute(0, 3, 1, 2).double().cpu()).sum().backward()
     ref = wt.grad.permute(2, 3, 1, 0).numpy()
     assert rel(dw.cpu().numpy(), ref) < 5e-6
+
+
+@pytest.mark.parametrize('k,Cl_in,Cl_out,act,res,raw', [
+    (3, 12, 16, 'leaky_relu', False, False),     # the data gradient of a 12 -> 16 ... layer: gradient comes in with Cl_out channels, goes out with Cl_in
+    (3, 12, 12, 'leaky_relu', True, True),       # inside a resnet: skip-connection gradient added, raw copy kept
+    (3, 8, 8, 'tanh', True, False),
+    (3, 8, 12, 'relu', False, True),
+    (3, 4, 1, 'leaky_relu', False, False),       # final/out1: one gradient channel in, four out
+    (3, 16, 12, 'linear', False, False),
+    (5, 16, 16, 'leaky_relu', True, True),
+    (3, 4, 4, 'leaky_relu', False, False),
+])
+def test_data_gradient_with_the_producers_activation_backward_fused(k, Cl_in, Cl_out, act, res, raw):
+    """pcnn_conv2d_dgrad_post (round 6): dx = conv(dz; flipped filter) [+ skip gradient], raw copy, times act'(producer's activation), producer's bias gradient
+    - against the two calls it replaces (conv2d_fwd + epilogue_bwd): dx and the raw copy bit-identical, the bias gradient equal up to its summation order.
+    Ragged image (the last tile row and column are partial) and a batch of 3."""
+    from poisson_cnn_amd import ops
+    prev_mode = ops._spectral_mode
+    ops.set_spectral_mode('off')                                  # 5 x 5 at 16 channels would otherwise go to the spectral route: this test is about the narrow kernel
+    try:
+        g = torch.Generator(device='cuda').manual_seed(100 * k + 10 * Cl_in + Cl_out)
+        N, H, W = 3, 61, 75
+        dz = torch.randn(N, H, W, Cl_out, device='cuda', generator=g)
+        w = torch.randn(k, k, Cl_in, Cl_out, device='cuda', generator=g) / (k * np.sqrt(Cl_in))
+        wf = ops.flip_transpose_weights(w)
+        a = torch.randn(N, H, W, Cl_in, device='cuda', generator=g)                     # the producer's saved activation output
+        if act == 'tanh':
+            a = torch.tanh(a)
+        add = torch.randn(N, H, W, Cl_in, device='cuda', generator=g) if res else None
+        p = k // 2
+        # reference: the two launches
+        ref_raw = ops.conv2d_fwd(dz, wf, None, pad_top=k - 1 - p, pad_left=k - 1 - p, residual=add)
+        ref_db = torch.zeros(Cl_in, device='cuda')
+        ref_dx = ops.epilogue_bwd(ref_raw, a if act != 'linear' else None, act=act, dz=torch.empty_like(ref_raw) if act != 'linear' else None, dbias=ref_db)
+        if act == 'linear':
+            ref_dx = ref_raw
+        # fused
+        db = torch.full((Cl_in,), 7.0, device='cuda')                                     # must be overwritten, not accumulated into
+        post = ops.Post(a, act, db, want_raw=raw)
+        dx = ops.conv2d_dgrad_post(dz, wf, pad_top=k - 1 - p, pad_left=k - 1 - p, out_hw=(H, W), residual=add, post=post)
+        assert dx is not None and post.applied, 'the narrow route must take the offer for %dx%d %d->%d' % (k, k, Cl_out, Cl_in)
+        torch.cuda.synchronize()
+        assert torch.equal(dx, ref_dx)
+        if raw:
+            assert torch.equal(post.raw, ref_raw)
+        assert float((db - ref_db).abs().max()) <= 2e-6 * float(ref_dx.abs().sum(dim=(0, 1, 2)).max())
+        # an offer the kernel cannot take is declined, nothing written
+        post2 = ops.Post(a[..., :Cl_in - 1] if Cl_in > 1 else a, act, None)
+        if Cl_in > 1:
+            assert ops.conv2d_dgrad_post(dz, wf, pad_top=k - 1 - p, pad_left=k - 1 - p, out_hw=(H, W), residual=None, post=post2) is None and not post2.applied
+    finally:
+        ops.set_spectral_mode(prev_mode)
