@@ -463,7 +463,7 @@ def run(args):
                 model.ctx.use_side = True
         # every rank's own convolution-kernel time per step (HIP events of the single-stream region): with rank_ms_per_step.ranks this tells a slow
         # rank (clock, NUMA placement) from collective cost on a scaling curve
-        conv_s = sum(prof.totals(k)[1] for k in ('conv_fwd', 'conv_wgrad', 'conv_bwd_fused', 'conv_stage')) if prof is not None else 0.0
+        conv_s = sum(prof.totals(k)[1] for k in ('conv_fwd', 'conv_wgrad', 'conv_bwd_fused', 'conv_stage', 'conv_fwd_post')) if prof is not None else 0.0
         rank_ms['conv_ms_per_step'] = [1e3 * v / steps for v in dp.gather_over_ranks(conv_s)]
         return elapsed, prof, loss, rank_ms, single
 
@@ -486,9 +486,11 @@ def run(args):
         wf, ws_, wc = prof.totals('conv_wgrad')
         bf, bs, bc = prof.totals('conv_bwd_fused')
         gf, gs, gc = prof.totals('conv_stage')                                # narrow resnet stages as one launch (three convolutions each)
-        af, as_, ac = flops + wf + bf + gf, secs + ws_ + bs + gs, calls + wc + bc + gc
+        pf, ps, pc = prof.totals('conv_fwd_post')                             # narrow data gradients that also run the producer's activation backward (round 6)
+        af, as_, ac = flops + wf + bf + gf + pf, secs + ws_ + bs + gs + ps, calls + wc + bc + gc + pc
         conv_s = as_ / max(steps, 1)
-        alg_bytes = (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad') + prof.total_bytes('conv_stage')) / max(steps, 1)
+        alg_bytes = (prof.total_bytes('conv_fwd') + prof.total_bytes('conv_bwd_fused') + prof.total_bytes('conv_wgrad') + prof.total_bytes('conv_stage')
+                     + prof.total_bytes('conv_fwd_post')) / max(steps, 1)
         summ, src = pmc_summary(mode, workload)
         traffic = busy = table = None
         if summ is not None:
@@ -504,6 +506,7 @@ def run(args):
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
         hf, hb, hs, hc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage') and b > 0 and f / b < ridge)
         sf, sb, ss, sc = prof.select(lambda k, f, b: k == 'conv_stage')   # narrow resnet stages as one launch: algorithmic bytes of the UNFUSED layers / time
+        qf, qb, qs, qc = prof.select(lambda k, f, b: k == 'conv_fwd_post')
         df, db, ds, dc = prof.select(lambda k, f, b: k == 'deconv_fwd')
         rf, rb, rs, rc = prof.select(lambda k, f, b: k == 'resize_fwd')
         direct_tflops = af / as_ / 1e12 if as_ else None
@@ -531,6 +534,9 @@ def run(args):
                 'hbm_bound': {'what': 'conv forward / data-gradient launches below the fp32 ridge (%.1f FLOP/B: the 3x3 tail with <= 8 channels and the Scaling convs)' % ridge,
                               'bound': 'hbm', 'achieved': hb / hs / 1e9 if hs else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s (algorithmic bytes)',
                               'frac': hb / hs / 1e9 / PEAK_HBM_GBS if hs else None, 'launches': hc, 'avg_launch_ms': 1e3 * hs / hc if hc else None,
+                              'narrow_dgrad_with_post': {'what': 'narrow data-gradient launches that also apply the producer\'s activation backward (input, output, the activation read, '
+                                                                 'optional skip gradient and raw copy) - not part of frac above, which keeps rounds 2-5\'s definition',
+                                                         'achieved': qb / qs / 1e9 if qs else None, 'frac': qb / qs / 1e9 / PEAK_HBM_GBS if qs else None, 'launches': qc},
                               'deconv_fwd': {'achieved': db / ds / 1e9 if ds else None, 'frac': db / ds / 1e9 / PEAK_HBM_GBS if ds else None, 'launches': dc},
                               'resize_fwd': {'achieved': rb / rs / 1e9 if rs else None, 'frac': rb / rs / 1e9 / PEAK_HBM_GBS if rs else None, 'launches': rc}}}
 

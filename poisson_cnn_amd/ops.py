@@ -405,9 +405,9 @@ def conv2d_dgrad_post(dz, wf, *, pad_top, pad_left, out_hw, residual, post):
     h = handle()
     if tuple(post.a.shape) != (N, Ho, Wo, Cout) or not h.lib.pcnn_conv2d_dgrad_post_eligible(h._h, byref(dg), _p(dz), _p(residual), _p(out), byref(pd)):
         return None
-    _launch('conv_fwd', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout,
+    _launch('conv_fwd_post', 2.0 * N * Ho * Wo * kh * kw * Cin * Cout,                  # (its own kind: a convolution launch that also does the producer's epilogue pass)
             lambda: h.call('pcnn_conv2d_dgrad_post', byref(dg), _p(dz), _p(wf), _p(residual), _p(out), byref(pd)),
-            4.0 * (N * H * W * Cin + N * Ho * Wo * Cout * (2 + (residual is not None) + (raw is not None)) + kh * kw * Cin * Cout))
+            4.0 * (N * H * W * Cin + N * Ho * Wo * Cout * (1 + (residual is not None)) + kh * kw * Cin * Cout))      # the convolution's own bytes, as conv2d_fwd counts them
     post.applied, post.raw = True, raw
     return out
 
