@@ -504,10 +504,11 @@ def run(args):
         achieved = alg_bytes / conv_s / 1e9 if conv_s else None                # ALGORITHMIC bytes over the kernels' measured time
         executed = traffic / conv_s / 1e9 if (traffic and conv_s) else None      # what the kernels really move (PMC), over the same time
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)           # FLOP per byte below which the fp32 conv is HBM-bound
-        # (the narrow data-gradient launches that took over their producer's activation backward in round 6 stay in the set - with the convolution's own bytes and
-        # their whole time, the extra pass included - so that the figure keeps the launches it has covered since round 2; hbm_bound.plain_launches: without them)
-        hf, hb, hs, hc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage', 'conv_fwd_post') and b > 0 and f / b < ridge)
-        nf, nb_, ns, nc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage') and b > 0 and f / b < ridge)
+        # launches that do a convolution and nothing else (the north star's "conv forward vs HBM roofline").  Since round 6 the narrow DATA-GRADIENT launches also run
+        # their producer's activation backward (kind conv_fwd_post) and left this set: what remains is the forward launches (compare inference.hbm_bound_frac_inference)
+        # and the few plain data gradients; hbm_bound.incl_post_launches puts them back with the convolution's own bytes over their whole time
+        hf, hb, hs, hc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage') and b > 0 and f / b < ridge)
+        nf, nb_, ns, nc = prof.select(lambda k, f, b: k in ('conv_fwd', 'conv_stage', 'conv_fwd_post') and b > 0 and f / b < ridge)
         sf, sb, ss, sc = prof.select(lambda k, f, b: k == 'conv_stage')   # narrow resnet stages as one launch: algorithmic bytes of the UNFUSED layers / time
         qf, qb, qs, qc = prof.select(lambda k, f, b: k == 'conv_fwd_post')
         df, db, ds, dc = prof.select(lambda k, f, b: k == 'deconv_fwd')
@@ -537,7 +538,7 @@ def run(args):
                 'hbm_bound': {'what': 'conv forward / data-gradient launches below the fp32 ridge (%.1f FLOP/B: the 3x3 tail with <= 8 channels and the Scaling convs)' % ridge,
                               'bound': 'hbm', 'achieved': hb / hs / 1e9 if hs else None, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s (algorithmic bytes)',
                               'frac': hb / hs / 1e9 / PEAK_HBM_GBS if hs else None, 'launches': hc, 'avg_launch_ms': 1e3 * hs / hc if hc else None,
-                              'plain_launches': {'frac': nb_ / ns / 1e9 / PEAK_HBM_GBS if ns else None, 'launches': nc},
+                              'incl_post_launches': {'frac': nb_ / ns / 1e9 / PEAK_HBM_GBS if ns else None, 'launches': nc},
                               'narrow_dgrad_with_post': {'what': 'narrow data-gradient launches that also apply the producer\'s activation backward (input, output, the activation read, '
                                                                  'optional skip gradient and raw copy): the convolution\'s own bytes over the whole launch time',
                                                          'achieved': qb / qs / 1e9 if qs else None, 'frac': qb / qs / 1e9 / PEAK_HBM_GBS if qs else None, 'launches': qc},
