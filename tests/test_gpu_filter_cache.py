@@ -218,3 +218,40 @@ def test_torch_optim_through_the_tape_with_and_without_the_cache():
     for (la, ya), (lb, yb) in zip(a, b):
         assert la == lb and torch.equal(ya, yb)
     assert torch.equal(wa, wb) and torch.equal(ra, rb)
+
+
+def _interleaved(cache):
+    """A.forward; B optimizer step (weights version moves); A.backward (first cached backward call under the new version: the handle refreshes EVERY kept
+    filter, B's flipped filters included); then B forward + backward with no further version bump.  Returns B's and A's gradients."""
+    from poisson_cnn_amd import ops
+    from poisson_cnn_amd.losses import loss_wrapper
+    from poisson_cnn_amd.train import Adam
+    ops.set_filter_cache(cache)
+    ops.set_spectral_mode('force')
+    full = configs.hpnn_tiny()
+    A, B = _build(full['model'], 31), _build(full['model'], 32)
+    for m in (A, B):
+        m.compile(loss=loss_wrapper(global_batch_size=2, **full['training']['loss_parameters']), optimizer=Adam(learning_rate=1e-2))
+    rhs, dx, target = _inputs(2, 72, 64, 5)
+    t = torch.tensor(target, device='cuda')
+    for m in (A, B):                                                    # one full step each: every layer has run a backward and keeps a flipped filter
+        m.train_step(((rhs, dx), target))
+    rhs_d, dx_d = torch.tensor(rhs, device='cuda'), torch.tensor(dx, device='cuda')
+    predA = A.call([rhs_d, dx_d], training=True)
+    B.train_step(((rhs, dx), target))                                   # B's weights move: new version
+    lossA, dpredA = A.loss_fn.value_and_grad(t, predA, rhs_d, torch.cat([dx_d, dx_d], 1))
+    A.backward(dpredA)
+    gA = A.store.flat_g.clone()
+    B._loss_and_grads(rhs_d, dx_d, t)                                   # no version bump in between
+    torch.cuda.synchronize()
+    return B.store.flat_g.clone(), gA
+
+
+def test_two_models_interleaved_see_current_flipped_filters():
+    """ConvUnit._flipped re-formed only ITS layer's flipped filter when a backward pass met a new weights version, while the cached convolution
+    behind it made the handle refresh - and stamp current - every kept filter, other models' stale flipped filters included.  With the fix every registered
+    layer is re-flipped first: the interleaved sequence gives bit-identical gradients with the cache on and off."""
+    gB1, gA1 = _interleaved(True)
+    gB0, gA0 = _interleaved(False)
+    assert torch.equal(gA1, gA0)
+    assert torch.equal(gB1, gB0), float((gB1 - gB0).abs().max())

@@ -169,3 +169,34 @@ def test_closing_captured_graphs_returns_their_handles_and_scratch():
         assert (dev, sp) not in ops._handles                         # ... and both are gone afterwards (a recycled stream pointer starts afresh)
         assert not any(sp in c._ws or sp in c._wflips for c in _ctxs(m))
     assert torch.equal(m([bc, dx, 40]), ref)                         # the eager path is untouched
+
+
+def test_replay_survives_another_model_replacing_the_flipped_filter_table():
+    """a captured train step records the launch that re-forms every layer's flipped filter from a device table of pointers
+    (ops.sync_flipped_filters).  When another model's first backward changes the set of layers, the module-level table is rebuilt and the old tensor used to
+    go back to the allocator - a later replay then read recycled memory as pointer entries.  The graph now owns the table (and the flipped filters) it
+    recorded: capture A, let a second model B register its layers and die, churn the allocator, replay A - bit-identical to the eager twin."""
+    import gc
+    eager, graphed = _dbcnn(5), _dbcnn(5)
+    from poisson_cnn_amd import ops
+    from poisson_cnn_amd.graphs import GraphedTrainStep
+    bc, dx, tgt = _dbcnn_batch(1)
+    step = GraphedTrainStep(graphed, ((bc, dx), tgt))
+    table_at_capture = ops._flip_table[1]
+    assert table_at_capture is not None and any(t is table_at_capture for t in step._keep)      # the graph holds what it recorded
+    le, lg = eager.train_step(((bc, dx), tgt)), step(((bc, dx), tgt))
+    assert float(le['loss']) == float(lg['loss']) and torch.equal(eager.store.flat_w, graphed.store.flat_w)
+    other = _dbcnn(9)                                                               # a second model: its first backward joins the layer set -> a new table
+    other.train_step(((bc, dx), tgt))
+    assert ops._flip_table[1] is not table_at_capture
+    del other
+    gc.collect()
+    junk = [torch.full((1 << 18,), float('nan'), device='cuda') for _ in range(64)]     # whatever was freed is overwritten with NaN bit patterns
+    del junk
+    torch.cuda.synchronize()
+    bc2, dx2, tgt2 = _dbcnn_batch(2)
+    for data in (((bc2, dx2), tgt2), ((bc, dx), tgt)):
+        le, lg = eager.train_step(data), step(data)
+        assert float(le['loss']) == float(lg['loss'])
+        assert torch.equal(eager.store.flat_g, graphed.store.flat_g) and torch.equal(eager.store.flat_w, graphed.store.flat_w)
+    step.close()
