@@ -309,6 +309,16 @@ int pcnn_resize_tables(int method, int n_in, int n_out, int32_t* idx /*n_out*4*/
 int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* x, int ldx,
                     const int32_t* idx_y, const float* wt_y, const int32_t* idx_x, const float* wt_x,
                     float alpha, float beta, float* y, int ldy);
+/* The resize branches of a merge in one pass over the destination (round 6; models/Homogeneous_Poisson_NN_Legacy.py:215-224: the three multilinear bottleneck
+ * branches are summed into the merge buffer): y = beta*y + alpha*(resize(x_0) + ... + resize(x_{nsrc-1})), nsrc = 2 or 3, accumulated in the order and with the
+ * roundings of nsrc consecutive pcnn_resize_fwd calls (beta, then 1, 1): bit-identical to them, with one read-modify-write of y instead of nsrc.  Eligible: C a
+ * multiple of 4, 16-byte aligned tensors, channel strides multiples of 4. */
+typedef struct pcnn_resize_src {
+  const float* x; int hc, wc, ldx;
+  const int32_t* idx_y; const float* wt_y; const int32_t* idx_x; const float* wt_x;
+} pcnn_resize_src;
+int pcnn_resize_fwd_multi_eligible(int N, int C, int Ho, int Wo, int nsrc, const pcnn_resize_src* src, const float* y, int ldy);
+int pcnn_resize_fwd_multi(pcnn_handle h, int N, int C, int Ho, int Wo, int nsrc, const pcnn_resize_src* src, float alpha, float beta, float* y, int ldy);
 /* dx = alpha * resize^T(dy); tmp must hold N*hc*Wo*C floats */
 int pcnn_resize_bwd(pcnn_handle h, int N, int hc, int wc, int C, int Ho, int Wo, const float* dy, int lddy,
                     const int32_t* idx_y, const float* wt_y, const int32_t* idx_x, const float* wt_x,

@@ -237,6 +237,54 @@ __global__ __launch_bounds__(256) void resize_fwd_y_kernel(int N, int hc, int C,
   }
 }
 
+// The same row pass for NS sources at once (round 6: the resize branches of the eight-branch merge, models/Homogeneous_Poisson_NN_Legacy.py:215-224): the
+// destination is read and written ONCE for all of them.  The accumulation runs in the order and with the roundings of NS consecutive calls of the kernel
+// above - y = beta y + alpha r0, then y = 1 y + alpha r1, ... - so the result is bit-identical to them.
+struct ResizeYSrc { const float* t; const int32_t* iy; const float* wy; int hc; };
+template <int NS>
+__global__ __launch_bounds__(256) void resize_fwd_y_multi_kernel(int N, int C, int Ho, int Wo, ResizeYSrc s0, ResizeYSrc s1, ResizeYSrc s2, float alpha, float beta,
+                                                                 float* __restrict__ y, int ldy) {
+  const ResizeYSrc src[3] = {s0, s1, s2};
+  const int CV = C >> 2;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= Wo * CV) return;
+  const int c = (u % CV) << 2, ox = u / CV;
+  const int chunks = (Ho + RESIZE_RPB - 1) / RESIZE_RPB;
+  const int n = blockIdx.y / chunks, oy0 = (blockIdx.y % chunks) * RESIZE_RPB;
+  const bool rmw = beta != 0.f;
+  for (int oy = oy0; oy < oy0 + RESIZE_RPB && oy < Ho; ++oy) {
+    float4 q[NS][4], old;
+    float w[NS][4];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const float* tn = src[k].t + ((int64_t)n * src[k].hc * Wo + ox) * C + c;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        w[k][a] = src[k].wy[oy * 4 + a];
+        q[k][a] = *reinterpret_cast<const float4*>(tn + (int64_t)src[k].iy[oy * 4 + a] * Wo * C);
+      }
+    }
+    float* dst = y + (((int64_t)n * Ho + oy) * Wo + ox) * ldy + c;
+    if (rmw) old = *reinterpret_cast<const float4*>(dst);
+    float4 o;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[0] += w[k][a] * q[k][a].x; acc[1] += w[k][a] * q[k][a].y; acc[2] += w[k][a] * q[k][a].z; acc[3] += w[k][a] * q[k][a].w;
+      }
+      if (k == 0) {
+        if (rmw) o = make_float4(beta * old.x + alpha * acc[0], beta * old.y + alpha * acc[1], beta * old.z + alpha * acc[2], beta * old.w + alpha * acc[3]);
+        else o = make_float4(alpha * acc[0], alpha * acc[1], alpha * acc[2], alpha * acc[3]);
+      } else {
+        o = make_float4(1.f * o.x + alpha * acc[0], 1.f * o.y + alpha * acc[1], 1.f * o.z + alpha * acc[2], 1.f * o.w + alpha * acc[3]);
+      }
+    }
+    *reinterpret_cast<float4*>(dst) = o;
+  }
+}
+
 // x pass of the two-pass form: t[n, yc, ox, c] = sum_b wx[ox][b] x[n, yc, ix[ox][b], c] on the COARSE rows only (hc of them); the row-uniform
 // kernel above then needs 4 row taps per output instead of 16 taps - it was bound by the texture path (16 cache-resident loads per 16 bytes
 // written), not by HBM
@@ -523,6 +571,38 @@ extern "C" int pcnn_resize_fwd(pcnn_handle h, int N, int hc, int wc, int C, int 
     hipLaunchKernelGGL(resize_fwd_kernel<1>, grid1d((int64_t)N * Ho * Wo * C), dim3(256), 0, h->stream, N, hc, wc, C, Ho, Wo, x, ldx, idx_y, wt_y, idx_x, wt_x,
                        alpha, beta, y, ldy);
   PCNN_CHECK_LAUNCH(h, "pcnn_resize_fwd");
+  return 0;
+}
+
+// y = beta y + alpha (resize(x_0) + resize(x_1) [+ resize(x_2)]) with ONE pass over y - bit-identical to nsrc calls of pcnn_resize_fwd (beta, then 1, 1).
+extern "C" int pcnn_resize_fwd_multi_eligible(int N, int C, int Ho, int Wo, int nsrc, const pcnn_resize_src* src, const float* y, int ldy) {
+  if (!src || !y || (nsrc != 2 && nsrc != 3) || C < 4 || C % 4 != 0 || ldy % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0) return 0;
+  if ((int64_t)N * ((Ho + RESIZE_RPB - 1) / RESIZE_RPB) >= 65536) return 0;
+  for (int k = 0; k < nsrc; ++k)
+    if (!src[k].x || !src[k].idx_y || !src[k].wt_y || !src[k].idx_x || !src[k].wt_x || src[k].ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(src[k].x) & 15) != 0 ||
+        src[k].hc < 1 || src[k].wc < 1) return 0;
+  return 1;
+}
+extern "C" int pcnn_resize_fwd_multi(pcnn_handle h, int N, int C, int Ho, int Wo, int nsrc, const pcnn_resize_src* src, float alpha, float beta, float* y, int ldy) {
+  PCNN_REQUIRE(h, h && pcnn_resize_fwd_multi_eligible(N, C, Ho, Wo, nsrc, src, y, ldy), "pcnn_resize_fwd_multi: not eligible (ask pcnn_resize_fwd_multi_eligible first)");
+  size_t off[4] = {0, 0, 0, 0};
+  for (int k = 0; k < nsrc; ++k) off[k + 1] = off[k] + (((size_t)N * src[k].hc * Wo * C * sizeof(float) + 255) & ~(size_t)255);
+  if (h->aux_ws_bytes < off[nsrc]) {
+    if (h->aux_ws) { pcnn_release(h, h->aux_ws); h->aux_ws = nullptr; h->aux_ws_bytes = 0; }
+    if (hipMalloc(&h->aux_ws, off[nsrc]) != hipSuccess) PCNN_FAIL(h, "pcnn_resize_fwd_multi: cannot allocate %zu B of scratch", off[nsrc]);
+    h->aux_ws_bytes = off[nsrc];
+  }
+  ResizeYSrc ys[3] = {};
+  for (int k = 0; k < nsrc; ++k) {
+    float* t = reinterpret_cast<float*>(static_cast<char*>(h->aux_ws) + off[k]);
+    hipLaunchKernelGGL(resize_x_kernel, grid1d((int64_t)N * src[k].hc * Wo * (C / 4)), dim3(256), 0, h->stream, (int64_t)N * src[k].hc, src[k].wc, C, Wo, src[k].x, src[k].ldx,
+                       src[k].idx_x, src[k].wt_x, t);
+    ys[k] = ResizeYSrc{t, src[k].idx_y, src[k].wt_y, src[k].hc};
+  }
+  const dim3 grid((unsigned)((Wo * (C / 4) + 255) / 256), (unsigned)(N * ((Ho + RESIZE_RPB - 1) / RESIZE_RPB)));
+  if (nsrc == 2) hipLaunchKernelGGL(resize_fwd_y_multi_kernel<2>, grid, dim3(256), 0, h->stream, N, C, Ho, Wo, ys[0], ys[1], ys[1], alpha, beta, y, ldy);
+  else hipLaunchKernelGGL(resize_fwd_y_multi_kernel<3>, grid, dim3(256), 0, h->stream, N, C, Ho, Wo, ys[0], ys[1], ys[2], alpha, beta, y, ldy);
+  PCNN_CHECK_LAUNCH(h, "pcnn_resize_fwd_multi");
   return 0;
 }
 

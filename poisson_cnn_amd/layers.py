@@ -614,6 +614,10 @@ class bottleneck_block_multilinearupsample(_bottleneck_base):
         assert self.out_hw(*hw) == tuple(hw)
         ops.resize_fwd(o, tuple(hw), self.method, alpha=alpha, beta=beta, out=merged)
 
+    def note_upsampled(self, o):
+        """the caller has up-sampled `o` itself (ops.resize_fwd_multi: several resize branches in one pass over the merge buffer): what forward_up remembers"""
+        self.coarse_hw = (o.shape[1], o.shape[2])
+
     def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
         self.forward_up(self.forward_convs(x, training, pooled), (x.shape[1], x.shape[2]), merged, alpha, beta, training)
 

@@ -468,6 +468,12 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
                 pending[b] = (o, done)
                 if training:
                     self._branch_streams[b] = st
+        # the resize branches at the end of the accumulation order are summed into the merge buffer in ONE read-modify-write pass (ops.resize_fwd_multi: the
+        # arithmetic and order of their separate calls, bit for bit); the transposed-convolution branches before them accumulate one by one
+        ntail = 0
+        while ntail < min(3, len(order) - 1) and hasattr(order[len(order) - 1 - ntail], 'method'):
+            ntail += 1
+        tail = []
         for i, b in enumerate(order):
             if b in pending:
                 o, done = pending[b]
@@ -475,7 +481,18 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
                 o.record_stream(torch.cuda.current_stream())
             else:
                 o = b.forward_convs(initial, training, pyr[b.f][0] if b.f in pyr else None)
+            if ntail >= 2 and i >= len(order) - ntail:
+                tail.append((i, b, o))
+                continue
             b.forward_up(o, (H, W), merged, alpha, 0.0 if i == 0 else 1.0, training)
+        if tail:
+            beta0 = 0.0 if tail[0][0] == 0 else 1.0
+            if ops.resize_fwd_multi([o for _, _, o in tail], (H, W), [b.method for _, b, _ in tail], alpha=alpha, beta=beta0, out=merged) is not None:
+                for _, b, o in tail:
+                    b.note_upsampled(o)
+            else:
+                for i, b, o in tail:
+                    b.forward_up(o, (H, W), merged, alpha, 0.0 if i == 0 else 1.0, training)
         self._pyr = pyr if training else None
         self.non_bottleneck_conv.forward(initial, out=cat[..., :F], training=training)
         x = self.post_merge_conv.forward(cat, training=training)

@@ -757,6 +757,40 @@ def resize_fwd(x, out_hw, method, *, alpha=1.0, beta=0.0, out=None):
     return y
 
 
+class ResizeSrc(ctypes.Structure):
+    """include/pcnn.h pcnn_resize_src"""
+    _fields_ = [('x', c_void_p), ('hc', c_int), ('wc', c_int), ('ldx', c_int), ('idx_y', c_void_p), ('wt_y', c_void_p), ('idx_x', c_void_p), ('wt_x', c_void_p)]
+
+
+_resize_multi = __import__('os').environ.get('PCNN_RESIZE_MULTI', '1') != '0'      # developer switch (A/B): 0 = one resize_fwd per branch
+
+
+def resize_fwd_multi(xs, out_hw, methods, *, alpha, beta, out):
+    """out = beta out + alpha (resize(xs[0]) + resize(xs[1]) [+ resize(xs[2])]) with ONE read-modify-write pass over `out` (pcnn_resize_fwd_multi): bit-identical to
+    len(xs) consecutive resize_fwd calls with beta, 1, 1.  Returns out, or None when the library declines (channel count, alignment, more than three sources)."""
+    if not _resize_multi or not 2 <= len(xs) <= 3:
+        return None
+    N, _, _, C = xs[0].shape
+    Ho, Wo = out_hw
+    arr = (ResizeSrc * len(xs))()
+    keep = []
+    nbytes = 4.0 * N * Ho * Wo * C * (2 if beta != 0.0 else 1)
+    for k, (x, m) in enumerate(zip(xs, methods)):
+        if x.shape[0] != N or x.shape[3] != C:
+            return None
+        iy, wy = resize_tables(m, x.shape[1], Ho, x.device)
+        ix, wx = resize_tables(m, x.shape[2], Wo, x.device)
+        keep += [iy, wy, ix, wx]
+        arr[k] = ResizeSrc(x.data_ptr(), x.shape[1], x.shape[2], _ld(x), iy.data_ptr(), wy.data_ptr(), ix.data_ptr(), wx.data_ptr())
+        nbytes += 4.0 * x.numel()
+    lib = _lib.load()
+    if not lib.pcnn_resize_fwd_multi_eligible(c_int(N), c_int(C), c_int(Ho), c_int(Wo), c_int(len(xs)), arr, _p(out), c_int(_ld(out))):
+        return None
+    _launch('resize_fwd', 0.0, lambda: handle().call('pcnn_resize_fwd_multi', c_int(N), c_int(C), c_int(Ho), c_int(Wo), c_int(len(xs)), arr, c_float(alpha), c_float(beta),
+                                                     _p(out), c_int(_ld(out))), nbytes)
+    return out
+
+
 def resize_bwd(dy, coarse_hw, method, *, alpha=1.0, out=None):
     N, Ho, Wo, C = dy.shape
     hc, wc = coarse_hw

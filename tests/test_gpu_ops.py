@@ -648,3 +648,24 @@ def test_channel_scale_backward_with_the_producers_activation_backward(act):
     assert float((db - db_ref).abs().max()) <= 2e-6 * float(dz_ref.abs().sum(dim=(0, 1, 2)).max())
     other = ops.Post(x.clone(), act, db)
     assert ops.channel_scale_bwd_post(x, s, dy, other) is None and not other.applied
+
+
+@pytest.mark.parametrize('nsrc,beta', [(3, 1.0), (3, 0.0), (2, 1.0)])
+def test_resize_branches_summed_in_one_pass_equal_their_separate_calls(nsrc, beta):
+    """pcnn_resize_fwd_multi (round 6): bicubic + bilinear + nearest up-sampling of three coarse images accumulated into one destination slice in ONE pass -
+    bit-identical to the separate resize_fwd calls (beta, then 1, 1); odd output sizes, a destination that is a channel slice of a wider buffer."""
+    from poisson_cnn_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(17 + nsrc)
+    N, C, Ho, Wo = 3, 32, 67, 93
+    shapes = [(3, 4), (5, 6), (9, 12)][:nsrc]
+    methods = ['bicubic', 'bilinear', 'nearest'][:nsrc]
+    xs = [torch.randn(N, h, w, C, device='cuda', generator=g) for h, w in shapes]
+    base = torch.randn(N, Ho, Wo, 2 * C, device='cuda', generator=g)
+    ref = base.clone()
+    for k, (x, m) in enumerate(zip(xs, methods)):
+        ops.resize_fwd(x, (Ho, Wo), m, alpha=0.125, beta=beta if k == 0 else 1.0, out=ref[..., C:])
+    got = base.clone()
+    assert ops.resize_fwd_multi(xs, (Ho, Wo), methods, alpha=0.125, beta=beta, out=got[..., C:]) is not None
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert ops.resize_fwd_multi(xs[:1], (Ho, Wo), methods[:1], alpha=1.0, beta=0.0, out=got[..., C:]) is None      # one source: not this entry point's business
