@@ -669,3 +669,19 @@ def test_resize_branches_summed_in_one_pass_equal_their_separate_calls(nsrc, bet
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
     assert ops.resize_fwd_multi(xs[:1], (Ho, Wo), methods[:1], alpha=1.0, beta=0.0, out=got[..., C:]) is None      # one source: not this entry point's business
+
+
+@pytest.mark.parametrize('method', ['nearest', 'bilinear', 'bicubic'])
+@pytest.mark.parametrize('C,hc,wc,Ho,Wo', [(32, 2, 3, 256, 384), (32, 9, 5, 288, 207), (16, 3, 3, 97, 131), (64, 4, 2, 130, 67)])
+def test_resize_backward_at_the_merge_branches_factors(method, C, hc, wc, Ho, Wo):
+    """The adjoint of tf.image.resize at the up-sampling factors of the multilinear bottleneck branches (32 ... 128), 16 / 32 / 64 channels, against the fp64
+    autograd twin.  (Round 6 tried its column pass with one wave per coarse pixel - the X window spread over the lanes, butterfly sum: correct, and the train step
+    did not move: 187.7 / 187.5 / 186.2 vs 185.8 / 186.4 / 186.2 ms A/B on one box - the 1.1 ms of this latency-bound kernel already runs beside other streams' work.)"""
+    from poisson_cnn_amd import ops
+    rng = np.random.default_rng(C + hc + Wo)
+    x = f32(rng.standard_normal((2, C, hc, wc)))
+    dy = f32(rng.standard_normal((2, C, Ho, Wo)))
+    xt = torch.tensor(x, requires_grad=True)
+    (torch_twin.resize2d(xt, (Ho, Wo), method) * torch.tensor(dy)).sum().backward()
+    dx = ops.resize_bwd(nhwc(dy), (hc, wc), method, alpha=0.5)
+    assert rel(nchw(dx), 0.5 * xt.grad.numpy()) < TOL_RED
