@@ -573,10 +573,17 @@ class bottleneck_block_deconvupsample(_bottleneck_base):
         return self._down_and_convs(x, training, pooled)
 
     def forward_up(self, o, hw, merged, alpha, beta, training=True):
+        self.note_upsampled(o, training)
+        self.up_into(o, hw, merged, alpha, beta)
+
+    def up_into(self, o, hw, merged, alpha, beta):
+        """the up-sampling alone (no state): merged = beta merged + alpha deconv(o); `o` / `merged` may be the same batch slice of the branch output / merge buffer"""
         assert self.out_hw(*hw) == tuple(hw), 'deconv branch must restore the input resolution'
-        self.coarse = o if training else None
         ops.deconv_fwd(o, self.store.w[self.name + '/deconv/kernel'], self.store.w[self.name + '/deconv/bias'] if self.deconv_use_bias else None,
                        tuple(hw), self.up, alpha=alpha, beta=beta, out=merged)
+
+    def note_upsampled(self, o, training=True):
+        self.coarse = o if training else None
 
     def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):
         self.forward_up(self.forward_convs(x, training, pooled), (x.shape[1], x.shape[2]), merged, alpha, beta, training)
@@ -610,12 +617,15 @@ class bottleneck_block_multilinearupsample(_bottleneck_base):
         return self._down_and_convs(x, training, pooled)
 
     def forward_up(self, o, hw, merged, alpha, beta, training=True):
-        self.coarse_hw = (o.shape[1], o.shape[2])
+        self.note_upsampled(o, training)
+        self.up_into(o, hw, merged, alpha, beta)
+
+    def up_into(self, o, hw, merged, alpha, beta):
         assert self.out_hw(*hw) == tuple(hw)
         ops.resize_fwd(o, tuple(hw), self.method, alpha=alpha, beta=beta, out=merged)
 
-    def note_upsampled(self, o):
-        """the caller has up-sampled `o` itself (ops.resize_fwd_multi: several resize branches in one pass over the merge buffer): what forward_up remembers"""
+    def note_upsampled(self, o, training=True):
+        """what forward_up remembers for the backward pass (the caller may up-sample `o` itself: ops.resize_fwd_multi, batch chunks)"""
         self.coarse_hw = (o.shape[1], o.shape[2])
 
     def forward_into(self, x, merged, alpha, beta, training=True, pooled=None):

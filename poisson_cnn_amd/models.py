@@ -468,31 +468,33 @@ class Homogeneous_Poisson_NN_Legacy(_ModelBase):
                 pending[b] = (o, done)
                 if training:
                     self._branch_streams[b] = st
-        # the resize branches at the end of the accumulation order are summed into the merge buffer in ONE read-modify-write pass (ops.resize_fwd_multi: the
-        # arithmetic and order of their separate calls, bit for bit); the transposed-convolution branches before them accumulate one by one
+        # The eight branches accumulate into the merge slice (8 x 1024^2 x 32 channels: 1.07 GB, read and written once per branch); the resize branches at the end of
+        # the order are summed in ONE read-modify-write pass (ops.resize_fwd_multi: the arithmetic and order of their separate calls, bit for bit).  (Measured and
+        # rejected, round 6: running the accumulation over batch chunks of <= 160 MB of merge slice, every branch per chunk, so that a chunk would stay in the 256 MB
+        # Infinity Cache between its passes - the single-stream step did not move, 195.4 vs 195.2 ms.)
         ntail = 0
         while ntail < min(3, len(order) - 1) and hasattr(order[len(order) - 1 - ntail], 'method'):
             ntail += 1
+        if ntail < 2:
+            ntail = 0
         tail = []
         for i, b in enumerate(order):
-            if b in pending:
-                o, done = pending[b]
+            if b in pending:                                          # (a branch is waited for right before ITS up-sampling: the later branches' convolution
+                o, done = pending[b]                                  # stages keep running on their streams under the earlier branches' up-sampling)
                 torch.cuda.current_stream().wait_event(done)
                 o.record_stream(torch.cuda.current_stream())
             else:
                 o = b.forward_convs(initial, training, pyr[b.f][0] if b.f in pyr else None)
-            if ntail >= 2 and i >= len(order) - ntail:
-                tail.append((i, b, o))
-                continue
-            b.forward_up(o, (H, W), merged, alpha, 0.0 if i == 0 else 1.0, training)
-        if tail:
-            beta0 = 0.0 if tail[0][0] == 0 else 1.0
-            if ops.resize_fwd_multi([o for _, _, o in tail], (H, W), [b.method for _, b, _ in tail], alpha=alpha, beta=beta0, out=merged) is not None:
-                for _, b, o in tail:
-                    b.note_upsampled(o)
+            b.note_upsampled(o, training)
+            if i >= len(order) - ntail:
+                tail.append((b, o))
             else:
-                for i, b, o in tail:
-                    b.forward_up(o, (H, W), merged, alpha, 0.0 if i == 0 else 1.0, training)
+                b.up_into(o, (H, W), merged, alpha, 0.0 if i == 0 else 1.0)
+        if tail:
+            beta0 = 0.0 if ntail == len(order) else 1.0
+            if ops.resize_fwd_multi([o for _, o in tail], (H, W), [b.method for b, _ in tail], alpha=alpha, beta=beta0, out=merged) is None:
+                for k, (b, o) in enumerate(tail):
+                    b.up_into(o, (H, W), merged, alpha, beta0 if k == 0 else 1.0)
         self._pyr = pyr if training else None
         self.non_bottleneck_conv.forward(initial, out=cat[..., :F], training=training)
         x = self.post_merge_conv.forward(cat, training=training)
