@@ -254,9 +254,11 @@ __global__ __launch_bounds__(1024) void fft32_fwd_multi_kernel(const FwdParams* 
 //     operations per burst the compiler's waits name exactly what they need.  (First version: `if (x < vx) store` - every store in a basic block of
 //     its own, re-using one data register: an s_waitcnt vmcnt(0) per pixel, i.e. every store COMPLETED before the next pixel was formed; the
 //     64-point inverse spent half its time there - tools/study_fft.sh.)
-template <bool TANH, bool RES, bool POST, int NPIX, int BURST, bool NT>
+struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
+// `between(b)` runs after the stores of burst b: the 32-point inverse issues a slice of the NEXT item's spectrum loads there (inv32_pipe)
+template <bool TANH, bool RES, bool POST, int NPIX, int BURST, bool NT, typename Between = NoBetween>
 __device__ __forceinline__ void epilogue_row(const InvParams& p, const float* X, float scale, int vx, unsigned pix0, int sgn, unsigned chv, float bias, float sc, float sh,
-                                             float* yimg, float* aimg, const float* rimg, const float* gimg, float* y2img, float& ymax, float& bsum) {
+                                             float* yimg, float* aimg, const float* rimg, const float* gimg, float* y2img, float& ymax, float& bsum, Between between = Between()) {
   auto st = [](float v, float* q) { if (NT) __builtin_nontemporal_store(v, q); else *q = v; };
   float first_y = 0.f, first_a = 0.f, first_y2 = 0.f;              // what the row's first pixel stores (pixels beyond vx repeat it)
 #pragma unroll
@@ -312,6 +314,7 @@ __device__ __forceinline__ void epilogue_row(const InvParams& p, const float* X,
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    between(x0b / BURST);
   }
 }
 
@@ -343,12 +346,31 @@ __device__ __forceinline__ void inv_request(const float* in, int wave, int half,
   }
 }
 
+// entries [J0, J0 + NJ) of inv_request's B (interleaved row order: a uniform pointer step): the slice of the next item's loads that one epilogue burst issues
+template <int J0, int NJ>
+__device__ __forceinline__ void inv_request_slice(const float* in, int wave, int half, int c, float (&B)[32]) {
+  const float* sp = in + (wave == 0 ? 0 : (64 + 64 * (wave - 1)) * RS);
+  const unsigned lo = (unsigned)((wave == 0 ? 32 : 2) * RS * half + c);
+  const int step = (wave == 0 ? 2 : 4) * RS;
+#pragma unroll
+  for (int j = J0; j < J0 + NJ; ++j) B[j] = FFT_STUDY(2) ? 1.f : NT_LOAD(8, &(sp + (j >> 4) * RS + (j & 15) * step)[lo]);
+}
+
 // Prefetch of the next item's spectrum column (32 registers that stay live through the x axis and the epilogue): with it the epilogue variants spill
 // 20-26 registers, and a spill costs more than the prefetch hides (scratch traffic shares the memory pipe) - off; measured both ways, DESIGN.md 4.8.
 #ifndef PCNN_INV32_PREFETCH
 #define PCNN_INV32_PREFETCH 0
 #endif
 constexpr bool INV32_PREFETCH = PCNN_INV32_PREFETCH;
+// Round 6: the next item's 32 spectrum loads issued in slices BETWEEN the epilogue's store bursts (each slice into the registers of the pixels the burst has just
+// stored), so that their latency runs under the rest of the epilogue and the barrier instead of behind this item's stores in the in-order memory counter.  Measured per
+// epilogue variant on one box (profiles/r06_step_ab_inv32_pipe.txt, ms per train step, plain / bursts of 4 / bursts of 4 + pipelined loads): plain epilogue
+// 16.1 / 16.1 / 15.6, residual + POST 3.30 / 3.29 / 3.2 - but POST alone 7.4 / 8.0 / 8.2 and residual alone 4.1 / 4.5 / 4.7 (their bursts of 8 hide more than the
+// pipelining returns).  So: pipelined with bursts of four where the epilogue has neither or both extra inputs, the round-5 form otherwise.  PCNN_INV32_PIPE=0: off.
+#ifndef PCNN_INV32_PIPE
+#define PCNN_INV32_PIPE 1
+#endif
+template <bool RES, bool POST> constexpr bool inv32_pipe() { return PCNN_INV32_PIPE && !PCNN_INV32_PREFETCH && PCNN_SP_P == 1 && RES == POST; }
 
 #ifndef PCNN_ST32_NT
 #define PCNN_ST32_NT 0
@@ -362,16 +384,17 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
   const int total = p.ntile * p.groups;
   int item = blockIdx.x;
   if (item >= total) return;
+  constexpr bool INV32_PIPE = inv32_pipe<RES, POST>();
   float B[32];
-  if (INV32_PREFETCH) inv_request(p.sp + sp_item32(item), wave, half, c, B);
+  if (INV32_PREFETCH || INV32_PIPE) inv_request(p.sp + sp_item32(item), wave, half, c, B);
   float ymax = 0.f, bsum = 0.f;
-  constexpr int BURST = (POST && RES) ? 4 : 8;                       // pixels per epilogue burst (registers: 128 per lane; epilogue_row keeps up to 5 values per pixel)
+  constexpr int BURST = (RES == POST) ? 4 : 8;                       // pixels per epilogue burst (registers: 128 per lane; epilogue_row keeps up to 5 values per pixel)
   for (;;) {
     const int next = item + gridDim.x;
     // ---- y axis inverse (unnormalised: the 1 / 1024 of both axes is applied once, after the x axis)
     {
       float V[32];
-      if (!INV32_PREFETCH) inv_request(p.sp + sp_item32(item), wave, half, c, B);
+      if (!INV32_PREFETCH && !INV32_PIPE) inv_request(p.sp + sp_item32(item), wave, half, c, B);
 #pragma unroll
       for (int i = 0; i < 32; ++i) V[i] = B[i];
       if (INV32_PREFETCH && next < total) inv_request(p.sp + sp_item32(next), wave, half, c, B);      // lands under the rest of this item
@@ -418,6 +441,9 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
       const int vy = min(p.Vy, p.Ho - y0), vx = min(p.Vx, p.Wo - x0 - subx);
       const int chan = g * p.cstride + cc;
       const bool cok = cc < p.cvalid && chan < p.C;
+      // (pipelined variants) the spectrum of the item after this one; the last item re-requests itself: a static number of loads per pass, no branch around them
+      const float* nin = p.sp + sp_item32(next < total ? next : item);
+      bool piped = false;
       if (2 * wave < vy) {                                            // uniform: at least the even row of this wave is an output row
         const int yy = 2 * wave + half;
         const bool rowok = cok && yy < vy && vx > 0;                  // (vx <= 0: this lane's packed tile lies beyond the image - its first pixel does not exist)
@@ -450,9 +476,29 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
         const float* gimg = POST ? p.gact + ipix * p.ld_gact : nullptr;
         float* y2img = (POST && p.y2) ? p.y2 + ipix * p.ld_y2 : nullptr;
         const unsigned chv = (unsigned)chan;
+        if (INV32_PIPE) {
+          auto between = [&](int b) {
+            if constexpr (BURST == 8) {
+              if (b == 0) inv_request_slice<0, 8>(nin, wave, half, c, B); else if (b == 1) inv_request_slice<8, 8>(nin, wave, half, c, B);
+              else if (b == 2) inv_request_slice<16, 8>(nin, wave, half, c, B); else inv_request_slice<24, 8>(nin, wave, half, c, B);
+            } else {
+              if (b == 0) inv_request_slice<0, 4>(nin, wave, half, c, B); else if (b == 1) inv_request_slice<4, 4>(nin, wave, half, c, B);
+              else if (b == 2) inv_request_slice<8, 4>(nin, wave, half, c, B); else if (b == 3) inv_request_slice<12, 4>(nin, wave, half, c, B);
+              else if (b == 4) inv_request_slice<16, 4>(nin, wave, half, c, B); else if (b == 5) inv_request_slice<20, 4>(nin, wave, half, c, B);
+              else if (b == 6) inv_request_slice<24, 4>(nin, wave, half, c, B); else inv_request_slice<28, 4>(nin, wave, half, c, B);
+            }
+          };
+          if (rowok && !FFT_STUDY(1)) {
+            epilogue_row<TANH, RES, POST, T, BURST, PCNN_ST32_NT != 0>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum, between);
+          } else {
+            inv_request(nin, wave, half, c, B);
+          }
+          piped = true;
+        } else
         if (rowok && !FFT_STUDY(1))
           epilogue_row<TANH, RES, POST, T, BURST, PCNN_ST32_NT != 0>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
       }
+      if (INV32_PIPE && !piped) inv_request(nin, wave, half, c, B);    // waves without an output row in this tile
     }
     if (next >= total) break;
     item = __builtin_amdgcn_readfirstlane(next);
