@@ -1,13 +1,14 @@
 #!/bin/bash
-# Everything under profiles/r05_* (run on the GPU box from the repo root through gpurun; two calls, because the PMC summaries of stage 1 must sit
+# The recurring evidence under profiles/<round>_* (round 6: R=r06; the A/B tables of that round come from tools/step_kernels_ab.sh and environment switches, see
+# profiles/README.md) (run on the GPU box from the repo root through gpurun; two calls, because the PMC summaries of stage 1 must sit
 # in profiles/ - copied there by hand between the calls - before stage 2's bench.py looks for a summary whose source stamp matches its tree):
 #   gpurun --timeout 1200 -- 'bash tools/collect_evidence.sh 1'     GPU test suite, rocprofv3 kernel stats + three --pmc passes per workload / mode
-#   cp gpurun_out/evidence/r05_c?_pmc_summary_*.json gpurun_out/evidence/r05_c?_kernel_stats_*.csv profiles/
+#   cp gpurun_out/evidence/r06_c?_pmc_summary_*.json gpurun_out/evidence/r06_c?_kernel_stats_*.csv profiles/
 #   gpurun --timeout 1200 -- 'bash tools/collect_evidence.sh 2'     bench.py (the driver's command), layer / model / dataset probes, training curves
 # then copy gpurun_out/evidence/* into profiles/ (gpurun merges gpurun_out/ back).
 set -o pipefail
 ROOT=$(pwd)
-R=r05
+R=${ROUND:-r06}
 STAGE=${1:-1}
 OUT=$ROOT/gpurun_out/evidence
 mkdir -p "$OUT"
@@ -30,5 +31,8 @@ else
   python tools/bench_pcnn.py 2>&1 | grep -v amdgpu > "$OUT/${R}_next_models_throughput.txt"
   python tools/train_curve.py --steps 60 2>&1 | grep -v amdgpu > "$OUT/${R}_train_curve_reverse.txt"
   python tools/train_curve.py --steps 80 --data numerical 2>&1 | grep -v amdgpu > "$OUT/${R}_train_curve_numerical.txt"
+  bash tools/collect_train_shipped.sh $R > "$OUT/collect_train_shipped.log" 2>&1; cp "$ROOT/gpurun_out/train_shipped_${R}.txt" "$OUT/${R}_train_shipped.txt"     # the reference's real training workload
+  bash tools/hip_calls_steady.sh 30 60 > /dev/null 2>&1; cp "$ROOT/gpurun_out/train_shipped_hip_steady.txt" "$OUT/${R}_train_shipped_hip_steady.txt"
+  python tools/probe_tile_shipped.py 50 2>&1 | grep -v amdgpu > "$OUT/${R}_probe_tile_shipped.txt"
 fi
 echo "evidence stage $STAGE written to $OUT"
