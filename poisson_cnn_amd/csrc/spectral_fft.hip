@@ -254,15 +254,26 @@ __global__ __launch_bounds__(1024) void fft32_fwd_multi_kernel(const FwdParams* 
 //     operations per burst the compiler's waits name exactly what they need.  (First version: `if (x < vx) store` - every store in a basic block of
 //     its own, re-using one data register: an s_waitcnt vmcnt(0) per pixel, i.e. every store COMPLETED before the next pixel was formed; the
 //     64-point inverse spent half its time there - tools/study_fft.sh.)
+// Round 6: a whole burst beyond the row's end is skipped (the round-5 form re-stored the row's first pixel for every pixel beyond vx so that the number of
+// memory operations per row stayed static; with bursts of four, a quarter of the bursts of an 11-tap layer and an eighth of a 7-tap layer's lie wholly beyond
+// the end).  One uniform branch per burst; measured on the 32-point inverse (profiles/r06_step_ab_epilogue_skip.txt): -3 % on the pipelined variants (bit 1),
+// -2...3 % on the others (bit 2).  The 64-point inverse keeps the static form (round 5: -1.3 % forward, +2 % backward with skipping).
+#ifndef PCNN_EPI_SKIP
+#define PCNN_EPI_SKIP 3
+#endif
 struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
 // `between(b)` runs after the stores of burst b: the 32-point inverse issues a slice of the NEXT item's spectrum loads there (inv32_pipe)
 template <bool TANH, bool RES, bool POST, int NPIX, int BURST, bool NT, typename Between = NoBetween>
 __device__ __forceinline__ void epilogue_row(const InvParams& p, const float* X, float scale, int vx, unsigned pix0, int sgn, unsigned chv, float bias, float sc, float sh,
-                                             float* yimg, float* aimg, const float* rimg, const float* gimg, float* y2img, float& ymax, float& bsum, Between between = Between()) {
+                                             float* yimg, float* aimg, const float* rimg, const float* gimg, float* y2img, float& ymax, float& bsum, Between between = Between(),
+                                             int vx_uniform = NPIX) {
   auto st = [](float v, float* q) { if (NT) __builtin_nontemporal_store(v, q); else *q = v; };
   float first_y = 0.f, first_a = 0.f, first_y2 = 0.f;              // what the row's first pixel stores (pixels beyond vx repeat it)
 #pragma unroll
   for (int x0b = 0; x0b < NPIX; x0b += BURST) {
+#if PCNN_EPI_SKIP
+    if (x0b >= vx_uniform) { between(x0b / BURST); continue; }      // a whole burst beyond the row's end (uniform): nothing to re-store
+#endif
     float rv[BURST], gv[BURST], oy[BURST], oa[BURST], oy2[BURST];
     if (RES) {
 #pragma unroll
@@ -489,14 +500,16 @@ __global__ __launch_bounds__(1024) void fft32_inv_kernel(InvParams p) {
             }
           };
           if (rowok && !FFT_STUDY(1)) {
-            epilogue_row<TANH, RES, POST, T, BURST, PCNN_ST32_NT != 0>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum, between);
+            epilogue_row<TANH, RES, POST, T, BURST, PCNN_ST32_NT != 0>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum, between,
+                                                                       p.pack > 1 ? T : __builtin_amdgcn_readfirstlane(min(p.Vx, p.Wo - x0)));
           } else {
             inv_request(nin, wave, half, c, B);
           }
           piped = true;
         } else
         if (rowok && !FFT_STUDY(1))
-          epilogue_row<TANH, RES, POST, T, BURST, PCNN_ST32_NT != 0>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
+          epilogue_row<TANH, RES, POST, T, BURST, PCNN_ST32_NT != 0>(p, X, 1.f / 1024.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum, NoBetween(),
+                                                                     (PCNN_EPI_SKIP & 2) ? (p.pack > 1 ? T : __builtin_amdgcn_readfirstlane(min(p.Vx, p.Wo - x0))) : T);
       }
       if (INV32_PIPE && !piped) inv_request(nin, wave, half, c, B);    // waves without an output row in this tile
     }
