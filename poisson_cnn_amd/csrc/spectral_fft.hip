@@ -257,9 +257,10 @@ __global__ __launch_bounds__(1024) void fft32_fwd_multi_kernel(const FwdParams* 
 // Round 6: a whole burst beyond the row's end is skipped (the round-5 form re-stored the row's first pixel for every pixel beyond vx so that the number of
 // memory operations per row stayed static; with bursts of four, a quarter of the bursts of an 11-tap layer and an eighth of a 7-tap layer's lie wholly beyond
 // the end).  One uniform branch per burst; measured on the 32-point inverse (profiles/r06_step_ab_epilogue_skip.txt): -3 % on the pipelined variants (bit 1),
-// -2...3 % on the others (bit 2).  The 64-point inverse keeps the static form (round 5: -1.3 % forward, +2 % backward with skipping).
+// -2...3 % on the others (bit 2); on the 64-point inverse (bit 4; bursts of eight: a 15-tap row has 50 of 64 pixels) -3...7 % per variant - round 5 had measured
+// -1.3 % forward / +2 % backward for the same idea, before the stores went non-temporal.
 #ifndef PCNN_EPI_SKIP
-#define PCNN_EPI_SKIP 3
+#define PCNN_EPI_SKIP 7
 #endif
 struct NoBetween { __device__ __forceinline__ void operator()(int) const {} };
 // `between(b)` runs after the stores of burst b: the 32-point inverse issues a slice of the NEXT item's spectrum loads there (inv32_pipe)
@@ -878,7 +879,10 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
   if (tid < 64) { TW[2 * tid] = cos64(((tid >> 4) * (tid & 15)) & 63); TW[2 * tid + 1] = -sin64(((tid >> 4) * (tid & 15)) & 63); }
   const float* const tw = TW + lg * 32;
   float ymax = 0.f, bsum = 0.f;
-  constexpr int BURST = 8;
+#ifndef PCNN_INV64_BURST
+#define PCNN_INV64_BURST 8
+#endif
+  constexpr int BURST = PCNN_INV64_BURST;
   for (;;) {
     const int next = v + gridDim.x;
     int tg, hf;
@@ -1017,7 +1021,8 @@ __global__ __launch_bounds__(512) void fft64_inv_kernel(InvParams p, int nvirt) 
         unsigned pix0 = (unsigned)(prow * p.Wo + pcol);
         asm volatile("" : "+v"(pix0));                               // opaque: per-pixel offsets are recomputed, not hoisted into registers per tensor
         if (cok && yy < vy && !FFT_STUDY(1))
-          epilogue_row<TANH, RES, POST, T64, BURST, PCNN_ST64_NT != 0>(p, R[u], 1.f / 4096.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum);
+          epilogue_row<TANH, RES, POST, T64, BURST, PCNN_ST64_NT != 0>(p, R[u], 1.f / 4096.f, vx, pix0, sgn, chv, bias, sc, sh, yimg, aimg, rimg, gimg, y2img, ymax, bsum, NoBetween(),
+                                                                       (PCNN_EPI_SKIP & 4) ? __builtin_amdgcn_readfirstlane(vx) : T64);
       }
     }
     if (next >= nvirt) break;
